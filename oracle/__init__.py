@@ -1,0 +1,222 @@
+"""CPU ORACLE loader (test infrastructure, NOT the product).
+
+ctypes binding of oracle/libtk_oracle.so (built by oracle/Makefile from tk_oracle.c).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product library
+(libtkmk_hip.so) never links or calls it.  Buffers are numpy uint8 arrays holding plain little-endian
+field elements (Fr 32 B, Fq 48 B, G1 affine 96 B) — see tk_oracle.h for the parity status.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE, "libtk_oracle.so"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libtk_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.tko_ntt.restype = ctypes.c_int
+        _LIB.tko_bintt.restype = ctypes.c_int
+        _LIB.tko_dft_naive.restype = ctypes.c_int
+        _LIB.tko_get_root_of_unity.restype = ctypes.c_int
+        _LIB.tko_g1_on_curve.restype = ctypes.c_int
+        _LIB.tko_num_threads.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _sz(n):
+    return ctypes.c_size_t(n)
+
+
+def _u64(n):
+    return ctypes.c_uint64(n)
+
+
+def _binop(name, width):
+    def f(a, b):
+        out = np.empty_like(a)
+        getattr(lib(), name)(_p(a), _p(b), _p(out), _sz(a.size // width))
+        return out
+    return f
+
+
+fr_add = _binop("tko_fr_add", 32)
+fr_sub = _binop("tko_fr_sub", 32)
+fr_mul = _binop("tko_fr_mul", 32)
+fq_add = _binop("tko_fq_add", 48)
+fq_sub = _binop("tko_fq_sub", 48)
+fq_mul = _binop("tko_fq_mul", 48)
+
+
+def fr_inv(a):
+    out = np.empty_like(a)
+    lib().tko_fr_inv(_p(a), _p(out), _sz(a.size // 32))
+    return out
+
+
+def fq_inv(a):
+    out = np.empty_like(a)
+    lib().tko_fq_inv(_p(a), _p(out), _sz(a.size // 48))
+    return out
+
+
+def fr_scalar_mul(s, a):
+    out = np.empty_like(a)
+    lib().tko_fr_scalar_mul(_p(s), _p(a), _p(out), _sz(a.size // 32))
+    return out
+
+
+def fr_scalar_add(s, a):
+    out = np.empty_like(a)
+    lib().tko_fr_scalar_add(_p(s), _p(a), _p(out), _sz(a.size // 32))
+    return out
+
+
+def fr_scalar_sub(s, a):
+    out = np.empty_like(a)
+    lib().tko_fr_scalar_sub(_p(s), _p(a), _p(out), _sz(a.size // 32))
+    return out
+
+
+def fr_pow(a, e):
+    out = np.empty(32, np.uint8)
+    lib().tko_fr_pow_u64(_p(a), _u64(e), _p(out))
+    return out
+
+
+def fr_transpose(a, rows, cols):
+    out = np.empty_like(a)
+    lib().tko_fr_transpose(_p(a), _sz(rows), _sz(cols), _p(out))
+    return out
+
+
+def fr_random(seed, n, first=0):
+    out = np.empty(32 * n, np.uint8)
+    lib().tko_fr_random(_u64(seed), _sz(first), _sz(n), _p(out))
+    return out
+
+
+def root_of_unity(max_size):
+    out = np.empty(32, np.uint8)
+    if lib().tko_get_root_of_unity(_u64(max_size), _p(out)) != 0:
+        raise ValueError("no root of unity of that order")
+    return out
+
+
+def ntt(a, n, batch=1, columns_batch=False, inverse=False, coset_gen=None):
+    out = np.empty_like(a)
+    rc = lib().tko_ntt(_p(a), _sz(n), _sz(batch), int(columns_batch), int(inverse), _p(coset_gen), _p(out))
+    if rc != 0:
+        raise ValueError("tko_ntt failed: %d" % rc)
+    return out
+
+
+def bintt(a, x_size, y_size, inverse=False, coset_x=None, coset_y=None):
+    out = np.empty_like(a)
+    rc = lib().tko_bintt(_p(a), _sz(x_size), _sz(y_size), int(inverse), _p(coset_x), _p(coset_y), _p(out))
+    if rc != 0:
+        raise ValueError("tko_bintt failed: %d" % rc)
+    return out
+
+
+def dft_naive(a, n):
+    out = np.empty_like(a)
+    rc = lib().tko_dft_naive(_p(a), _sz(n), _p(out))
+    if rc != 0:
+        raise ValueError("tko_dft_naive failed: %d" % rc)
+    return out
+
+
+def g1_generator():
+    out = np.empty(96, np.uint8)
+    lib().tko_g1_generator(_p(out))
+    return out
+
+
+def g1_on_curve(p):
+    return bool(lib().tko_g1_on_curve(_p(p)))
+
+
+def g1_add(p, q):
+    out = np.empty(96, np.uint8)
+    lib().tko_g1_add(_p(p), _p(q), _p(out))
+    return out
+
+
+def g1_neg(p):
+    out = np.empty(96, np.uint8)
+    lib().tko_g1_neg(_p(p), _p(out))
+    return out
+
+
+def g1_scalar_mul(s, p):
+    out = np.empty(96, np.uint8)
+    lib().tko_g1_scalar_mul(_p(s), _p(p), _p(out))
+    return out
+
+
+def g1_batch_scalar_mul(s, p):
+    n = s.size // 32
+    out = np.empty(96 * n, np.uint8)
+    lib().tko_g1_batch_scalar_mul(_p(s), _p(p), _sz(n), _p(out))
+    return out
+
+
+def g1_random_bases(seed, n, first=0):
+    out = np.empty(96 * n, np.uint8)
+    lib().tko_g1_random_bases(_u64(seed), _sz(first), _sz(n), _p(out))
+    return out
+
+
+def g1_msm_naive(s, p):
+    out = np.empty(96, np.uint8)
+    lib().tko_g1_msm_naive(_p(s), _p(p), _sz(s.size // 32), _p(out))
+    return out
+
+
+def g1_msm(s, p, threads=0):
+    out = np.empty(96, np.uint8)
+    lib().tko_g1_msm(_p(s), _p(p), _sz(s.size // 32), int(threads), _p(out))
+    return out
+
+
+def g1_proj_to_affine(p144):
+    out = np.empty(96, np.uint8)
+    lib().tko_g1_proj_to_affine(_p(p144), _p(out))
+    return out
+
+
+def num_threads():
+    return lib().tko_num_threads()
+
+
+# ---- helpers shared by tests: python int <-> plain LE bytes ----
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+P_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+
+
+def to_bytes(vals, width):
+    return np.frombuffer(b"".join(int(v).to_bytes(width, "little") for v in vals), np.uint8).copy()
+
+
+def to_ints(buf, width):
+    raw = buf.tobytes()
+    return [int.from_bytes(raw[i:i + width], "little") for i in range(0, len(raw), width)]

@@ -1,0 +1,758 @@
+/*
+ * tk_oracle.c — CPU ORACLE (test infrastructure, NOT the product). See tk_oracle.h for the
+ * scope, the reference call sites each routine restates and the parity status.
+ *
+ * Build: gcc -O2 -fopenmp -fPIC -shared (oracle/Makefile).
+ */
+#include "tk_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+/* ------------------------------------------------------------------------------------------
+ * Generic Montgomery field over N 64-bit limbs, instantiated for Fr (N=4) and Fq (N=6).
+ * Constants other than the modulus are derived at first use, so the only hard-coded numbers
+ * are r and p themselves (r is pinned by the .r1cs headers; p by the on-curve pins).
+ * ------------------------------------------------------------------------------------------ */
+#define DEFINE_FIELD(F, N)                                                                     \
+    typedef struct { u64 l[N]; } F##_t;                                                        \
+    static F##_t F##_P, F##_R1, F##_R2;                                                        \
+    static u64 F##_INV;                                                                        \
+    static int F##_ready = 0;                                                                  \
+    static inline int F##_geq_p(const F##_t *a) {                                              \
+        for (int i = N - 1; i >= 0; i--) {                                                     \
+            if (a->l[i] > F##_P.l[i]) return 1;                                                \
+            if (a->l[i] < F##_P.l[i]) return 0;                                                \
+        }                                                                                      \
+        return 1;                                                                              \
+    }                                                                                          \
+    static inline u64 F##_sub_p(F##_t *a) {                                                    \
+        u64 br = 0;                                                                            \
+        for (int i = 0; i < N; i++) {                                                          \
+            u128 d = (u128)a->l[i] - F##_P.l[i] - br;                                          \
+            a->l[i] = (u64)d;                                                                  \
+            br = (u64)(d >> 64) & 1;                                                           \
+        }                                                                                      \
+        return br;                                                                             \
+    }                                                                                          \
+    static inline void F##_add(F##_t *o, const F##_t *a, const F##_t *b) {                     \
+        u64 c = 0;                                                                             \
+        F##_t t;                                                                               \
+        for (int i = 0; i < N; i++) {                                                          \
+            u128 s = (u128)a->l[i] + b->l[i] + c;                                              \
+            t.l[i] = (u64)s;                                                                   \
+            c = (u64)(s >> 64);                                                                \
+        }                                                                                      \
+        if (c || F##_geq_p(&t)) F##_sub_p(&t);                                                 \
+        *o = t;                                                                                \
+    }                                                                                          \
+    static inline void F##_sub(F##_t *o, const F##_t *a, const F##_t *b) {                     \
+        u64 br = 0;                                                                            \
+        F##_t t;                                                                               \
+        for (int i = 0; i < N; i++) {                                                          \
+            u128 d = (u128)a->l[i] - b->l[i] - br;                                             \
+            t.l[i] = (u64)d;                                                                   \
+            br = (u64)(d >> 64) & 1;                                                           \
+        }                                                                                      \
+        if (br) {                                                                              \
+            u64 c = 0;                                                                         \
+            for (int i = 0; i < N; i++) {                                                      \
+                u128 s = (u128)t.l[i] + F##_P.l[i] + c;                                        \
+                t.l[i] = (u64)s;                                                               \
+                c = (u64)(s >> 64);                                                            \
+            }                                                                                  \
+        }                                                                                      \
+        *o = t;                                                                                \
+    }                                                                                          \
+    static inline void F##_neg(F##_t *o, const F##_t *a) {                                     \
+        F##_t z;                                                                               \
+        memset(&z, 0, sizeof z);                                                               \
+        F##_sub(o, &z, a);                                                                     \
+    }                                                                                          \
+    static inline int F##_is_zero(const F##_t *a) {                                            \
+        u64 x = 0;                                                                             \
+        for (int i = 0; i < N; i++) x |= a->l[i];                                              \
+        return x == 0;                                                                         \
+    }                                                                                          \
+    static inline int F##_eq(const F##_t *a, const F##_t *b) {                                 \
+        u64 x = 0;                                                                             \
+        for (int i = 0; i < N; i++) x |= a->l[i] ^ b->l[i];                                    \
+        return x == 0;                                                                         \
+    }                                                                                          \
+    /* CIOS Montgomery product: o = a*b/2^(64N) mod p */                                       \
+    static inline void F##_mul(F##_t *o, const F##_t *a, const F##_t *b) {                     \
+        u64 t[N + 2];                                                                          \
+        memset(t, 0, sizeof t);                                                                \
+        for (int i = 0; i < N; i++) {                                                          \
+            u64 c = 0;                                                                         \
+            for (int j = 0; j < N; j++) {                                                      \
+                u128 s = (u128)a->l[j] * b->l[i] + t[j] + c;                                   \
+                t[j] = (u64)s;                                                                 \
+                c = (u64)(s >> 64);                                                            \
+            }                                                                                  \
+            u128 s = (u128)t[N] + c;                                                           \
+            t[N] = (u64)s;                                                                     \
+            t[N + 1] = (u64)(s >> 64);                                                         \
+            u64 m = t[0] * F##_INV;                                                            \
+            s = (u128)m * F##_P.l[0] + t[0];                                                   \
+            c = (u64)(s >> 64);                                                                \
+            for (int j = 1; j < N; j++) {                                                      \
+                s = (u128)m * F##_P.l[j] + t[j] + c;                                           \
+                t[j - 1] = (u64)s;                                                             \
+                c = (u64)(s >> 64);                                                            \
+            }                                                                                  \
+            s = (u128)t[N] + c;                                                                \
+            t[N - 1] = (u64)s;                                                                 \
+            t[N] = t[N + 1] + (u64)(s >> 64);                                                  \
+        }                                                                                      \
+        F##_t r;                                                                               \
+        memcpy(r.l, t, sizeof r.l);                                                            \
+        if (t[N] || F##_geq_p(&r)) F##_sub_p(&r);                                              \
+        *o = r;                                                                                \
+    }                                                                                          \
+    static inline void F##_sqr(F##_t *o, const F##_t *a) { F##_mul(o, a, a); }                 \
+    static void F##_init(const u64 *p) {                                                       \
+        memcpy(F##_P.l, p, sizeof F##_P.l);                                                    \
+        u64 inv = 1;                                                                           \
+        for (int i = 0; i < 6; i++) inv *= 2 - p[0] * inv; /* p^-1 mod 2^64 (Newton) */        \
+        F##_INV = (u64)0 - inv;                                                                \
+        /* R mod p by 64N doublings of 1, R^2 mod p by 64N more */                             \
+        F##_t x;                                                                               \
+        memset(&x, 0, sizeof x);                                                               \
+        x.l[0] = 1;                                                                            \
+        for (int i = 0; i < 64 * N; i++) F##_add(&x, &x, &x);                                  \
+        F##_R1 = x;                                                                            \
+        for (int i = 0; i < 64 * N; i++) F##_add(&x, &x, &x);                                  \
+        F##_R2 = x;                                                                            \
+        F##_ready = 1;                                                                         \
+    }                                                                                          \
+    static inline void F##_to_mont(F##_t *o, const F##_t *a) { F##_mul(o, a, &F##_R2); }       \
+    static inline void F##_from_mont(F##_t *o, const F##_t *a) {                               \
+        F##_t one;                                                                             \
+        memset(&one, 0, sizeof one);                                                           \
+        one.l[0] = 1;                                                                          \
+        F##_mul(o, a, &one);                                                                   \
+    }                                                                                          \
+    /* plain LE bytes (value reduced mod p if needed) -> Montgomery */                         \
+    static inline void F##_load(F##_t *o, const uint8_t *b) {                                  \
+        F##_t t;                                                                               \
+        memcpy(t.l, b, 8 * N);                                                                 \
+        while (F##_geq_p(&t)) F##_sub_p(&t);                                                   \
+        F##_to_mont(o, &t);                                                                    \
+    }                                                                                          \
+    static inline void F##_store(uint8_t *b, const F##_t *a) {                                 \
+        F##_t t;                                                                               \
+        F##_from_mont(&t, a);                                                                  \
+        memcpy(b, t.l, 8 * N);                                                                 \
+    }                                                                                          \
+    /* o = a^e, e given as nl 64-bit limbs (plain) */                                          \
+    static void F##_pow(F##_t *o, const F##_t *a, const u64 *e, int nl) {                      \
+        F##_t acc = F##_R1, base = *a;                                                         \
+        for (int i = 0; i < nl; i++)                                                           \
+            for (int b = 0; b < 64; b++) {                                                     \
+                if ((e[i] >> b) & 1) F##_mul(&acc, &acc, &base);                               \
+                F##_sqr(&base, &base);                                                         \
+            }                                                                                  \
+        *o = acc;                                                                              \
+    }                                                                                          \
+    /* Fermat inverse, inv(0)=0 */                                                             \
+    static void F##_inv(F##_t *o, const F##_t *a) {                                            \
+        u64 e[N];                                                                              \
+        memcpy(e, F##_P.l, sizeof e);                                                          \
+        e[0] -= 2; /* p is odd and > 2: no borrow */                                           \
+        F##_pow(o, a, e, N);                                                                   \
+    }
+
+DEFINE_FIELD(fr, 4)
+DEFINE_FIELD(fq, 6)
+
+/* r: prime field of every committed .r1cs (qap-compiler/subcircuits/library/r1cs, header prime) */
+static const u64 FR_MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL,
+                              0x73eda753299d7d48ULL};
+/* p: BLS12-381 base field */
+static const u64 FQ_MOD[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
+                              0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
+
+static fq_t FQ_B;        /* curve constant 4 (Montgomery) */
+static fr_t FR_ROOT32;   /* w_{2^32} = 5^((r-1)/2^32) (Montgomery) */
+
+static void tko_init(void) {
+    if (fr_ready && fq_ready) return;
+#pragma omp critical(tko_init_lock)
+    {
+        if (!(fr_ready && fq_ready)) {
+            fq_init(FQ_MOD);
+            fq_t four;
+            memset(&four, 0, sizeof four);
+            four.l[0] = 4;
+            fq_to_mont(&FQ_B, &four);
+            /* root of unity before publishing fr_ready */
+            memcpy(fr_P.l, FR_MOD, sizeof fr_P.l);
+            fr_init(FR_MOD);
+            fr_t five;
+            memset(&five, 0, sizeof five);
+            five.l[0] = 5;
+            fr_to_mont(&five, &five);
+            /* (r-1) >> 32 */
+            u64 e[4];
+            for (int i = 0; i < 4; i++) e[i] = FR_MOD[i];
+            e[0] -= 1;
+            for (int i = 0; i < 4; i++) e[i] = (e[i] >> 32) | (i < 3 ? e[i + 1] << 32 : 0);
+            fr_pow(&FR_ROOT32, &five, e, 4);
+        }
+    }
+}
+
+int tko_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise Fr / Fq (ICICLE VecOps as used by libs/src/vector_operations/mod.rs:34-139)
+ * ------------------------------------------------------------------------------------------ */
+#define VEC_BINOP(NAME, F, SZ, OP)                                                             \
+    void NAME(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {                    \
+        tko_init();                                                                            \
+        _Pragma("omp parallel for schedule(static)") for (size_t i = 0; i < n; i++) {          \
+            F##_t x, y, z;                                                                     \
+            F##_load(&x, a + SZ * i);                                                          \
+            F##_load(&y, b + SZ * i);                                                          \
+            OP(&z, &x, &y);                                                                    \
+            F##_store(out + SZ * i, &z);                                                       \
+        }                                                                                      \
+    }
+VEC_BINOP(tko_fr_add, fr, 32, fr_add)
+VEC_BINOP(tko_fr_sub, fr, 32, fr_sub)
+VEC_BINOP(tko_fr_mul, fr, 32, fr_mul)
+VEC_BINOP(tko_fq_add, fq, 48, fq_add)
+VEC_BINOP(tko_fq_sub, fq, 48, fq_sub)
+VEC_BINOP(tko_fq_mul, fq, 48, fq_mul)
+
+void tko_fr_inv(const uint8_t *a, uint8_t *out, size_t n) {
+    tko_init();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        fr_t x, y;
+        fr_load(&x, a + 32 * i);
+        fr_inv(&y, &x);
+        fr_store(out + 32 * i, &y);
+    }
+}
+void tko_fq_inv(const uint8_t *a, uint8_t *out, size_t n) {
+    tko_init();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        fq_t x, y;
+        fq_load(&x, a + 48 * i);
+        fq_inv(&y, &x);
+        fq_store(out + 48 * i, &y);
+    }
+}
+void tko_fr_scalar_mul(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t n) {
+    tko_init();
+    fr_t k;
+    fr_load(&k, s);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        fr_t x;
+        fr_load(&x, a + 32 * i);
+        fr_mul(&x, &x, &k);
+        fr_store(out + 32 * i, &x);
+    }
+}
+void tko_fr_scalar_add(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t n) {
+    tko_init();
+    fr_t k;
+    fr_load(&k, s);
+    for (size_t i = 0; i < n; i++) {
+        fr_t x;
+        fr_load(&x, a + 32 * i);
+        fr_add(&x, &x, &k);
+        fr_store(out + 32 * i, &x);
+    }
+}
+void tko_fr_scalar_sub(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t n) {
+    tko_init();
+    fr_t k;
+    fr_load(&k, s);
+    for (size_t i = 0; i < n; i++) {
+        fr_t x;
+        fr_load(&x, a + 32 * i);
+        fr_sub(&x, &x, &k);
+        fr_store(out + 32 * i, &x);
+    }
+}
+void tko_fr_pow_u64(const uint8_t *a, uint64_t e, uint8_t *out) {
+    tko_init();
+    fr_t x;
+    fr_load(&x, a);
+    fr_pow(&x, &x, &e, 1);
+    fr_store(out, &x);
+}
+void tko_fr_transpose(const uint8_t *in, size_t rows, size_t cols, uint8_t *out) {
+    for (size_t i = 0; i < rows; i++)
+        for (size_t j = 0; j < cols; j++) memcpy(out + 32 * (j * rows + i), in + 32 * (i * cols + j), 32);
+}
+
+/* splitmix64 stream: element i consumes outputs 4i..4i+3 (little-endian limbs), reduced mod r */
+static inline u64 splitmix64_at(u64 seed, u64 idx) {
+    u64 z = seed + (idx + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline void fr_random_plain(u64 seed, u64 i, fr_t *o) {
+    for (int k = 0; k < 4; k++) o->l[k] = splitmix64_at(seed, 4 * i + k);
+    while (fr_geq_p(o)) fr_sub_p(o);
+}
+void tko_fr_random(uint64_t seed, size_t first, size_t n, uint8_t *out) {
+    tko_init();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        fr_t x;
+        fr_random_plain(seed, first + i, &x);
+        memcpy(out + 32 * i, x.l, 32);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * NTT. Definition restated from ICICLE v3.8.0's documented ntt::ntt (natural order "kNN",
+ * forward X[k] = sum_j x[j] w^{jk}, inverse scaled by 1/n, coset: forward evaluates on g*<w>,
+ * inverse undoes it) as exercised by libs/src/tests.rs:107-180 and 1075-1087.
+ * ------------------------------------------------------------------------------------------ */
+static int log2_exact(size_t n) {
+    int l = 0;
+    if (n == 0 || (n & (n - 1))) return -1;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+static void fr_root_of_unity(int logn, fr_t *w) { /* w_{2^logn} */
+    *w = FR_ROOT32;
+    for (int i = logn; i < 32; i++) fr_sqr(w, w);
+}
+int tko_get_root_of_unity(uint64_t max_size, uint8_t *out) {
+    tko_init();
+    int l = 0;
+    while (l < 32 && ((u64)1 << l) < max_size) l++;
+    if (((u64)1 << l) < max_size) return -1;
+    fr_t w;
+    fr_root_of_unity(l, &w);
+    fr_store(out, &w);
+    return 0;
+}
+
+/* in-place iterative radix-2 DIT on Montgomery values; tw[i] = w^i, i < n/2 */
+static void fr_ntt_inplace(fr_t *a, size_t n, int logn, const fr_t *tw) {
+    for (size_t i = 0, j = 0; i < n; i++) {
+        if (i < j) {
+            fr_t t = a[i];
+            a[i] = a[j];
+            a[j] = t;
+        }
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+    }
+    for (int s = 1; s <= logn; s++) {
+        size_t m = (size_t)1 << s, h = m >> 1, step = n / m;
+        for (size_t k = 0; k < n; k += m)
+            for (size_t j = 0; j < h; j++) {
+                fr_t t, u = a[k + j];
+                fr_mul(&t, &a[k + j + h], &tw[j * step]);
+                fr_add(&a[k + j], &u, &t);
+                fr_sub(&a[k + j + h], &u, &t);
+            }
+    }
+}
+
+int tko_ntt(const uint8_t *in, size_t n, size_t batch, int columns_batch, int inverse,
+            const uint8_t *coset_gen, uint8_t *out) {
+    tko_init();
+    int logn = log2_exact(n);
+    if (logn < 0 || logn > 32) return -1;
+    fr_t w, g, ginv, ninv;
+    fr_root_of_unity(logn, &w);
+    if (inverse) fr_inv(&w, &w);
+    int has_coset = 0;
+    if (coset_gen) {
+        fr_load(&g, coset_gen);
+        has_coset = !fr_eq(&g, &fr_R1);
+        fr_inv(&ginv, &g);
+    }
+    {
+        fr_t nn;
+        memset(&nn, 0, sizeof nn);
+        nn.l[0] = (u64)n;
+        fr_to_mont(&nn, &nn);
+        fr_inv(&ninv, &nn);
+    }
+    size_t half = n > 1 ? n / 2 : 1;
+    fr_t *tw = (fr_t *)malloc(sizeof(fr_t) * half);
+    fr_t *cs = has_coset ? (fr_t *)malloc(sizeof(fr_t) * n) : NULL; /* g^j or (g^-j)/n */
+    if (!tw || (has_coset && !cs)) return -2;
+    tw[0] = fr_R1;
+    for (size_t i = 1; i < half; i++) fr_mul(&tw[i], &tw[i - 1], &w);
+    if (has_coset) {
+        cs[0] = fr_R1;
+        for (size_t i = 1; i < n; i++) fr_mul(&cs[i], &cs[i - 1], inverse ? &ginv : &g);
+    }
+    size_t estride = columns_batch ? batch : 1, bstride = columns_batch ? 1 : n;
+#pragma omp parallel
+    {
+        fr_t *buf = (fr_t *)malloc(sizeof(fr_t) * n);
+#pragma omp for schedule(static)
+        for (size_t b = 0; b < batch; b++) {
+            for (size_t j = 0; j < n; j++) {
+                fr_load(&buf[j], in + 32 * (b * bstride + j * estride));
+                if (has_coset && !inverse) fr_mul(&buf[j], &buf[j], &cs[j]);
+            }
+            fr_ntt_inplace(buf, n, logn, tw);
+            for (size_t j = 0; j < n; j++) {
+                if (inverse) {
+                    fr_mul(&buf[j], &buf[j], &ninv);
+                    if (has_coset) fr_mul(&buf[j], &buf[j], &cs[j]);
+                }
+                fr_store(out + 32 * (b * bstride + j * estride), &buf[j]);
+            }
+        }
+        free(buf);
+    }
+    free(tw);
+    free(cs);
+    return 0;
+}
+
+int tko_bintt(const uint8_t *in, size_t x_size, size_t y_size, int inverse, const uint8_t *coset_x,
+              const uint8_t *coset_y, uint8_t *out) {
+    /* libs/src/bivariate_polynomial/mod.rs:1449-1476 */
+    if (x_size == 1) return tko_ntt(in, y_size, 1, 0, inverse, coset_y, out);
+    if (y_size == 1) return tko_ntt(in, x_size, 1, 0, inverse, coset_x, out);
+    uint8_t *tmp = (uint8_t *)malloc(32 * x_size * y_size);
+    if (!tmp) return -2;
+    int rc = tko_ntt(in, y_size, x_size, 0, inverse, coset_y, tmp);
+    if (!rc) rc = tko_ntt(tmp, x_size, y_size, 1, inverse, coset_x, out);
+    free(tmp);
+    return rc;
+}
+
+int tko_dft_naive(const uint8_t *in, size_t n, uint8_t *out) {
+    tko_init();
+    int logn = log2_exact(n);
+    if (logn < 0) return -1;
+    fr_t w;
+    fr_root_of_unity(logn, &w);
+    fr_t *x = (fr_t *)malloc(sizeof(fr_t) * n);
+    for (size_t j = 0; j < n; j++) fr_load(&x[j], in + 32 * j);
+    for (size_t k = 0; k < n; k++) {
+        fr_t wk, acc, cur = fr_R1;
+        u64 e = k;
+        fr_pow(&wk, &w, &e, 1);
+        memset(&acc, 0, sizeof acc);
+        for (size_t j = 0; j < n; j++) {
+            fr_t t;
+            fr_mul(&t, &x[j], &cur);
+            fr_add(&acc, &acc, &t);
+            fr_mul(&cur, &cur, &wk);
+        }
+        fr_store(out + 32 * k, &acc);
+    }
+    free(x);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * G1: y^2 = x^3 + 4 over Fq, Jacobian coordinates (X/Z^2, Y/Z^3), Z = 0 <=> infinity.
+ * Standard short-Weierstrass a=0 formulas (dbl-2009-l, add-2007-bl / madd-2007-bl).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { fq_t x, y, z; } g1j_t;
+typedef struct { fq_t x, y; int inf; } g1a_t;
+
+static void g1a_load(g1a_t *o, const uint8_t *b) {
+    int z = 1;
+    for (int i = 0; i < 96; i++)
+        if (b[i]) { z = 0; break; }
+    o->inf = z;
+    fq_load(&o->x, b);
+    fq_load(&o->y, b + 48);
+}
+static void g1a_store(uint8_t *b, const g1a_t *p) {
+    if (p->inf) { memset(b, 0, 96); return; }
+    fq_store(b, &p->x);
+    fq_store(b + 48, &p->y);
+}
+static void g1j_set_inf(g1j_t *p) { memset(p, 0, sizeof *p); p->x = fq_R1; p->y = fq_R1; }
+static void g1j_from_affine(g1j_t *o, const g1a_t *p) {
+    if (p->inf) { g1j_set_inf(o); return; }
+    o->x = p->x; o->y = p->y; o->z = fq_R1;
+}
+static void g1j_to_affine(g1a_t *o, const g1j_t *p) {
+    if (fq_is_zero(&p->z)) { memset(o, 0, sizeof *o); o->inf = 1; return; }
+    fq_t zi, zi2, zi3;
+    fq_inv(&zi, &p->z);
+    fq_sqr(&zi2, &zi);
+    fq_mul(&zi3, &zi2, &zi);
+    fq_mul(&o->x, &p->x, &zi2);
+    fq_mul(&o->y, &p->y, &zi3);
+    o->inf = 0;
+}
+static void g1j_double(g1j_t *o, const g1j_t *p) {
+    if (fq_is_zero(&p->z)) { *o = *p; return; }
+    fq_t a, b, c, d, e, f, t;
+    fq_sqr(&a, &p->x);
+    fq_sqr(&b, &p->y);
+    fq_sqr(&c, &b);
+    fq_add(&t, &p->x, &b);
+    fq_sqr(&t, &t);
+    fq_sub(&t, &t, &a);
+    fq_sub(&t, &t, &c);
+    fq_add(&d, &t, &t);
+    fq_add(&e, &a, &a);
+    fq_add(&e, &e, &a);
+    fq_sqr(&f, &e);
+    g1j_t r;
+    fq_mul(&r.z, &p->y, &p->z);
+    fq_add(&r.z, &r.z, &r.z);
+    fq_sub(&r.x, &f, &d);
+    fq_sub(&r.x, &r.x, &d);
+    fq_sub(&t, &d, &r.x);
+    fq_mul(&t, &t, &e);
+    fq_add(&c, &c, &c);
+    fq_add(&c, &c, &c);
+    fq_add(&c, &c, &c);
+    fq_sub(&r.y, &t, &c);
+    *o = r;
+}
+static void g1j_add(g1j_t *o, const g1j_t *p, const g1j_t *q) {
+    if (fq_is_zero(&p->z)) { *o = *q; return; }
+    if (fq_is_zero(&q->z)) { *o = *p; return; }
+    fq_t z1z1, z2z2, u1, u2, s1, s2, h, i, j, rr, v, t;
+    fq_sqr(&z1z1, &p->z);
+    fq_sqr(&z2z2, &q->z);
+    fq_mul(&u1, &p->x, &z2z2);
+    fq_mul(&u2, &q->x, &z1z1);
+    fq_mul(&s1, &p->y, &q->z);
+    fq_mul(&s1, &s1, &z2z2);
+    fq_mul(&s2, &q->y, &p->z);
+    fq_mul(&s2, &s2, &z1z1);
+    if (fq_eq(&u1, &u2)) {
+        if (fq_eq(&s1, &s2)) { g1j_double(o, p); return; }
+        g1j_set_inf(o);
+        return;
+    }
+    fq_sub(&h, &u2, &u1);
+    fq_add(&i, &h, &h);
+    fq_sqr(&i, &i);
+    fq_mul(&j, &h, &i);
+    fq_sub(&rr, &s2, &s1);
+    fq_add(&rr, &rr, &rr);
+    fq_mul(&v, &u1, &i);
+    g1j_t r;
+    fq_sqr(&r.x, &rr);
+    fq_sub(&r.x, &r.x, &j);
+    fq_sub(&r.x, &r.x, &v);
+    fq_sub(&r.x, &r.x, &v);
+    fq_sub(&t, &v, &r.x);
+    fq_mul(&t, &t, &rr);
+    fq_mul(&s1, &s1, &j);
+    fq_add(&s1, &s1, &s1);
+    fq_sub(&r.y, &t, &s1);
+    fq_add(&t, &p->z, &q->z);
+    fq_sqr(&t, &t);
+    fq_sub(&t, &t, &z1z1);
+    fq_sub(&t, &t, &z2z2);
+    fq_mul(&r.z, &t, &h);
+    *o = r;
+}
+static void g1j_add_affine(g1j_t *o, const g1j_t *p, const g1a_t *q, int negate) {
+    if (q->inf) { *o = *p; return; }
+    g1j_t qq;
+    qq.x = q->x;
+    qq.y = q->y;
+    if (negate) fq_neg(&qq.y, &qq.y);
+    qq.z = fq_R1;
+    g1j_add(o, p, &qq);
+}
+/* [s]P, s plain 4 limbs, MSB-first double-and-add */
+static void g1j_scalar_mul(g1j_t *o, const u64 *s, const g1j_t *p) {
+    g1j_t acc;
+    g1j_set_inf(&acc);
+    for (int i = 255; i >= 0; i--) {
+        g1j_double(&acc, &acc);
+        if ((s[i >> 6] >> (i & 63)) & 1) g1j_add(&acc, &acc, p);
+    }
+    *o = acc;
+}
+static void load_scalar_plain(u64 *s, const uint8_t *b) { /* reduce mod r like Fr import */
+    fr_t t;
+    memcpy(t.l, b, 32);
+    while (fr_geq_p(&t)) fr_sub_p(&t);
+    memcpy(s, t.l, 32);
+}
+
+/* standard generator, restated from setup/mpc-setup/src/conversions.rs:68-79 (u32 LE limbs) */
+static const uint32_t G1_GEN_X[12] = {0xdb22c6bb, 0xfb3af00a, 0xf97a1aef, 0x6c55e83f, 0x171bac58, 0xa14e3a3f,
+                                      0x9774b905, 0xc3688c4f, 0x4fa9ac0f, 0x2695638c, 0x3197d794, 0x17f1d3a7};
+static const uint32_t G1_GEN_Y[12] = {1187375073u, 212476713u,  2726857444u, 3493644100u, 738505709u,  14358731u,
+                                      3587181302u, 4243972245u, 1948093156u, 2694721773u, 3819610353u, 146011265u};
+void tko_g1_generator(uint8_t *out96) {
+    memcpy(out96, G1_GEN_X, 48);
+    memcpy(out96 + 48, G1_GEN_Y, 48);
+}
+int tko_g1_on_curve(const uint8_t *p96) {
+    tko_init();
+    g1a_t p;
+    g1a_load(&p, p96);
+    if (p.inf) return 1;
+    fq_t l, r;
+    fq_sqr(&l, &p.y);
+    fq_sqr(&r, &p.x);
+    fq_mul(&r, &r, &p.x);
+    fq_add(&r, &r, &FQ_B);
+    return fq_eq(&l, &r);
+}
+void tko_g1_add(const uint8_t *p96, const uint8_t *q96, uint8_t *out96) {
+    tko_init();
+    g1a_t p, q, r;
+    g1j_t pj, rj;
+    g1a_load(&p, p96);
+    g1a_load(&q, q96);
+    g1j_from_affine(&pj, &p);
+    g1j_add_affine(&rj, &pj, &q, 0);
+    g1j_to_affine(&r, &rj);
+    g1a_store(out96, &r);
+}
+void tko_g1_neg(const uint8_t *p96, uint8_t *out96) {
+    tko_init();
+    g1a_t p;
+    g1a_load(&p, p96);
+    if (!p.inf) fq_neg(&p.y, &p.y);
+    g1a_store(out96, &p);
+}
+void tko_g1_scalar_mul(const uint8_t *s32, const uint8_t *p96, uint8_t *out96) {
+    tko_init();
+    g1a_t p, r;
+    g1j_t pj, rj;
+    u64 s[4];
+    load_scalar_plain(s, s32);
+    g1a_load(&p, p96);
+    g1j_from_affine(&pj, &p);
+    g1j_scalar_mul(&rj, s, &pj);
+    g1j_to_affine(&r, &rj);
+    g1a_store(out96, &r);
+}
+void tko_g1_batch_scalar_mul(const uint8_t *s, const uint8_t *p96, size_t n, uint8_t *out) {
+    tko_init();
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < n; i++) tko_g1_scalar_mul(s + 32 * i, p96, out + 96 * i);
+}
+void tko_g1_random_bases(uint64_t seed, size_t first, size_t n, uint8_t *out) {
+    tko_init();
+    uint8_t g[96];
+    tko_g1_generator(g);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < n; i++) {
+        fr_t h;
+        fr_random_plain(seed, first + i, &h);
+        tko_g1_scalar_mul((const uint8_t *)h.l, g, out + 96 * i);
+    }
+}
+void tko_g1_msm_naive(const uint8_t *s, const uint8_t *p, size_t n, uint8_t *out96) {
+    tko_init();
+    g1j_t acc;
+    g1j_set_inf(&acc);
+    for (size_t i = 0; i < n; i++) {
+        g1a_t a;
+        g1j_t pj, t;
+        u64 k[4];
+        load_scalar_plain(k, s + 32 * i);
+        g1a_load(&a, p + 96 * i);
+        g1j_from_affine(&pj, &a);
+        g1j_scalar_mul(&t, k, &pj);
+        g1j_add(&acc, &acc, &t);
+    }
+    g1a_t r;
+    g1j_to_affine(&r, &acc);
+    g1a_store(out96, &r);
+}
+
+/* Pippenger bucket method (the published algorithm ICICLE's CPU/CUDA msm backends implement):
+ * unsigned c-bit windows, per-window buckets, running-sum reduction, Horner over windows. */
+void tko_g1_msm(const uint8_t *s, const uint8_t *p, size_t n, int threads, uint8_t *out96) {
+    tko_init();
+    if (n == 0) { memset(out96, 0, 96); return; }
+    int c = 4;
+    while (c < 16 && ((size_t)1 << (c + 4)) < n) c++;
+    int nwin = (255 + c - 1) / c;
+    g1a_t *pts = (g1a_t *)malloc(sizeof(g1a_t) * n);
+    u64 *sc = (u64 *)malloc(32 * n);
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (size_t i = 0; i < n; i++) {
+        g1a_load(&pts[i], p + 96 * i);
+        load_scalar_plain(sc + 4 * i, s + 32 * i);
+    }
+    g1j_t *wsum = (g1j_t *)malloc(sizeof(g1j_t) * nwin);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int w = 0; w < nwin; w++) {
+        size_t nb = ((size_t)1 << c) - 1;
+        g1j_t *bk = (g1j_t *)malloc(sizeof(g1j_t) * nb);
+        for (size_t b = 0; b < nb; b++) g1j_set_inf(&bk[b]);
+        int lo = w * c;
+        for (size_t i = 0; i < n; i++) {
+            const u64 *k = sc + 4 * i;
+            int li = lo >> 6, sh = lo & 63;
+            u64 d = k[li] >> sh;
+            if (sh + c > 64 && li < 3) d |= k[li + 1] << (64 - sh);
+            d &= ((u64)1 << c) - 1;
+            if (d) g1j_add_affine(&bk[d - 1], &bk[d - 1], &pts[i], 0);
+        }
+        g1j_t run, tot;
+        g1j_set_inf(&run);
+        g1j_set_inf(&tot);
+        for (size_t b = nb; b-- > 0;) {
+            g1j_add(&run, &run, &bk[b]);
+            g1j_add(&tot, &tot, &run);
+        }
+        wsum[w] = tot;
+        free(bk);
+    }
+    g1j_t acc;
+    g1j_set_inf(&acc);
+    for (int w = nwin - 1; w >= 0; w--) {
+        for (int k = 0; k < c; k++) g1j_double(&acc, &acc);
+        g1j_add(&acc, &acc, &wsum[w]);
+    }
+    g1a_t r;
+    g1j_to_affine(&r, &acc);
+    g1a_store(out96, &r);
+    free(wsum);
+    free(sc);
+    free(pts);
+}
+
+void tko_g1_proj_to_affine(const uint8_t *p144, uint8_t *out96) {
+    tko_init();
+    fq_t x, y, z, zi;
+    fq_load(&x, p144);
+    fq_load(&y, p144 + 48);
+    fq_load(&z, p144 + 96);
+    if (fq_is_zero(&z)) { memset(out96, 0, 96); return; }
+    fq_inv(&zi, &z);
+    fq_mul(&x, &x, &zi);
+    fq_mul(&y, &y, &zi);
+    fq_store(out96, &x);
+    fq_store(out96 + 48, &y);
+}

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/pins.json from the reference tree (run in the build container only).
+
+Collects the few constants the reference pins for the MSM / NTT hot path as DATA:
+  * the prime in the header of every committed .r1cs   (qap-compiler/subcircuits/library/r1cs)
+  * the standard G1 generator limbs                     (setup/mpc-setup/src/conversions.rs:68-79)
+  * the fixed-tau G1 generator and trapdoor scalars     (setup/trusted-setup/src/main.rs:71-74,
+                                                         libs/src/field_structures/mod.rs:43-64)
+  * production setup parameters                         (qap-compiler/subcircuits/library/setupParams.json)
+Values are parsed out of those files' text/bytes; nothing from the reference is executed.
+"""
+import glob
+import json
+import os
+import re
+import struct
+
+REF = "/root/reference/packages"
+out = {}
+
+primes = set()
+files = sorted(glob.glob(REF + "/frontend/qap-compiler/subcircuits/library/r1cs/*.r1cs"))
+for f in files:
+    b = open(f, "rb").read()
+    assert b[:4] == b"r1cs"
+    nsec = struct.unpack_from("<I", b, 8)[0]
+    off = 12
+    for _ in range(nsec):
+        typ, size = struct.unpack_from("<IQ", b, off)
+        off += 12
+        if typ == 1:
+            fs = struct.unpack_from("<I", b, off)[0]
+            primes.add(int.from_bytes(b[off + 4:off + 4 + fs], "little"))
+        off += size
+assert len(primes) == 1
+out["r1cs_files"] = len(files)
+out["r1cs_prime"] = hex(primes.pop())
+
+src = open(REF + "/backend/setup/mpc-setup/src/conversions.rs").read()
+m = re.search(r"fn icicle_g1_generator.*?x_limbs: \[u32; 12\] = \[(.*?)\];.*?y_limbs: \[u32; 12\] = \[(.*?)\];", src, re.S)
+out["g1_generator_x_limbs"] = [int(t, 0) for t in re.findall(r"0x[0-9a-fA-F]+|\d+", m.group(1))]
+out["g1_generator_y_limbs"] = [int(t, 0) for t in re.findall(r"0x[0-9a-fA-F]+|\d+", m.group(2))]
+
+src = open(REF + "/backend/setup/trusted-setup/src/main.rs").read()
+m = re.search(r"G1Affine::from_limbs\(\s*BaseField::from_hex\(\"(0x[0-9a-f]+)\"\).*?BaseField::from_hex\(\"(0x[0-9a-f]+)\"\)", src, re.S)
+out["fixed_tau_g1_x"], out["fixed_tau_g1_y"] = m.group(1), m.group(2)
+
+src = open(REF + "/backend/libs/src/field_structures/mod.rs").read()
+body = src[src.index("pub fn gen_fixed"):]
+for name in ("x", "y", "alpha", "gamma", "delta", "eta"):
+    m = re.search(name + r": ScalarField::from_hex\(\s*\"(0x[0-9a-f]+)\"", body)
+    out["tau_" + name] = m.group(1)
+
+out["setup_params"] = json.load(open(REF + "/frontend/qap-compiler/subcircuits/library/setupParams.json"))
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pins.json"), "w") as fh:
+    json.dump(out, fh, indent=1)
+print(json.dumps(out, indent=1))
