@@ -1,0 +1,211 @@
+/*
+ * tkmk.h — C ABI of libtkmk_hip.so, the MI355X (gfx950) backend for the Tokamak zk-EVM prover's
+ * polynomial-commitment hot path: BLS12-381 G1 multi-scalar multiplication, scalar-field (Fr)
+ * NTT / iNTT incl. the bivariate "_biNTT", and the element-wise Fr vector ops between them.
+ *
+ * WHAT THIS REPLACES.  The reference's Rust crate `libs` (packages/backend/libs) reaches the device
+ * only through ICICLE v3.8.0's Rust wrappers (icicle_core / icicle_runtime / icicle_bls12_381, git tag
+ * pinned at packages/backend/Cargo.toml:20-23), each a thin shim over one `extern "C"` symbol of the
+ * ICICLE frontend library.  ICICLE is not vendored in the reference and is absent from this build
+ * environment, so the symbol names and struct layouts below follow ICICLE v3's public C API as
+ * documented/remembered and MUST be re-checked against the v3.8.0 headers
+ * before claiming link-level compatibility; the semantics are fixed by the reference call sites
+ * cited on every entry point.  INTEGRATION.md shows the Rust binding a maintainer adds.
+ *
+ * DATA ENCODING (pinned by packages/backend/setup/mpc-setup/src/conversions.rs:43-95 and
+ * libs/src/iotools/mod.rs:1701-1706,1785-1816): every field element crosses this ABI as the PLAIN
+ * (non-Montgomery) integer in little-endian u32 limbs — Fr 32 B, Fq 48 B; G1 affine = {x, y} 96 B with
+ * (0,0) = point at infinity; G1 projective = {x, y, z} 144 B, homogeneous (X/Z, Y/Z), z = 0 = infinity.
+ *
+ * ERRORS: every function returns a tkmk_error (0 = success); nothing throws or aborts across the ABI.
+ * THREADING: calls may be issued from one host thread at a time per stream (the reference issues all
+ * device calls from its main thread: SURVEY.md §8b); the NTT domain is process-global like ICICLE's.
+ * There is NO CPU fallback: without a usable gfx950 device every compute entry returns
+ * TKMK_ERR_NO_DEVICE.
+ */
+#ifndef TKMK_H
+#define TKMK_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mirrors icicle_runtime::errors::eIcicleError as matched by libs/src/vector_operations/mod.rs:386 */
+typedef enum {
+    TKMK_SUCCESS = 0,
+    TKMK_ERR_INVALID_DEVICE = 1,
+    TKMK_ERR_OUT_OF_MEMORY = 2,
+    TKMK_ERR_INVALID_POINTER = 3,
+    TKMK_ERR_ALLOCATION_FAILED = 4,
+    TKMK_ERR_DEALLOCATION_FAILED = 5,
+    TKMK_ERR_COPY_FAILED = 6,
+    TKMK_ERR_SYNCHRONIZATION_FAILED = 7,
+    TKMK_ERR_STREAM_CREATION_FAILED = 8,
+    TKMK_ERR_STREAM_DESTRUCTION_FAILED = 9,
+    TKMK_ERR_API_NOT_IMPLEMENTED = 10,
+    TKMK_ERR_INVALID_ARGUMENT = 11,
+    TKMK_ERR_NO_DEVICE = 12,
+    TKMK_ERR_UNKNOWN = 999
+} tkmk_error;
+
+typedef struct { uint32_t limbs[8]; } tkmk_fr;            /* icicle_bls12_381::curve::ScalarField */
+typedef struct { uint32_t limbs[12]; } tkmk_fq;           /* BaseField */
+typedef struct { tkmk_fq x, y; } tkmk_g1_affine;          /* G1Affine  (96 B)  */
+typedef struct { tkmk_fq x, y, z; } tkmk_g1_projective;   /* G1Projective (144 B) */
+typedef void *tkmk_stream;                                /* IcicleStream handle (a hipStream_t) */
+
+/* ---------------------------------------------------------------------------------------------
+ * Device runtime — replaces icicle_runtime::{memory::DeviceVec, stream::IcicleStream, Device}
+ * used at ~40 sites, e.g. libs/src/bivariate_polynomial/mod.rs:446-457,1661-1662;
+ * libs/src/utils/mod.rs:78-110 (check_device); libs/src/vector_operations/mod.rs:484-549.
+ * --------------------------------------------------------------------------------------------- */
+tkmk_error tkmk_device_count(int *count);                 /* is_device_available */
+tkmk_error tkmk_set_device(int device_id);                /* icicle_runtime::set_device (id is 0 in the reference) */
+tkmk_error tkmk_get_available_memory(size_t *total, size_t *free_bytes); /* get_available_memory */
+tkmk_error tkmk_malloc(void **ptr, size_t bytes);         /* DeviceVec::device_malloc */
+tkmk_error tkmk_malloc_async(void **ptr, size_t bytes, tkmk_stream s);
+tkmk_error tkmk_free(void *ptr);                          /* Drop for DeviceVec */
+tkmk_error tkmk_free_async(void *ptr, tkmk_stream s);
+tkmk_error tkmk_memcpy_h2d(void *dst, const void *src, size_t bytes);   /* copy_from_host */
+tkmk_error tkmk_memcpy_d2h(void *dst, const void *src, size_t bytes);   /* copy_to_host   */
+tkmk_error tkmk_memcpy_d2d(void *dst, const void *src, size_t bytes);   /* DeviceVec::copy */
+tkmk_error tkmk_memcpy_h2d_async(void *dst, const void *src, size_t bytes, tkmk_stream s);
+tkmk_error tkmk_memcpy_d2h_async(void *dst, const void *src, size_t bytes, tkmk_stream s);
+tkmk_error tkmk_memset(void *ptr, int value, size_t bytes);
+tkmk_error tkmk_stream_create(tkmk_stream *s);            /* IcicleStream::create */
+tkmk_error tkmk_stream_synchronize(tkmk_stream s);        /* IcicleStream::synchronize */
+tkmk_error tkmk_stream_destroy(tkmk_stream s);            /* IcicleStream::destroy */
+tkmk_error tkmk_device_synchronize(void);
+const char *tkmk_error_string(tkmk_error e);
+/* 1 if libtkmk_hip.so was built with gfx950 code objects (always, for this library) */
+int tkmk_is_hip_build(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * MSM — replaces icicle_core::msm::msm<G1> (extern "C" bls12_381_msm in ICICLE v3) as called at
+ *   libs/src/iotools/mod.rs:2093-2099          (encode_poly: one dense MSM over the CRS sub-grid)
+ *   libs/src/group_structures/mod.rs:108-114   (macro twin over an owned Sigma1)
+ *   libs/src/group_structures/mod.rs:127-143   (msm_g1_bases: gathered binding MSMs)
+ *   libs/src/iotools/mod.rs:1113-1151,1239-1252 (setup: batched scalar-mul expressed as MSM batches)
+ * Field order and defaults follow ICICLE v3 MSMConfig.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    tkmk_stream stream_handle;          /* NULL = default stream */
+    int precompute_factor;              /* 1; >1 is rejected with API_NOT_IMPLEMENTED */
+    int c;                              /* window bits; 0 = choose from size */
+    int bitsize;                        /* scalar bits to process; 0 = 255 */
+    int batch_size;                     /* number of MSMs; results = batch_size points */
+    bool are_points_shared_in_batch;    /* true: one bases array of msm_size; false: batch_size * msm_size */
+    bool are_scalars_on_device;
+    bool are_scalars_montgomery_form;
+    bool are_points_on_device;
+    bool are_points_montgomery_form;
+    bool are_results_on_device;
+    bool is_async;                      /* true: return before completion (device results only) */
+    void *ext;                          /* must be NULL */
+} tkmk_msm_config;
+
+tkmk_msm_config tkmk_msm_default_config(void);            /* MSMConfig::default() */
+
+/* results[b] = sum_i scalars[b*msm_size + i] * bases[(shared ? 0 : b*msm_size) + i].
+ * msm_size = points per MSM.  Results are returned as canonical projective (x_affine, y_affine, 1)
+ * or (0,1,0) for infinity, so that the reference's `G1Affine::from(projective)`
+ * (libs/src/iotools/mod.rs:2112) yields the unique affine point. */
+tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *bases, int msm_size,
+                         const tkmk_msm_config *cfg, tkmk_g1_projective *results);
+
+/* ---------------------------------------------------------------------------------------------
+ * NTT — replaces icicle_core::ntt::{ntt, initialize_domain, release_domain, get_root_of_unity}
+ * (extern "C" bls12_381_ntt, _ntt_init_domain, _ntt_release_domain, _get_root_of_unity) as called at
+ *   libs/src/bivariate_polynomial/mod.rs:33-55      (init_ntt_domain_for_size: global, grow-only)
+ *   libs/src/bivariate_polynomial/mod.rs:1449-1476  (_biNTT: 1-D, row batch, strided column batch)
+ * --------------------------------------------------------------------------------------------- */
+typedef enum { TKMK_NTT_FORWARD = 0, TKMK_NTT_INVERSE = 1 } tkmk_ntt_dir;   /* NTTDir::{kForward,kInverse} */
+typedef enum { TKMK_ORDER_NN = 0 } tkmk_ntt_ordering;     /* only natural->natural is used by the reference */
+
+typedef struct {
+    tkmk_stream stream_handle;
+    tkmk_fr coset_gen;                  /* 1 = no coset. forward: x[j] *= g^j first; inverse: undone last */
+    int batch_size;
+    bool columns_batch;                 /* false: vector b at [b*n, (b+1)*n); true: element i of vector b at i*batch+b */
+    tkmk_ntt_ordering ordering;
+    bool are_inputs_on_device;
+    bool are_outputs_on_device;
+    bool is_async;
+    void *ext;                          /* must be NULL */
+} tkmk_ntt_config;
+
+typedef struct {
+    tkmk_stream stream_handle;
+    bool is_async;
+    void *ext;
+} tkmk_ntt_init_domain_config;
+
+tkmk_ntt_config tkmk_ntt_default_config(void);            /* NTTConfig::default() */
+tkmk_error bls12_381_get_root_of_unity(uint64_t max_size, tkmk_fr *rou_out);
+/* primitive_root must have order 2^k; builds twiddles for sizes up to 2^k. Fails if a domain exists. */
+tkmk_error bls12_381_ntt_init_domain(const tkmk_fr *primitive_root, const tkmk_ntt_init_domain_config *cfg);
+tkmk_error bls12_381_ntt_release_domain(void);
+/* size = length n of ONE vector (power of two, <= domain); total elements = n * batch_size.
+ * input may equal output (in place). */
+tkmk_error bls12_381_ntt(const tkmk_fr *input, int size, tkmk_ntt_dir dir, const tkmk_ntt_config *cfg,
+                         tkmk_fr *output);
+
+/* The reference's own 2-D transform, restated as ONE device entry so the intermediate never leaves
+ * HBM: DensePolynomialExt::_biNTT (libs/src/bivariate_polynomial/mod.rs:1422-1478) =
+ * rows (length y_size, coset_y) then strided columns (length x_size, coset_x); element (ix,iy) at
+ * ix*y_size + iy.  coset_x / coset_y may be NULL (= 1).  Pointers are device pointers when
+ * on_device is true, host pointers otherwise. */
+tkmk_error tkmk_bintt(const tkmk_fr *input, size_t x_size, size_t y_size, tkmk_ntt_dir dir,
+                      const tkmk_fr *coset_x, const tkmk_fr *coset_y, bool on_device,
+                      tkmk_stream stream, tkmk_fr *output);
+
+/* ---------------------------------------------------------------------------------------------
+ * Vector ops — replaces icicle_core::vec_ops::VecOps<ScalarField> (extern "C" bls12_381_vector_add, …)
+ * as used at libs/src/vector_operations/mod.rs:34-139,326-336,612-626 and
+ * libs/src/bivariate_polynomial/mod.rs:332-435,835,935,1590-1611,1974,2180,2230,2276.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    tkmk_stream stream_handle;
+    bool is_a_on_device;
+    bool is_b_on_device;
+    bool is_result_on_device;
+    bool is_async;
+    int batch_size;                     /* 1 (batched reductions: sum over batch_size vectors) */
+    bool columns_batch;
+    void *ext;
+} tkmk_vecops_config;
+
+tkmk_vecops_config tkmk_vecops_default_config(void);      /* VecOpsConfig::default() */
+tkmk_error bls12_381_vector_add(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+tkmk_error bls12_381_vector_sub(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+tkmk_error bls12_381_vector_mul(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+tkmk_error bls12_381_vector_div(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+tkmk_error bls12_381_vector_inv(const tkmk_fr *a, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+/* a is ONE scalar (a[0]); out[i] = a + b[i],  a - b[i] (ICICLE v3 scalar_sub_vec),  a * b[i] */
+tkmk_error bls12_381_scalar_add_vec(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+tkmk_error bls12_381_scalar_sub_vec(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+tkmk_error bls12_381_scalar_mul_vec(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+/* out[b] = sum / product of vector b (batch_size vectors of n) */
+tkmk_error bls12_381_vector_sum(const tkmk_fr *a, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+tkmk_error bls12_381_vector_product(const tkmk_fr *a, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+/* row-major rows x cols -> cols x rows */
+tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, uint32_t cols, const tkmk_vecops_config *cfg, tkmk_fr *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Deterministic input generation on the device — used by bench.py and the tests to
+ * build 2^24-point inputs without a multi-GiB fixture; also the "MSM as batched scalar-mul" setup
+ * path of libs/src/iotools/mod.rs:1113-1151 (n results = n independent [s_i]P).
+ * --------------------------------------------------------------------------------------------- */
+/* out[i] = splitmix64(seed) stream element (first + i), reduced mod r; device pointer */
+tkmk_error tkmk_fr_random_device(uint64_t seed, uint64_t first, uint64_t n, tkmk_fr *out_dev, tkmk_stream s);
+/* out[i] = [scalars[i]] base  (affine results); all pointers device except `base` (host) */
+tkmk_error tkmk_g1_batch_scalar_mul_device(const tkmk_fr *scalars_dev, const tkmk_g1_affine *base_host,
+                                           uint64_t n, tkmk_g1_affine *out_dev, tkmk_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TKMK_H */

@@ -287,7 +287,7 @@ void tko_fr_scalar_sub(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t 
     for (size_t i = 0; i < n; i++) {
         fr_t x;
         fr_load(&x, a + 32 * i);
-        fr_sub(&x, &x, &k);
+        fr_sub(&x, &k, &x); /* ICICLE v3 scalar_sub_vec: res[i] = scalar - vec[i] */
         fr_store(out + 32 * i, &x);
     }
 }

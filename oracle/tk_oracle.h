@@ -46,7 +46,7 @@ void tko_fr_mul(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
 void tko_fr_inv(const uint8_t *a, uint8_t *out, size_t n);           /* inv(0) = 0 */
 void tko_fr_scalar_mul(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t n);
 void tko_fr_scalar_add(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t n);
-void tko_fr_scalar_sub(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t n); /* a[i] - s */
+void tko_fr_scalar_sub(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t n); /* s - a[i] (ICICLE v3 scalar_sub_vec) */
 void tko_fr_pow_u64(const uint8_t *a, uint64_t e, uint8_t *out);
 void tko_fr_transpose(const uint8_t *in, size_t rows, size_t cols, uint8_t *out);
 void tko_fq_mul(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);

@@ -17,3 +17,24 @@ def oracle():
     import oracle as o
     o.lib()
     return o
+
+
+PKG = os.path.join(ROOT, "tokamak-zk-evm_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+
+@pytest.fixture(scope="session")
+def tkmk():
+    """The product: ctypes binding over tokamak-zk-evm_amd/libtkmk_hip.so (C ABI in include/tkmk.h)."""
+    import tkmk as t
+    t.lib()
+    return t
+
+
+@pytest.fixture(scope="session")
+def gpu(tkmk):
+    if tkmk.device_count() < 1:
+        pytest.fail("GPU test selected but no HIP device is visible (the product has no CPU fallback)")
+    tkmk.set_device(0)
+    return tkmk

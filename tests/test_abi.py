@@ -1,0 +1,54 @@
+"""not-gpu tier: the C-ABI library loads, exports every symbol include/tkmk.h declares, and fails loudly
+(TKMK_ERR_NO_DEVICE) instead of falling back to a CPU path when no GPU is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "tkmk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = re.findall(r"\b((?:tkmk|bls12_381)_[a-z0-9_]+)\s*\(", hdr)
+    return sorted(set(names))
+
+
+def test_header_and_binding_agree(tkmk):
+    assert _declared_symbols() == sorted(tkmk.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(tkmk):
+    lib = tkmk.lib()
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.tkmk_is_hip_build() == 1
+
+
+def test_config_defaults_match_icicle(tkmk):
+    m = tkmk.lib().tkmk_msm_default_config()
+    assert (m.precompute_factor, m.c, m.bitsize, m.batch_size, m.are_points_shared_in_batch) == (1, 0, 0, 1, True)
+    assert not (m.are_scalars_on_device or m.are_points_on_device or m.are_results_on_device or m.is_async)
+    n = tkmk.lib().tkmk_ntt_default_config()
+    assert list(n.coset_gen.limbs) == [1, 0, 0, 0, 0, 0, 0, 0] and n.batch_size == 1 and not n.columns_batch
+    v = tkmk.lib().tkmk_vecops_default_config()
+    assert v.batch_size == 1 and not v.is_a_on_device
+
+
+def test_root_of_unity_is_host_side_and_matches_oracle(tkmk, oracle):
+    for n in (1, 2, 256, 1 << 23, 5):
+        assert (tkmk.get_root_of_unity(n) == oracle.root_of_unity(n)).all()
+
+
+def test_no_silent_cpu_fallback(tkmk):
+    if tkmk.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    a = np.zeros(64, np.uint8)
+    for call in (lambda: tkmk.vec_add(a, a), lambda: tkmk.ntt(a, 2), lambda: tkmk.msm(a[:32], np.zeros(96, np.uint8)),
+                 lambda: tkmk.init_ntt_domain_for_size(4), lambda: tkmk.DeviceBuffer(64)):
+        with pytest.raises(tkmk.TkmkError) as e:
+            call()
+        assert e.value.code == 12  # TKMK_ERR_NO_DEVICE

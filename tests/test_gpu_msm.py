@@ -1,0 +1,117 @@
+"""gpu tier: BLS12-381 G1 MSM through the C ABI vs the oracle, bit-exact on the affine result.
+Edge cases follow what the prover feeds encode_poly: zero scalars, repeated bases,
+(0,0)=infinity bases, tiny sizes, every window width."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _msm_affine(gpu, s, p, **kw):
+    return gpu.projective_to_affine_bytes(gpu.msm(s, p, **kw))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 128, 257, 1000, 4099])
+def test_msm_vs_oracle_sizes(gpu, oracle, n):
+    s = oracle.fr_random(1000 + n, n)
+    p = oracle.g1_random_bases(2000 + n, n)
+    assert (_msm_affine(gpu, s, p) == oracle.g1_msm(s, p)).all()
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 15, 16])
+def test_msm_every_window_width(gpu, oracle, c):
+    n = 300
+    s = oracle.fr_random(77, n)
+    p = oracle.g1_random_bases(78, n)
+    assert (_msm_affine(gpu, s, p, c=c) == oracle.g1_msm(s, p)).all()
+
+
+def test_msm_edge_scalars_and_bases(gpu, oracle):
+    n = 64
+    sv = oracle.to_ints(oracle.fr_random(5, n), 32)
+    sv[0:6] = [0, 1, oracle.R_MOD - 1, 2, (1 << 255) % oracle.R_MOD, 0x8000]
+    sv[10:20] = [0] * 10
+    s = oracle.to_bytes(sv, 32)
+    p = oracle.g1_random_bases(6, n)
+    p[96 * 7:96 * 8] = 0                               # infinity base
+    p[96 * 9:96 * 10] = p[96 * 8:96 * 9]               # repeated base (same bucket -> doubling branch)
+    sv2 = list(sv)
+    sv2[9] = sv2[8]
+    s2 = oracle.to_bytes(sv2, 32)
+    p[96 * 12:96 * 13] = oracle.g1_neg(p[96 * 11:96 * 12].copy())   # P and -P
+    sv2[12] = sv2[11]
+    s2 = oracle.to_bytes(sv2, 32)
+    for sc in (s, s2):
+        assert (_msm_affine(gpu, sc, p) == oracle.g1_msm(sc, p)).all()
+    # all-zero scalars -> infinity; all-same base and scalar 1 -> [n]P
+    z = np.zeros(32 * n, np.uint8)
+    assert (_msm_affine(gpu, z, p) == 0).all()
+    ones = oracle.to_bytes([1] * n, 32)
+    same = np.tile(p[:96], n)
+    assert (_msm_affine(gpu, ones, same) == oracle.g1_scalar_mul(oracle.to_bytes([n], 32), p[:96].copy())).all()
+    assert (_msm_affine(gpu, s[:0], p[:0], msm_size=0) == 0).all()
+
+
+def test_msm_batch_shapes(gpu, oracle):
+    # batch with shared / per-batch bases (libs/src/iotools/mod.rs:1239-1252) and n one-point MSMs (:1113-1151)
+    n, batch = 50, 3
+    s = oracle.fr_random(8, n * batch)
+    p = oracle.g1_random_bases(9, n * batch)
+    shared = _msm_affine(gpu, s, p[:96 * n].copy(), msm_size=n, batch=batch, shared_points=True)
+    per = _msm_affine(gpu, s, p, msm_size=n, batch=batch, shared_points=False)
+    for b in range(batch):
+        sb = s[32 * n * b:32 * n * (b + 1)].copy()
+        assert (shared[96 * b:96 * (b + 1)] == oracle.g1_msm(sb, p[:96 * n].copy())).all()
+        assert (per[96 * b:96 * (b + 1)] == oracle.g1_msm(sb, p[96 * n * b:96 * n * (b + 1)].copy())).all()
+    g = oracle.g1_generator()
+    k = 20
+    sc = oracle.fr_random(10, k)
+    ones = _msm_affine(gpu, sc, g, msm_size=1, batch=k, shared_points=True)
+    assert (ones == oracle.g1_batch_scalar_mul(sc, g)).all()
+
+
+def test_commit_identity_on_fixed_tau_crs(gpu, oracle):
+    # encode_poly(P) == [P(tau_x, tau_y)] G on a CRS sub-grid built like Sigma1.xy_powers
+    # (setup/trusted-setup/src/main.rs:236-246; libs/src/iotools/mod.rs:2075-2099), CRS made on the GPU
+    import json
+    import os
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pins.json")))
+    R = oracle.R_MOD
+    tx, ty = int(pins["tau_x"], 16), int(pins["tau_y"], 16)
+    g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
+    xs, ys = 33, 17
+    mon = [pow(tx, i, R) * pow(ty, j, R) % R for i in range(xs) for j in range(ys)]
+    d_mon = gpu.DeviceBuffer.from_host(oracle.to_bytes(mon, 32))
+    crs = gpu.g1_batch_scalar_mul_device(d_mon, g, xs * ys)
+    crs_host = crs.to_host()
+    assert (crs_host[:96] == g).all()
+    assert (crs_host[96 * ys:96 * (ys + 1)] == oracle.g1_scalar_mul(oracle.to_bytes([tx], 32), g)).all()
+    coeffs = oracle.fr_random(12, xs * ys)
+    val = sum(c * m for c, m in zip(oracle.to_ints(coeffs, 32), mon)) % R
+    got = _msm_affine(gpu, gpu.DeviceBuffer.from_host(coeffs), crs)
+    assert (got == oracle.g1_scalar_mul(oracle.to_bytes([val], 32), g)).all()
+
+
+def test_msm_2_16_vs_oracle(gpu, oracle):
+    # BASELINE.json configs[0] size: 2^16 points, oracle Pippenger on the host cores
+    n = 1 << 16
+    s = gpu.fr_random_device(0x746F6B616D616B01, n)
+    h = gpu.fr_random_device(0x746F6B616D616B02, n)
+    p = gpu.g1_batch_scalar_mul_device(h, oracle.g1_generator(), n)
+    sh, ph = s.to_host(), p.to_host()
+    assert (ph[:96 * 8] == oracle.g1_random_bases(0x746F6B616D616B02, 8)).all()
+    assert (_msm_affine(gpu, s, p) == oracle.g1_msm(sh, ph)).all()
+
+
+def test_msm_linearity_2_20(gpu, oracle):
+    # size-independent properties at 2^20: MSM(a+b) == MSM(a) + MSM(b); MSM(k*a) == k*MSM(a)
+    n = 1 << 20
+    a, b = gpu.fr_random_device(61, n), gpu.fr_random_device(62, n)
+    h = gpu.fr_random_device(63, n)
+    p = gpu.g1_batch_scalar_mul_device(h, oracle.g1_generator(), n)
+    ma, mb = _msm_affine(gpu, a, p), _msm_affine(gpu, b, p)
+    mab = _msm_affine(gpu, gpu.vec_add(a, b), p)
+    assert (mab == oracle.g1_add(ma, mb)).all()
+    k = oracle.fr_random(64, 1)
+    mka = _msm_affine(gpu, gpu.scalar_mul(k, a), p)
+    assert (mka == oracle.g1_scalar_mul(k, ma)).all()

@@ -1,0 +1,71 @@
+"""gpu tier: Fr vector ops through the C ABI vs the oracle, bit-exact (integer work).
+Mirrors the reference's use at libs/src/vector_operations/mod.rs:30-139."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _edge_vec(oracle, seed, n):
+    v = oracle.to_ints(oracle.fr_random(seed, n), 32)
+    v[:4] = [0, 1, oracle.R_MOD - 1, 2]
+    return oracle.to_bytes(v, 32)
+
+
+@pytest.mark.parametrize("n", [1, 5, 255, 4097])
+def test_binary_and_scalar_ops(gpu, oracle, n):
+    a = _edge_vec(oracle, 1, n)
+    b = oracle.fr_random(2, n)
+    s = oracle.fr_random(3, 1)
+    assert (gpu.vec_add(a, b) == oracle.fr_add(a, b)).all()
+    assert (gpu.vec_sub(a, b) == oracle.fr_sub(a, b)).all()
+    assert (gpu.vec_mul(a, b) == oracle.fr_mul(a, b)).all()
+    assert (gpu.scalar_mul(s, a) == oracle.fr_scalar_mul(s, a)).all()
+    assert (gpu.scalar_add(s, a) == oracle.fr_scalar_add(s, a)).all()
+    assert (gpu.scalar_sub(s, a) == oracle.fr_scalar_sub(s, a)).all()
+    assert (gpu.vec_inv(a) == oracle.fr_inv(a)).all()          # inv(0) = 0
+    assert (gpu.vec_div(b, a) == oracle.fr_mul(b, oracle.fr_inv(a))).all()
+
+
+def test_device_resident_operands(gpu, oracle):
+    n = 3000
+    a, b = oracle.fr_random(5, n), oracle.fr_random(6, n)
+    da, db = gpu.DeviceBuffer.from_host(a), gpu.DeviceBuffer.from_host(b)
+    out = gpu.vec_mul(da, db)
+    assert isinstance(out, gpu.DeviceBuffer)
+    assert (out.to_host() == oracle.fr_mul(a, b)).all()
+    assert (gpu.vec_add(da, b).to_host() == oracle.fr_add(a, b)).all()   # mixed host/device like the reference
+    gpu.vec_sub(da, db, out=da)                                          # in place
+    assert (da.to_host() == oracle.fr_sub(a, b)).all()
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 7), (16, 16), (33, 5), (256, 64), (100, 257)])
+def test_transpose(gpu, oracle, rows, cols):
+    a = oracle.fr_random(rows * 1000 + cols, rows * cols)
+    assert (gpu.transpose(a, rows, cols) == oracle.fr_transpose(a, rows, cols)).all()
+
+
+@pytest.mark.parametrize("n,batch", [(1, 1), (300, 1), (10000, 1), (64, 5)])
+def test_sum_and_product(gpu, oracle, n, batch):
+    a = oracle.fr_random(n + batch, n * batch)
+    vals = oracle.to_ints(a, 32)
+    want_sum = [sum(vals[b * n:(b + 1) * n]) % oracle.R_MOD for b in range(batch)]
+    assert oracle.to_ints(gpu.vec_sum(a, n, batch), 32) == want_sum
+    want_prod = []
+    for b in range(batch):
+        p = 1
+        for v in vals[b * n:(b + 1) * n]:
+            p = p * v % oracle.R_MOD
+        want_prod.append(p)
+    assert oracle.to_ints(gpu.vec_product(a, n, batch), 32) == want_prod
+
+
+def test_large_mul_linearity(gpu, oracle):
+    # size-independent property at 2^22 elements: (a + b) * c == a*c + b*c
+    n = 1 << 22
+    a, b, c = (gpu.fr_random_device(s, n) for s in (21, 22, 23))
+    lhs = gpu.vec_mul(gpu.vec_add(a, b), c)
+    rhs = gpu.vec_add(gpu.vec_mul(a, c), gpu.vec_mul(b, c))
+    assert (lhs.to_host() == rhs.to_host()).all()
+    # and the device generator equals the oracle stream
+    assert (a.to_host(32 * 1000) == oracle.fr_random(21, 1000)).all()

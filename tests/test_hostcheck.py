@@ -1,0 +1,103 @@
+"""not-gpu tier: the product's __host__ __device__ field / curve templates (csrc/ff.h, csrc/ec.h), compiled
+for the HOST into a test-only library (tests/hostcheck), agree with the oracle bit for bit.  This is the
+same source the HIP kernels inline, so arithmetic bugs are caught before a GPU is involved."""
+import ctypes
+import os
+import random
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "tokamak-zk-evm_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
+    so = os.path.join(HERE, "hostcheck", "libhostcheck.so")
+    deps = [src] + [os.path.join(CSRC, f) for f in ("ff.h", "ec.h", "field_params.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        if shutil.which("hipcc") is None:
+            pytest.skip("hipcc not available")
+        subprocess.run(["hipcc", "-O2", "-fPIC", "-shared", "--offload-host-only", "-I" + CSRC, src, "-o", so], check=True)
+    return ctypes.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _edge(mod, n, rnd):
+    v = [rnd.randrange(mod) for _ in range(n)]
+    v[:6] = [0, 1, mod - 1, mod - 2, 2, (1 << (mod.bit_length() - 1))]
+    return v
+
+
+@pytest.mark.parametrize("field", ["fr", "fq"])
+def test_field_templates(hc, oracle, field):
+    rnd = random.Random(3)
+    width, mod = (32, oracle.R_MOD) if field == "fr" else (48, oracle.P_MOD)
+    fn = getattr(hc, "hc_%s_op" % field)
+    n = 200
+    a, b = _edge(mod, n, rnd), _edge(mod, n, rnd)
+    rnd.shuffle(b)
+    A, B = oracle.to_bytes(a, width), oracle.to_bytes(b, width)
+    out = np.empty_like(A)
+    o_add, o_sub, o_mul, o_inv = [getattr(oracle, "%s_%s" % (field, k)) for k in ("add", "sub", "mul", "inv")]
+    for op, want in ((0, o_add(A, B)), (1, o_sub(A, B)), (2, o_mul(A, B)), (3, o_mul(A, B)), (4, o_inv(A)),
+                     (5, o_sub(np.zeros_like(A), A))):
+        fn(op, _p(A), _p(B), _p(out), ctypes.c_size_t(n))
+        assert (out == want).all(), "op %d" % op
+
+
+def test_g1_templates(hc, oracle):
+    g = oracle.g1_generator()
+    pts = oracle.g1_random_bases(42, 6)
+    P = [pts[96 * i:96 * (i + 1)].copy() for i in range(6)]
+    zero = np.zeros(96, np.uint8)
+    out = np.empty(96, np.uint8)
+    cases = [(P[0], P[1]), (P[2], P[2]), (P[3], oracle.g1_neg(P[3])), (zero, P[4]), (P[4], zero), (zero, zero), (g, g)]
+    for p, q in cases:
+        s = oracle.g1_add(p, q)
+        for mode in (0, 1):
+            hc.hc_g1_add(mode, _p(p), _p(q), _p(out))
+            assert (out == s).all(), mode
+        hc.hc_g1_add(2, _p(p), _p(q), _p(out))
+        assert (out == oracle.g1_add(s, s)).all()
+        hc.hc_g1_add(3, _p(p), _p(q), _p(out))
+        assert (out == oracle.g1_add(s, q)).all()
+    for k in (0, 1, 2, oracle.R_MOD - 1, 0x1234567890ABCDEF1234567890ABCDEF):
+        K = oracle.to_bytes([k], 32)
+        hc.hc_g1_scalar_mul(_p(K), _p(P[5]), _p(out))
+        assert (out == oracle.g1_scalar_mul(K, P[5])).all()
+
+
+def _hc_ntt(hc, x, logn, batch, columns, inverse, coset, max_logR, log_tile, logN):
+    out = np.empty_like(x)
+    rc = hc.hc_ntt(_p(x), logn, ctypes.c_uint64(batch), int(columns), int(inverse), _p(coset) if coset is not None else None,
+                   _p(out), max_logR, log_tile, logN)
+    assert rc > 0
+    return out, rc
+
+
+@pytest.mark.parametrize("logn,batch,max_logR,log_tile", [
+    (0, 3, 3, 5), (1, 5, 3, 5), (3, 1, 3, 5), (3, 7, 3, 5), (5, 4, 3, 5), (6, 3, 3, 5), (7, 2, 3, 5), (9, 1, 3, 5),
+    (8, 3, 4, 6), (10, 2, 9, 11), (11, 1, 9, 11), (12, 2, 9, 11),
+])
+def test_ntt_pass_plan_emulation(hc, oracle, logn, batch, max_logR, log_tile):
+    """The kernel's plan / index algebra (csrc/ntt_plan.h) reproduces the oracle NTT for 1..3-pass plans, both
+    layouts, both directions, with and without coset, with a domain larger than the transform."""
+    n = 1 << logn
+    x = oracle.fr_random(1000 + logn, n * batch)
+    g = oracle.to_bytes([0x9E3779B97F4A7C15F39CC0605CEDC834], 32)
+    for columns in (False, True):
+        for inverse in (False, True):
+            for coset in (None, g):
+                want = oracle.ntt(x, n, batch=batch, columns_batch=columns, inverse=inverse, coset_gen=coset)
+                got, passes = _hc_ntt(hc, x, logn, batch, columns, inverse, coset, max_logR, log_tile, logn + 2)
+                assert passes == max(1, -(-logn // max_logR))
+                assert (got == want).all(), (columns, inverse, coset is not None)

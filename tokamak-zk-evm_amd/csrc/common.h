@@ -1,0 +1,80 @@
+// common.h — host-side plumbing shared by the HIP translation units of libtkmk_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/tkmk.h"
+#include "ec.h"
+
+#define TK_API extern "C" __attribute__((visibility("default")))
+
+tkmk_error tk_map_hip_error(hipError_t e);
+
+#define TK_HIP(call)                                         \
+    do {                                                     \
+        hipError_t _e = (call);                              \
+        if (_e != hipSuccess) return tk_map_hip_error(_e);   \
+    } while (0)
+
+#define TK_TRY(call)                          \
+    do {                                      \
+        tkmk_error _t = (call);               \
+        if (_t != TKMK_SUCCESS) return _t;    \
+    } while (0)
+
+// Makes sure a gfx950 device is current; TKMK_ERR_NO_DEVICE otherwise (there is no CPU fallback).
+tkmk_error tk_require_device();
+
+static inline hipStream_t tk_stream(tkmk_stream s) { return (hipStream_t)s; }
+
+// Device scratch: stream-ordered allocations from the HIP memory pool (hipMallocAsync), so launchers
+// never call hipMalloc/hipFree synchronously between kernels (cdna_hip_programming.md Guideline 9).
+struct tk_scratch {
+    void *p = nullptr;
+    hipStream_t s = nullptr;
+    tkmk_error alloc(size_t bytes, hipStream_t stream);
+    ~tk_scratch();
+    tk_scratch() = default;
+    tk_scratch(const tk_scratch &) = delete;
+    tk_scratch &operator=(const tk_scratch &) = delete;
+    template <class T>
+    T *as() const { return (T *)p; }
+};
+
+// Stages a caller buffer on the device when it is a host pointer; no-op (aliases) when it is already
+// a device pointer.  copy_back() returns device results to a host destination.
+struct tk_staged {
+    void *dev = nullptr;
+    tk_scratch own;
+    tkmk_error in(const void *src, size_t bytes, bool on_device, hipStream_t s);     // for inputs
+    tkmk_error out(void *dst, size_t bytes, bool on_device, hipStream_t s);          // for outputs
+    tkmk_error copy_back(void *dst, size_t bytes, bool on_device, hipStream_t s);
+};
+
+static inline unsigned tk_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+static inline int tk_log2_exact(uint64_t n) {
+    if (n == 0 || (n & (n - 1))) return -1;
+    int l = 0;
+    while ((1ull << l) < n) l++;
+    return l;
+}
+
+// ---- 16-byte vectorised global access for field elements (2 or 3 x dwordx4 per element) ----
+template <class E>
+__device__ __forceinline__ E tk_load(const E *p) {
+    static_assert(sizeof(E) % 16 == 0, "");
+    E r;
+    const uint4 *s = reinterpret_cast<const uint4 *>(p);
+    uint4 *d = reinterpret_cast<uint4 *>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(E) / 16); i++) d[i] = s[i];
+    return r;
+}
+template <class E>
+__device__ __forceinline__ void tk_store(E *p, const E &v) {
+    uint4 *d = reinterpret_cast<uint4 *>(p);
+    const uint4 *s = reinterpret_cast<const uint4 *>(&v);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(E) / 16); i++) d[i] = s[i];
+}

@@ -1,0 +1,439 @@
+// msm.hip — BLS12-381 G1 multi-scalar multiplication (Pippenger bucket method) for gfx950 behind
+// bls12_381_msm (include/tkmk.h).  Work-alike of icicle_core::msm::msm as the reference calls it
+// (packages/backend/libs/src/iotools/mod.rs:2093-2099 encode_poly; group_structures/mod.rs:108-143).
+//
+// Pipeline (all on one stream, no host round trip until the W window sums come back):
+//   k_convert_bases   plain affine -> Montgomery affine, once per call (skipped for Montgomery input)
+//   k_digits          scalar -> W signed c-bit digits (|d| <= 2^(c-1)), coalesced [w][i] u32 records
+//   k_hist            per (window, chunk) workgroup: LDS-privatised bucket histogram (<= 128 KiB of LDS)
+//   k_scan            per window: chunk-exclusive cursors + bucket start offsets
+//   k_scatter         per (window, chunk): LDS cursors, ds_add_rtn ranks -> bucket-sorted point indices
+//   k_accumulate      one lane per bucket: XYZZ accumulator in VGPRs += gathered affine bases (8M+2S each)
+//   k_reduce_segments / k_reduce_windows   sum_v v*B_v per window via 16-bucket running sums
+//   host              Horner over the W window sums (W*c doublings) + one inversion -> canonical result
+// Sorting by bucket instead of atomically adding points: there are no 384-bit atomics, and the sorted
+// order makes each bucket a private serial chain with no inter-lane communication.
+//
+// Bound: integer VALU (v_mad_u64_u32): ~4.8e4 mul-adds per point-window vs 128 B of traffic; not HBM,
+// and MFMA is not applicable.
+#include <stdlib.h>
+
+#include <vector>
+
+#include "common.h"
+
+// --- curve arithmetic flavour for the long-running kernels: keep the 12-limb Montgomery product out of
+// line so the accumulate loop body stays small (10 inlined products are ~50 KB of code) ---
+struct FqK : Fq {
+    static __device__ __noinline__ fq_t mul(fq_t a, fq_t b) { return Fq::mul(a, b); }
+    static __device__ __forceinline__ fq_t sqr(const fq_t &a) { return mul(a, a); }
+};
+using G1K = ec<FqK>;
+using g1k_xyzz = G1K::X;
+using g1k_aff = G1K::A;
+
+static_assert(sizeof(g1_affine_t) == 96 && sizeof(g1_xyzz_t) == 192, "layout");
+
+struct msm_plan_t {
+    uint32_t n;        // points
+    uint32_t c;        // window bits
+    uint32_t W;        // windows
+    uint32_t B;        // buckets per window = 2^(c-1)
+    uint32_t chunks;   // histogram chunks per window
+    uint32_t chunk_len;
+    uint32_t bits;
+};
+
+__global__ __launch_bounds__(256) void k_convert_bases(const g1_affine_t *__restrict__ in, g1_affine_t *__restrict__ out,
+                                                      uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g1_affine_t p = tk_load(in + i);
+    if (!G1::is_inf(p)) {
+        p.x = Fq::to_mont(Fq::canon(p.x));
+        p.y = Fq::to_mont(Fq::canon(p.y));
+    }
+    tk_store(out + i, p);
+}
+
+// digit record: bit 31 = negative, low bits = |d| in [1, B]; 0 = skip
+__global__ __launch_bounds__(256) void k_digits(const fr_t *__restrict__ scalars, uint32_t *__restrict__ dig, msm_plan_t pl,
+                                               int scalars_mont) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pl.n) return;
+    fr_t s = Fr::canon(tk_load(scalars + i));
+    if (scalars_mont) s = Fr::from_mont(s);
+    uint32_t carry = 0;
+    const uint32_t mask = (1u << pl.c) - 1u;
+    for (uint32_t w = 0; w < pl.W; w++) {
+        uint32_t lo = w * pl.c, li = lo >> 5, sh = lo & 31;
+        uint32_t raw = 0;
+        if (li < 8) {
+            raw = s.l[li] >> sh;
+            if (sh + pl.c > 32 && li + 1 < 8) raw |= s.l[li + 1] << (32 - sh);
+        }
+        raw &= mask;
+        if (lo + pl.c > pl.bits) {  // drop bits above `bits`
+            uint32_t keep = pl.bits > lo ? pl.bits - lo : 0;
+            raw &= keep >= 32 ? 0xffffffffu : ((1u << keep) - 1u);
+        }
+        uint32_t v = raw + carry;
+        uint32_t rec;
+        if (v > pl.B) {
+            rec = ((1u << pl.c) - v) | 0x80000000u;
+            carry = 1;
+        } else {
+            rec = v;
+            carry = 0;
+        }
+        dig[(uint64_t)w * pl.n + i] = rec;
+    }
+}
+
+// grid (chunks, W); dynamic LDS = B * 4 bytes
+__global__ __launch_bounds__(1024) void k_hist(const uint32_t *__restrict__ dig, uint32_t *__restrict__ counts, msm_plan_t pl) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t w = blockIdx.y, ch = blockIdx.x;
+    for (uint32_t b = threadIdx.x; b < pl.B; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    uint32_t lo = ch * pl.chunk_len, hi = lo + pl.chunk_len;
+    if (hi > pl.n) hi = pl.n;
+    const uint32_t *d = dig + (uint64_t)w * pl.n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t r = d[i] & 0x7fffffffu;
+        if (r) atomicAdd(&hist[r - 1], 1u);
+    }
+    __syncthreads();
+    // counts[w][b][chunk]
+    uint32_t *c = counts + (uint64_t)w * pl.B * pl.chunks;
+    for (uint32_t b = threadIdx.x; b < pl.B; b += blockDim.x) c[(uint64_t)b * pl.chunks + ch] = hist[b];
+}
+
+// grid (W), 1024 threads.  counts[w][b][chunk] -> exclusive cursor (absolute position in the window's
+// sorted list); bstart[w][b] for b in [0, B]
+__global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ counts, uint32_t *__restrict__ bstart, msm_plan_t pl) {
+    __shared__ uint32_t part[1024];
+    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    uint32_t *c = counts + (uint64_t)w * pl.B * pl.chunks;
+    uint32_t *bs = bstart + (uint64_t)w * (pl.B + 1);
+    // each thread owns a contiguous range of buckets
+    uint32_t per = (pl.B + blockDim.x - 1) / blockDim.x;
+    uint32_t b0 = t * per, b1 = b0 + per;
+    if (b0 > pl.B) b0 = pl.B;
+    if (b1 > pl.B) b1 = pl.B;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++)
+        for (uint32_t k = 0; k < pl.chunks; k++) sum += c[(uint64_t)b * pl.chunks + k];
+    part[t] = sum;
+    __syncthreads();
+    // exclusive scan of part[] (Hillis-Steele, 1024 entries)
+    for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
+        uint32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t b = b0; b < b1; b++) {
+        bs[b] = run;
+        for (uint32_t k = 0; k < pl.chunks; k++) {
+            uint32_t v = c[(uint64_t)b * pl.chunks + k];
+            c[(uint64_t)b * pl.chunks + k] = run;
+            run += v;
+        }
+    }
+    if (t == blockDim.x - 1) bs[pl.B] = part[t];
+}
+
+// grid (chunks, W); dynamic LDS = B * 4 bytes.  sorted[w][pos] = point index | sign
+__global__ __launch_bounds__(1024) void k_scatter(const uint32_t *__restrict__ dig, const uint32_t *__restrict__ counts,
+                                                 uint32_t *__restrict__ sorted, msm_plan_t pl) {
+    extern __shared__ uint32_t cur[];
+    const uint32_t w = blockIdx.y, ch = blockIdx.x;
+    const uint32_t *c = counts + (uint64_t)w * pl.B * pl.chunks;
+    for (uint32_t b = threadIdx.x; b < pl.B; b += blockDim.x) cur[b] = c[(uint64_t)b * pl.chunks + ch];
+    __syncthreads();
+    uint32_t lo = ch * pl.chunk_len, hi = lo + pl.chunk_len;
+    if (hi > pl.n) hi = pl.n;
+    const uint32_t *d = dig + (uint64_t)w * pl.n;
+    uint32_t *s = sorted + (uint64_t)w * pl.n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t rec = d[i];
+        uint32_t r = rec & 0x7fffffffu;
+        if (r) {
+            uint32_t pos = atomicAdd(&cur[r - 1], 1u);
+            s[pos] = i | (rec & 0x80000000u);
+        }
+    }
+}
+
+// one lane per (window, bucket): sum of the bucket's (signed) bases.  GK = ec<FqK> (out-of-line product)
+// or ec<Fq> (fully inlined): selected at run time by TKMK_MSM_INLINE for A/B measurements.
+template <class GK>
+__global__ __launch_bounds__(256) void k_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
+                                                   const uint32_t *__restrict__ bstart, g1_xyzz_t *__restrict__ buckets,
+                                                   msm_plan_t pl) {
+    using XA = typename GK::X;
+    using AA = typename GK::A;
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= pl.W * pl.B) return;
+    uint32_t w = gid / pl.B, b = gid - w * pl.B;
+    const uint32_t *bs = bstart + (uint64_t)w * (pl.B + 1);
+    uint32_t lo = bs[b], hi = bs[b + 1];
+    const uint32_t *s = sorted + (uint64_t)w * pl.n;
+    XA acc = GK::inf();
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t rec = s[k];
+        AA p = tk_load(reinterpret_cast<const AA *>(bases) + (rec & 0x7fffffffu));
+        if (rec & 0x80000000u) p.y = Fq::neg(p.y);
+        acc = GK::add_mixed(acc, p);
+    }
+    tk_store(reinterpret_cast<XA *>(buckets) + gid, acc);
+}
+
+#define MSM_SEG 16
+// one lane per (window, segment of MSM_SEG buckets): seg_out = sum_{v in segment} v * B_v
+//   = tot + v0 * run   with run = sum B_v, tot = sum (v - v0) B_v by the running-sum trick
+__global__ __launch_bounds__(128) void k_reduce_segments(const g1_xyzz_t *__restrict__ buckets, g1_xyzz_t *__restrict__ seg_out,
+                                                        msm_plan_t pl, uint32_t segs) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= pl.W * segs) return;
+    uint32_t w = gid / segs, sg = gid - w * segs;
+    uint32_t v0 = sg * MSM_SEG;  // bucket array index b holds value v = b + 1; segment covers b in [v0, v0+L)
+    uint32_t len = pl.B - v0 < MSM_SEG ? pl.B - v0 : MSM_SEG;
+    const g1k_xyzz *bk = reinterpret_cast<const g1k_xyzz *>(buckets) + (uint64_t)w * pl.B + v0;
+    g1k_xyzz run = G1K::inf(), tot = G1K::inf();
+    for (int k = (int)len - 1; k >= 0; k--) {
+        run = G1K::add(run, tk_load(bk + k));
+        tot = G1K::add(tot, run);
+    }
+    // + v0 * run  (v0 < 2^15)
+    if (v0) {
+        g1k_xyzz m = G1K::inf();
+        for (int bit = 31 - __builtin_clz(v0); bit >= 0; bit--) {
+            m = G1K::dbl(m);
+            if ((v0 >> bit) & 1) m = G1K::add(m, run);
+        }
+        tot = G1K::add(tot, m);
+    }
+    tk_store(reinterpret_cast<g1k_xyzz *>(seg_out) + gid, tot);
+}
+
+// grid (W), 256 threads: window sum = sum of its segment results
+__global__ __launch_bounds__(256) void k_reduce_windows(const g1_xyzz_t *__restrict__ seg_in, g1_xyzz_t *__restrict__ win_out,
+                                                       uint32_t segs) {
+    __shared__ g1k_xyzz sh[256];
+    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    const g1k_xyzz *in = reinterpret_cast<const g1k_xyzz *>(seg_in) + (uint64_t)w * segs;
+    g1k_xyzz acc = G1K::inf();
+    for (uint32_t k = t; k < segs; k += 256) acc = G1K::add(acc, tk_load(in + k));
+    sh[t] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            acc = G1K::add(acc, sh[t + s]);
+            sh[t] = acc;
+        }
+        __syncthreads();
+    }
+    if (t == 0) tk_store(reinterpret_cast<g1k_xyzz *>(win_out) + w, acc);
+}
+
+// out[b] = [s_b] P_b : the "batch of one-point MSMs" shape (libs/src/iotools/mod.rs:1113-1151)
+__global__ __launch_bounds__(128) void k_msm_size1(const fr_t *__restrict__ scalars, const g1_affine_t *__restrict__ bases,
+                                                  int shared, uint32_t n, int points_mont, g1_xyzz_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_t s = Fr::canon(tk_load(scalars + i));
+    g1_affine_t p0 = tk_load(bases + (shared ? 0 : i));
+    g1k_aff p;
+    p.x = p0.x;
+    p.y = p0.y;
+    if (!points_mont && !G1::is_inf(p0)) {
+        p.x = Fq::to_mont(Fq::canon(p0.x));
+        p.y = Fq::to_mont(Fq::canon(p0.y));
+    }
+    g1k_xyzz acc = G1K::inf();
+    for (int bit = 254; bit >= 0; bit--) {
+        acc = G1K::dbl(acc);
+        if ((s.l[bit >> 5] >> (bit & 31)) & 1) acc = G1K::add_mixed(acc, p);
+    }
+    tk_store(reinterpret_cast<g1k_xyzz *>(out) + i, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static uint32_t choose_c(uint32_t n) {
+    // minimise W * (n + ~4*B) over c; capped at 16 by the 128 KiB LDS histogram (2^15 buckets * 4 B)
+    uint32_t best = 2;
+    double best_cost = 1e300;
+    for (uint32_t c = 2; c <= 16; c++) {
+        double W = (double)(255 / c + 1);
+        double cost = W * ((double)n + 4.0 * (double)(1u << (c - 1)));
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
+static void store_canonical(tkmk_g1_projective *o, const g1_xyzz_t &r) {
+    g1_affine_t a = G1::to_affine(r);
+    bool inf = G1::is_inf(r);
+    fq_t x = inf ? Fq::zero() : Fq::from_mont(a.x);
+    fq_t y = Fq::from_mont(a.y);
+    fq_t z = Fq::zero();
+    if (inf) {
+        y = Fq::zero();
+        y.l[0] = 1;
+    } else {
+        z.l[0] = 1;
+    }
+    for (int i = 0; i < 12; i++) {
+        o->x.limbs[i] = x.l[i];
+        o->y.limbs[i] = y.l[i];
+        o->z.limbs[i] = z.l[i];
+    }
+}
+
+TK_API tkmk_msm_config tkmk_msm_default_config(void) {
+    tkmk_msm_config c;
+    c.stream_handle = nullptr;
+    c.precompute_factor = 1;
+    c.c = 0;
+    c.bitsize = 0;
+    c.batch_size = 1;
+    c.are_points_shared_in_batch = true;
+    c.are_scalars_on_device = false;
+    c.are_scalars_montgomery_form = false;
+    c.are_points_on_device = false;
+    c.are_points_montgomery_form = false;
+    c.are_results_on_device = false;
+    c.is_async = false;
+    c.ext = nullptr;
+    return c;
+}
+
+// One MSM of n points with device-resident scalars / Montgomery bases -> host XYZZ window sums -> result.
+static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, uint32_t n, uint32_t c_req, uint32_t bits,
+                          bool scalars_mont, hipStream_t s, g1_xyzz_t *result_host) {
+    msm_plan_t pl;
+    pl.n = n;
+    pl.bits = bits;
+    pl.c = c_req ? c_req : choose_c(n);
+    if (pl.c < 2) pl.c = 2;
+    if (pl.c > 16) pl.c = 16;
+    pl.W = bits / pl.c + 1;
+    pl.B = 1u << (pl.c - 1);
+    uint32_t want = (512 + pl.W - 1) / pl.W;
+    uint32_t maxc = (n + 8191) / 8192;
+    pl.chunks = want < maxc ? want : maxc;
+    if (pl.chunks < 1) pl.chunks = 1;
+    pl.chunk_len = (n + pl.chunks - 1) / pl.chunks;
+
+    tk_scratch d_dig, d_sorted, d_counts, d_bstart, d_buckets, d_segs, d_wins;
+    TK_TRY(d_dig.alloc((size_t)pl.W * n * 4, s));
+    TK_TRY(d_sorted.alloc((size_t)pl.W * n * 4, s));
+    TK_TRY(d_counts.alloc((size_t)pl.W * pl.B * pl.chunks * 4, s));
+    TK_TRY(d_bstart.alloc((size_t)pl.W * (pl.B + 1) * 4, s));
+    TK_TRY(d_buckets.alloc((size_t)pl.W * pl.B * sizeof(g1_xyzz_t), s));
+    uint32_t segs = (pl.B + MSM_SEG - 1) / MSM_SEG;
+    TK_TRY(d_segs.alloc((size_t)pl.W * segs * sizeof(g1_xyzz_t), s));
+    TK_TRY(d_wins.alloc((size_t)pl.W * sizeof(g1_xyzz_t), s));
+
+    hipLaunchKernelGGL(k_digits, tk_div_up(n, 256), 256, 0, s, scalars, d_dig.as<uint32_t>(), pl, scalars_mont ? 1 : 0);
+    size_t lds = (size_t)pl.B * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TK_HIP(hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        TK_HIP(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_hist, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, d_counts.as<uint32_t>(), pl);
+    hipLaunchKernelGGL(k_scan, pl.W, 1024, 0, s, d_counts.as<uint32_t>(), d_bstart.as<uint32_t>(), pl);
+    hipLaunchKernelGGL(k_scatter, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, (const uint32_t *)d_counts.p,
+                       d_sorted.as<uint32_t>(), pl);
+    static const bool inline_mul = getenv("TKMK_MSM_INLINE") && atoi(getenv("TKMK_MSM_INLINE")) != 0;
+    if (inline_mul)
+        hipLaunchKernelGGL(k_accumulate<ec<Fq>>, tk_div_up((size_t)pl.W * pl.B, 256), 256, 0, s, bases_mont,
+                           (const uint32_t *)d_sorted.p, (const uint32_t *)d_bstart.p, d_buckets.as<g1_xyzz_t>(), pl);
+    else
+        hipLaunchKernelGGL(k_accumulate<G1K>, tk_div_up((size_t)pl.W * pl.B, 256), 256, 0, s, bases_mont,
+                           (const uint32_t *)d_sorted.p, (const uint32_t *)d_bstart.p, d_buckets.as<g1_xyzz_t>(), pl);
+    hipLaunchKernelGGL(k_reduce_segments, tk_div_up((size_t)pl.W * segs, 128), 128, 0, s, (const g1_xyzz_t *)d_buckets.p,
+                       d_segs.as<g1_xyzz_t>(), pl, segs);
+    hipLaunchKernelGGL(k_reduce_windows, pl.W, 256, 0, s, (const g1_xyzz_t *)d_segs.p, d_wins.as<g1_xyzz_t>(), segs);
+    TK_HIP(hipGetLastError());
+    std::vector<g1_xyzz_t> wins(pl.W);
+    TK_HIP(hipMemcpyAsync(wins.data(), d_wins.p, pl.W * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    // Horner over windows on the host: acc = 2^c * acc + W_w
+    g1_xyzz_t acc = G1::inf();
+    for (int w = (int)pl.W - 1; w >= 0; w--) {
+        for (uint32_t k = 0; k < pl.c; k++) acc = G1::dbl(acc);
+        acc = G1::add(acc, wins[w]);
+    }
+    *result_host = acc;
+    return TKMK_SUCCESS;
+}
+
+TK_API tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *bases, int msm_size, const tkmk_msm_config *cfg,
+                                tkmk_g1_projective *results) {
+    if (!cfg || cfg->ext) return TKMK_ERR_INVALID_ARGUMENT;
+    if (cfg->precompute_factor > 1) return TKMK_ERR_API_NOT_IMPLEMENTED;
+    if (msm_size < 0 || cfg->batch_size < 1 || cfg->bitsize < 0 || cfg->bitsize > 255 || cfg->c < 0 || cfg->c > 16)
+        return TKMK_ERR_INVALID_ARGUMENT;
+    if (!results) return TKMK_ERR_INVALID_POINTER;
+    TK_TRY(tk_require_device());
+    const uint32_t n = (uint32_t)msm_size, batch = (uint32_t)cfg->batch_size;
+    const uint32_t bits = cfg->bitsize ? (uint32_t)cfg->bitsize : 255u;
+    hipStream_t s = tk_stream(cfg->stream_handle);
+    std::vector<tkmk_g1_projective> host_res(batch);
+    if (n == 0) {
+        for (uint32_t b = 0; b < batch; b++) store_canonical(&host_res[b], G1::inf());
+    } else {
+        if (!scalars || !bases) return TKMK_ERR_INVALID_POINTER;
+        const size_t n_bases = cfg->are_points_shared_in_batch ? n : (size_t)n * batch;
+        tk_staged S, P;
+        TK_TRY(S.in(scalars, (size_t)n * batch * 32, cfg->are_scalars_on_device, s));
+        TK_TRY(P.in(bases, n_bases * 96, cfg->are_points_on_device, s));
+        if (n == 1) {
+            // batch of one-point MSMs = batched scalar multiplication
+            tk_scratch d_out;
+            TK_TRY(d_out.alloc((size_t)batch * sizeof(g1_xyzz_t), s));
+            hipLaunchKernelGGL(k_msm_size1, tk_div_up(batch, 128), 128, 0, s, (const fr_t *)S.dev, (const g1_affine_t *)P.dev,
+                               cfg->are_points_shared_in_batch ? 1 : 0, batch, cfg->are_points_montgomery_form ? 1 : 0,
+                               d_out.as<g1_xyzz_t>());
+            TK_HIP(hipGetLastError());
+            std::vector<g1_xyzz_t> r(batch);
+            TK_HIP(hipMemcpyAsync(r.data(), d_out.p, (size_t)batch * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, s));
+            TK_HIP(hipStreamSynchronize(s));
+            for (uint32_t b = 0; b < batch; b++) store_canonical(&host_res[b], r[b]);
+        } else {
+            const g1_affine_t *bm = (const g1_affine_t *)P.dev;
+            tk_scratch d_bm;
+            if (!cfg->are_points_montgomery_form) {
+                TK_TRY(d_bm.alloc(n_bases * 96, s));
+                hipLaunchKernelGGL(k_convert_bases, tk_div_up(n_bases, 256), 256, 0, s, (const g1_affine_t *)P.dev,
+                                   d_bm.as<g1_affine_t>(), (uint64_t)n_bases);
+                TK_HIP(hipGetLastError());
+                bm = d_bm.as<g1_affine_t>();
+            }
+            for (uint32_t b = 0; b < batch; b++) {
+                g1_xyzz_t r;
+                TK_TRY(msm_one((const fr_t *)S.dev + (size_t)b * n, bm + (cfg->are_points_shared_in_batch ? 0 : (size_t)b * n), n,
+                               (uint32_t)cfg->c, bits, cfg->are_scalars_montgomery_form, s, &r));
+                store_canonical(&host_res[b], r);
+            }
+        }
+    }
+    if (cfg->are_results_on_device) {
+        TK_HIP(hipMemcpyAsync(results, host_res.data(), (size_t)batch * sizeof(tkmk_g1_projective), hipMemcpyHostToDevice, s));
+        TK_HIP(hipStreamSynchronize(s));
+    } else {
+        for (uint32_t b = 0; b < batch; b++) results[b] = host_res[b];
+    }
+    return TKMK_SUCCESS;
+}

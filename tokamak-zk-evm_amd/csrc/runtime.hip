@@ -1,0 +1,247 @@
+// runtime.hip — device runtime entry points of the C ABI (include/tkmk.h): the work-alike of
+// icicle_runtime::{Device, DeviceVec, IcicleStream} that the reference uses around every MSM / NTT
+// (e.g. packages/backend/libs/src/bivariate_polynomial/mod.rs:446-457, libs/src/utils/mod.rs:78-110).
+#include <mutex>
+
+#include "common.h"
+
+tkmk_error tk_map_hip_error(hipError_t e) {
+    switch (e) {
+        case hipSuccess: return TKMK_SUCCESS;
+        case hipErrorOutOfMemory: return TKMK_ERR_OUT_OF_MEMORY;
+        case hipErrorInvalidDevice: return TKMK_ERR_INVALID_DEVICE;
+        case hipErrorNoDevice: return TKMK_ERR_NO_DEVICE;
+        case hipErrorInvalidValue: return TKMK_ERR_INVALID_ARGUMENT;
+        case hipErrorInvalidDevicePointer: return TKMK_ERR_INVALID_POINTER;
+        default: return TKMK_ERR_UNKNOWN;
+    }
+}
+
+static std::once_flag g_dev_once;
+static tkmk_error g_dev_status = TKMK_ERR_NO_DEVICE;
+
+tkmk_error tk_require_device() {
+    std::call_once(g_dev_once, [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+            g_dev_status = TKMK_ERR_NO_DEVICE;
+            return;
+        }
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            g_dev_status = TKMK_ERR_INVALID_DEVICE;
+            return;
+        }
+        // the code objects in this library are gfx950 only
+        const char *arch = prop.gcnArchName;
+        bool ok = arch[0] == 'g' && arch[1] == 'f' && arch[2] == 'x' && arch[3] == '9' && arch[4] == '5' && arch[5] == '0';
+        g_dev_status = ok ? TKMK_SUCCESS : TKMK_ERR_INVALID_DEVICE;
+        if (ok) {
+            // keep freed scratch in the pool instead of returning it to the driver between calls
+            hipMemPool_t pool;
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                uint64_t thr = ~0ull;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+            }
+        }
+    });
+    return g_dev_status;
+}
+
+tkmk_error tk_scratch::alloc(size_t bytes, hipStream_t stream) {
+    s = stream;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMallocAsync(&p, bytes, stream);
+    if (e != hipSuccess) {
+        p = nullptr;
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? TKMK_ERR_OUT_OF_MEMORY : TKMK_ERR_ALLOCATION_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+tk_scratch::~tk_scratch() {
+    if (p) (void)hipFreeAsync(p, s);
+}
+
+tkmk_error tk_staged::in(const void *src, size_t bytes, bool on_device, hipStream_t s) {
+    if (!src && bytes) return TKMK_ERR_INVALID_POINTER;
+    if (on_device) {
+        dev = const_cast<void *>(src);
+        return TKMK_SUCCESS;
+    }
+    TK_TRY(own.alloc(bytes, s));
+    dev = own.p;
+    TK_HIP(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, s));
+    return TKMK_SUCCESS;
+}
+tkmk_error tk_staged::out(void *dst, size_t bytes, bool on_device, hipStream_t s) {
+    if (!dst && bytes) return TKMK_ERR_INVALID_POINTER;
+    if (on_device) {
+        dev = dst;
+        return TKMK_SUCCESS;
+    }
+    TK_TRY(own.alloc(bytes, s));
+    dev = own.p;
+    return TKMK_SUCCESS;
+}
+tkmk_error tk_staged::copy_back(void *dst, size_t bytes, bool on_device, hipStream_t s) {
+    if (on_device) return TKMK_SUCCESS;
+    TK_HIP(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, s));
+    return TKMK_SUCCESS;
+}
+
+TK_API tkmk_error tkmk_device_count(int *count) {
+    if (!count) return TKMK_ERR_INVALID_POINTER;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_set_device(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TKMK_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return TKMK_ERR_INVALID_DEVICE;
+    TK_HIP(hipSetDevice(device_id));
+    return tk_require_device();
+}
+TK_API tkmk_error tkmk_get_available_memory(size_t *total, size_t *free_bytes) {
+    TK_TRY(tk_require_device());
+    size_t f = 0, t = 0;
+    TK_HIP(hipMemGetInfo(&f, &t));
+    if (total) *total = t;
+    if (free_bytes) *free_bytes = f;
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_malloc(void **ptr, size_t bytes) {
+    if (!ptr) return TKMK_ERR_INVALID_POINTER;
+    TK_TRY(tk_require_device());
+    hipError_t e = hipMalloc(ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return e == hipErrorOutOfMemory ? TKMK_ERR_OUT_OF_MEMORY : TKMK_ERR_ALLOCATION_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_malloc_async(void **ptr, size_t bytes, tkmk_stream s) {
+    if (!ptr) return TKMK_ERR_INVALID_POINTER;
+    TK_TRY(tk_require_device());
+    hipError_t e = hipMallocAsync(ptr, bytes ? bytes : 16, tk_stream(s));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return e == hipErrorOutOfMemory ? TKMK_ERR_OUT_OF_MEMORY : TKMK_ERR_ALLOCATION_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_free(void *ptr) {
+    if (!ptr) return TKMK_SUCCESS;
+    if (hipFree(ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_ERR_DEALLOCATION_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_free_async(void *ptr, tkmk_stream s) {
+    if (!ptr) return TKMK_SUCCESS;
+    if (hipFreeAsync(ptr, tk_stream(s)) != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_ERR_DEALLOCATION_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+static tkmk_error copy(void *dst, const void *src, size_t bytes, hipMemcpyKind k) {
+    if (bytes == 0) return TKMK_SUCCESS;
+    if (!dst || !src) return TKMK_ERR_INVALID_POINTER;
+    TK_TRY(tk_require_device());
+    if (hipMemcpy(dst, src, bytes, k) != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_ERR_COPY_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+static tkmk_error copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind k, tkmk_stream s) {
+    if (bytes == 0) return TKMK_SUCCESS;
+    if (!dst || !src) return TKMK_ERR_INVALID_POINTER;
+    TK_TRY(tk_require_device());
+    if (hipMemcpyAsync(dst, src, bytes, k, tk_stream(s)) != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_ERR_COPY_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_memcpy_h2d(void *dst, const void *src, size_t bytes) { return copy(dst, src, bytes, hipMemcpyHostToDevice); }
+TK_API tkmk_error tkmk_memcpy_d2h(void *dst, const void *src, size_t bytes) { return copy(dst, src, bytes, hipMemcpyDeviceToHost); }
+TK_API tkmk_error tkmk_memcpy_d2d(void *dst, const void *src, size_t bytes) { return copy(dst, src, bytes, hipMemcpyDeviceToDevice); }
+TK_API tkmk_error tkmk_memcpy_h2d_async(void *dst, const void *src, size_t bytes, tkmk_stream s) {
+    return copy_async(dst, src, bytes, hipMemcpyHostToDevice, s);
+}
+TK_API tkmk_error tkmk_memcpy_d2h_async(void *dst, const void *src, size_t bytes, tkmk_stream s) {
+    return copy_async(dst, src, bytes, hipMemcpyDeviceToHost, s);
+}
+TK_API tkmk_error tkmk_memset(void *ptr, int value, size_t bytes) {
+    if (bytes == 0) return TKMK_SUCCESS;
+    if (!ptr) return TKMK_ERR_INVALID_POINTER;
+    TK_TRY(tk_require_device());
+    TK_HIP(hipMemset(ptr, value, bytes));
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_stream_create(tkmk_stream *s) {
+    if (!s) return TKMK_ERR_INVALID_POINTER;
+    TK_TRY(tk_require_device());
+    hipStream_t h;
+    if (hipStreamCreateWithFlags(&h, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_ERR_STREAM_CREATION_FAILED;
+    }
+    *s = (tkmk_stream)h;
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_stream_synchronize(tkmk_stream s) {
+    TK_TRY(tk_require_device());
+    if (hipStreamSynchronize(tk_stream(s)) != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_ERR_SYNCHRONIZATION_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_stream_destroy(tkmk_stream s) {
+    if (!s) return TKMK_SUCCESS;
+    if (hipStreamDestroy(tk_stream(s)) != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_ERR_STREAM_DESTRUCTION_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_device_synchronize(void) {
+    TK_TRY(tk_require_device());
+    if (hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_ERR_SYNCHRONIZATION_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
+TK_API const char *tkmk_error_string(tkmk_error e) {
+    switch (e) {
+        case TKMK_SUCCESS: return "success";
+        case TKMK_ERR_INVALID_DEVICE: return "invalid device (libtkmk_hip.so carries gfx950 code objects only)";
+        case TKMK_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case TKMK_ERR_INVALID_POINTER: return "invalid pointer";
+        case TKMK_ERR_ALLOCATION_FAILED: return "allocation failed";
+        case TKMK_ERR_DEALLOCATION_FAILED: return "deallocation failed";
+        case TKMK_ERR_COPY_FAILED: return "copy failed";
+        case TKMK_ERR_SYNCHRONIZATION_FAILED: return "synchronization failed";
+        case TKMK_ERR_STREAM_CREATION_FAILED: return "stream creation failed";
+        case TKMK_ERR_STREAM_DESTRUCTION_FAILED: return "stream destruction failed";
+        case TKMK_ERR_API_NOT_IMPLEMENTED: return "not implemented";
+        case TKMK_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case TKMK_ERR_NO_DEVICE: return "no HIP device (there is no CPU fallback)";
+        default: return "unknown error";
+    }
+}
+TK_API int tkmk_is_hip_build(void) { return 1; }

@@ -1,0 +1,366 @@
+"""tkmk — Python (ctypes) binding of libtkmk_hip.so, the MI355X backend's C ABI (include/tkmk.h).
+
+This is plumbing for tests and bench.py: numpy arrays of plain little-endian field elements in, the HIP
+library does the work.  It mirrors the reference's thin wrappers over ICICLE
+(packages/backend/libs/src/vector_operations/mod.rs, bivariate_polynomial/mod.rs:_biNTT,
+iotools/mod.rs:encode_poly) — same argument meaning, errors surface as TkmkError.
+
+There is NO CPU fallback: if the shared library is missing or no gfx950 device is visible, calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libtkmk_hip.so")
+_lib = None
+
+
+class TkmkError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().tkmk_error_string(code).decode() if _lib is not None else str(code)
+        super().__init__("%s failed: %s (tkmk_error %d)" % (where, msg, code))
+
+
+class Fr(ctypes.Structure):
+    _fields_ = [("limbs", ctypes.c_uint32 * 8)]
+
+
+class MSMConfig(ctypes.Structure):
+    _fields_ = [
+        ("stream_handle", ctypes.c_void_p),
+        ("precompute_factor", ctypes.c_int),
+        ("c", ctypes.c_int),
+        ("bitsize", ctypes.c_int),
+        ("batch_size", ctypes.c_int),
+        ("are_points_shared_in_batch", ctypes.c_bool),
+        ("are_scalars_on_device", ctypes.c_bool),
+        ("are_scalars_montgomery_form", ctypes.c_bool),
+        ("are_points_on_device", ctypes.c_bool),
+        ("are_points_montgomery_form", ctypes.c_bool),
+        ("are_results_on_device", ctypes.c_bool),
+        ("is_async", ctypes.c_bool),
+        ("ext", ctypes.c_void_p),
+    ]
+
+
+class NTTConfig(ctypes.Structure):
+    _fields_ = [
+        ("stream_handle", ctypes.c_void_p),
+        ("coset_gen", Fr),
+        ("batch_size", ctypes.c_int),
+        ("columns_batch", ctypes.c_bool),
+        ("ordering", ctypes.c_int),
+        ("are_inputs_on_device", ctypes.c_bool),
+        ("are_outputs_on_device", ctypes.c_bool),
+        ("is_async", ctypes.c_bool),
+        ("ext", ctypes.c_void_p),
+    ]
+
+
+class NTTInitDomainConfig(ctypes.Structure):
+    _fields_ = [("stream_handle", ctypes.c_void_p), ("is_async", ctypes.c_bool), ("ext", ctypes.c_void_p)]
+
+
+class VecOpsConfig(ctypes.Structure):
+    _fields_ = [
+        ("stream_handle", ctypes.c_void_p),
+        ("is_a_on_device", ctypes.c_bool),
+        ("is_b_on_device", ctypes.c_bool),
+        ("is_result_on_device", ctypes.c_bool),
+        ("is_async", ctypes.c_bool),
+        ("batch_size", ctypes.c_int),
+        ("columns_batch", ctypes.c_bool),
+        ("ext", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/tkmk.h declares (tests/test_abi.py checks the library exports all of them)
+SYMBOLS = [
+    "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
+    "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
+    "tkmk_memcpy_d2h_async", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
+    "tkmk_device_synchronize", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm",
+    "tkmk_ntt_default_config", "bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain",
+    "bls12_381_ntt", "tkmk_bintt", "tkmk_vecops_default_config", "bls12_381_vector_add", "bls12_381_vector_sub",
+    "bls12_381_vector_mul", "bls12_381_vector_div", "bls12_381_vector_inv", "bls12_381_scalar_add_vec",
+    "bls12_381_scalar_sub_vec", "bls12_381_scalar_mul_vec", "bls12_381_vector_sum", "bls12_381_vector_product",
+    "bls12_381_matrix_transpose", "tkmk_fr_random_device", "tkmk_g1_batch_scalar_mul_device",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libtkmk_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.tkmk_error_string.restype = ctypes.c_char_p
+        _lib.tkmk_msm_default_config.restype = MSMConfig
+        _lib.tkmk_ntt_default_config.restype = NTTConfig
+        _lib.tkmk_vecops_default_config.restype = VecOpsConfig
+    return _lib
+
+
+def _check(code, where):
+    if code != 0:
+        raise TkmkError(code, where)
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, DeviceBuffer):
+        return ctypes.c_void_p(a.ptr)
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _on_dev(a):
+    return isinstance(a, DeviceBuffer)
+
+
+def _fr_struct(buf32):
+    f = Fr()
+    ctypes.memmove(ctypes.byref(f), buf32.ctypes.data, 32)
+    return f
+
+
+def _out_like(a, nbytes, out):
+    if out is not None:
+        return out
+    if _on_dev(a):
+        return DeviceBuffer(nbytes)
+    return np.empty(nbytes, np.uint8)
+
+
+class DeviceBuffer:
+    """RAII device allocation — the work-alike of icicle_runtime::memory::DeviceVec."""
+
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        _check(lib().tkmk_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes)), "tkmk_malloc")
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    @classmethod
+    def from_host(cls, arr):
+        d = cls(arr.size)
+        _check(lib().tkmk_memcpy_h2d(ctypes.c_void_p(d.ptr), _p(arr), ctypes.c_size_t(arr.size)), "tkmk_memcpy_h2d")
+        return d
+
+    def to_host(self, nbytes=None, offset=0):
+        n = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(n, np.uint8)
+        _check(lib().tkmk_memcpy_d2h(_p(out), ctypes.c_void_p(self.ptr + offset), ctypes.c_size_t(n)), "tkmk_memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().tkmk_free(ctypes.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def device_count():
+    n = ctypes.c_int()
+    _check(lib().tkmk_device_count(ctypes.byref(n)), "tkmk_device_count")
+    return n.value
+
+
+def set_device(i):
+    _check(lib().tkmk_set_device(int(i)), "tkmk_set_device")
+
+
+def synchronize():
+    _check(lib().tkmk_device_synchronize(), "tkmk_device_synchronize")
+
+
+def available_memory():
+    t, f = ctypes.c_size_t(), ctypes.c_size_t()
+    _check(lib().tkmk_get_available_memory(ctypes.byref(t), ctypes.byref(f)), "tkmk_get_available_memory")
+    return t.value, f.value
+
+
+# ---- NTT (reference: libs/src/bivariate_polynomial/mod.rs:33-55, 1422-1478) ----
+def get_root_of_unity(max_size):
+    out = np.empty(32, np.uint8)
+    _check(lib().bls12_381_get_root_of_unity(ctypes.c_uint64(max_size), _p(out)), "bls12_381_get_root_of_unity")
+    return out
+
+
+_domain_size = None
+
+
+def init_ntt_domain_for_size(size):
+    """grow-only global domain, like init_ntt_domain_for_size (bivariate_polynomial/mod.rs:33-55)"""
+    global _domain_size
+    if size <= 0 or size & (size - 1):
+        raise ValueError("NTT domain size must be a non-zero power of two")
+    if _domain_size is not None and _domain_size >= size:
+        return
+    if _domain_size is not None:
+        release_ntt_domain()
+    root = get_root_of_unity(size)
+    cfg = NTTInitDomainConfig(None, False, None)
+    _check(lib().bls12_381_ntt_init_domain(_p(root), ctypes.byref(cfg)), "bls12_381_ntt_init_domain")
+    _domain_size = size
+
+
+def release_ntt_domain():
+    global _domain_size
+    _check(lib().bls12_381_ntt_release_domain(), "bls12_381_ntt_release_domain")
+    _domain_size = None
+
+
+def ntt(a, n, batch=1, columns_batch=False, inverse=False, coset_gen=None, out=None, stream=None):
+    cfg = lib().tkmk_ntt_default_config()
+    cfg.batch_size = batch
+    cfg.columns_batch = columns_batch
+    if coset_gen is not None:
+        cfg.coset_gen = _fr_struct(coset_gen)
+    cfg.stream_handle = stream
+    out = _out_like(a, 32 * n * batch, out)
+    cfg.are_inputs_on_device = _on_dev(a)
+    cfg.are_outputs_on_device = _on_dev(out)
+    _check(lib().bls12_381_ntt(_p(a), int(n), 1 if inverse else 0, ctypes.byref(cfg), _p(out)), "bls12_381_ntt")
+    return out
+
+
+def bintt(a, x_size, y_size, inverse=False, coset_x=None, coset_y=None, out=None, stream=None):
+    out = _out_like(a, 32 * x_size * y_size, out)
+    if _on_dev(a) != _on_dev(out):
+        raise ValueError("tkmk_bintt takes both buffers on the same side")
+    _check(lib().tkmk_bintt(_p(a), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size), 1 if inverse else 0, _p(coset_x),
+                            _p(coset_y), _on_dev(a), ctypes.c_void_p(stream), _p(out)), "tkmk_bintt")
+    return out
+
+
+# ---- vector ops (reference: libs/src/vector_operations/mod.rs:30-139) ----
+def _vec(name, a, b, n, out, batch=1, columns_batch=False, out_elems=None):
+    cfg = lib().tkmk_vecops_default_config()
+    cfg.is_a_on_device = _on_dev(a)
+    cfg.is_b_on_device = _on_dev(b) if b is not None else False
+    cfg.batch_size = batch
+    cfg.columns_batch = columns_batch
+    nbytes = 32 * (out_elems if out_elems is not None else n * batch)
+    if out is None:
+        out = DeviceBuffer(nbytes) if (_on_dev(a) or _on_dev(b)) else np.empty(nbytes, np.uint8)
+    cfg.is_result_on_device = _on_dev(out)
+    fn = getattr(lib(), name)
+    if b is None:
+        _check(fn(_p(a), ctypes.c_uint64(n), ctypes.byref(cfg), _p(out)), name)
+    else:
+        _check(fn(_p(a), _p(b), ctypes.c_uint64(n), ctypes.byref(cfg), _p(out)), name)
+    return out
+
+
+def vec_add(a, b, out=None):
+    return _vec("bls12_381_vector_add", a, b, _len(a), out)
+
+
+def vec_sub(a, b, out=None):
+    return _vec("bls12_381_vector_sub", a, b, _len(a), out)
+
+
+def vec_mul(a, b, out=None):
+    return _vec("bls12_381_vector_mul", a, b, _len(a), out)
+
+
+def vec_div(a, b, out=None):
+    return _vec("bls12_381_vector_div", a, b, _len(a), out)
+
+
+def vec_inv(a, out=None):
+    return _vec("bls12_381_vector_inv", a, None, _len(a), out)
+
+
+def scalar_add(s, v, out=None):
+    return _vec("bls12_381_scalar_add_vec", s, v, _len(v), out)
+
+
+def scalar_sub(s, v, out=None):
+    return _vec("bls12_381_scalar_sub_vec", s, v, _len(v), out)
+
+
+def scalar_mul(s, v, out=None):
+    return _vec("bls12_381_scalar_mul_vec", s, v, _len(v), out)
+
+
+def vec_sum(a, n=None, batch=1, columns_batch=False):
+    n = _len(a) // batch if n is None else n
+    return _vec("bls12_381_vector_sum", a, None, n, None, batch, columns_batch, out_elems=batch)
+
+
+def vec_product(a, n=None, batch=1, columns_batch=False):
+    n = _len(a) // batch if n is None else n
+    return _vec("bls12_381_vector_product", a, None, n, None, batch, columns_batch, out_elems=batch)
+
+
+def transpose(a, rows, cols, out=None):
+    cfg = lib().tkmk_vecops_default_config()
+    cfg.is_a_on_device = _on_dev(a)
+    out = _out_like(a, 32 * rows * cols, out)
+    cfg.is_result_on_device = _on_dev(out)
+    _check(lib().bls12_381_matrix_transpose(_p(a), ctypes.c_uint32(rows), ctypes.c_uint32(cols), ctypes.byref(cfg), _p(out)),
+           "bls12_381_matrix_transpose")
+    return out
+
+
+def _len(a):
+    return (a.nbytes if _on_dev(a) else a.size) // 32
+
+
+# ---- MSM (reference: libs/src/iotools/mod.rs:2093-2099, group_structures/mod.rs:108-143) ----
+def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize=0, stream=None):
+    """returns `batch` projective results (144 B each) on the host"""
+    cfg = lib().tkmk_msm_default_config()
+    n = _len(scalars) // batch if msm_size is None else msm_size
+    cfg.batch_size = batch
+    cfg.are_points_shared_in_batch = shared_points
+    cfg.are_scalars_on_device = _on_dev(scalars)
+    cfg.are_points_on_device = _on_dev(bases)
+    cfg.c = c
+    cfg.bitsize = bitsize
+    cfg.stream_handle = stream
+    out = np.empty(144 * batch, np.uint8)
+    _check(lib().bls12_381_msm(_p(scalars), _p(bases), int(n), ctypes.byref(cfg), _p(out)), "bls12_381_msm")
+    return out
+
+
+def projective_to_affine_bytes(p144):
+    """ABI results are canonical (x_aff, y_aff, 1) / (0,1,0): dropping z is the affine conversion"""
+    out = []
+    for i in range(0, p144.size, 144):
+        z = p144[i + 96:i + 144]
+        out.append(np.zeros(96, np.uint8) if not z.any() else p144[i:i + 96].copy())
+    return np.concatenate(out)
+
+
+# ---- deterministic device-side input generation ----
+def fr_random_device(seed, n, first=0, out=None):
+    out = DeviceBuffer(32 * n) if out is None else out
+    _check(lib().tkmk_fr_random_device(ctypes.c_uint64(seed), ctypes.c_uint64(first), ctypes.c_uint64(n), _p(out), None),
+           "tkmk_fr_random_device")
+    return out
+
+
+def g1_batch_scalar_mul_device(scalars_dev, base_host, n, out=None):
+    out = DeviceBuffer(96 * n) if out is None else out
+    _check(lib().tkmk_g1_batch_scalar_mul_device(_p(scalars_dev), _p(base_host), ctypes.c_uint64(n), _p(out), None),
+           "tkmk_g1_batch_scalar_mul_device")
+    return out
+
+
+def diag_bench(kind, iters, blocks, reps=3):
+    ms = ctypes.c_float()
+    _check(lib().tkmk_diag_bench(int(kind), ctypes.c_uint32(iters), ctypes.c_uint32(blocks), int(reps), ctypes.byref(ms)),
+           "tkmk_diag_bench")
+    return ms.value
