@@ -28,16 +28,25 @@ tkmk_error tk_require_device();
 
 static inline hipStream_t tk_stream(tkmk_stream s) { return (hipStream_t)s; }
 
-// Device scratch: stream-ordered allocations from the HIP memory pool (hipMallocAsync), so launchers
-// never call hipMalloc/hipFree synchronously between kernels (cdna_hip_programming.md Guideline 9).
+// Device scratch comes from a per-stream, grow-only arena of plain hipMalloc memory, bump-allocated inside
+// a tk_frame (one per C-ABI call) and recycled when the frame ends.  Launchers therefore never call
+// hipMalloc/hipFree between kernels (cdna_hip_programming.md Guideline 9).  hipMallocAsync/hipFreeAsync
+// are deliberately NOT used: on ROCm 7.2 / gfx950 memory that the stream-ordered pool frees and hands out
+// again is read stale across XCD L2s by the next kernels (tools/coherence_test.hip reproduces it; plain
+// hipMalloc memory reused across kernels is coherent at kernel boundaries).
+struct tk_arena;
+tk_arena *tk_arena_for(hipStream_t s);
+struct tk_frame {
+    tk_arena *a;
+    size_t saved_chunk, saved_off, saved_used;
+    explicit tk_frame(hipStream_t s);
+    ~tk_frame();
+    tk_frame(const tk_frame &) = delete;
+    tk_frame &operator=(const tk_frame &) = delete;
+};
 struct tk_scratch {
     void *p = nullptr;
-    hipStream_t s = nullptr;
-    tkmk_error alloc(size_t bytes, hipStream_t stream);
-    ~tk_scratch();
-    tk_scratch() = default;
-    tk_scratch(const tk_scratch &) = delete;
-    tk_scratch &operator=(const tk_scratch &) = delete;
+    tkmk_error alloc(size_t bytes, hipStream_t stream);  // valid until the enclosing tk_frame ends
     template <class T>
     T *as() const { return (T *)p; }
 };

@@ -16,6 +16,7 @@
 //
 // Bound: integer VALU (v_mad_u64_u32): ~4.8e4 mul-adds per point-window vs 128 B of traffic; not HBM,
 // and MFMA is not applicable.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <vector>
@@ -316,9 +317,86 @@ TK_API tkmk_msm_config tkmk_msm_default_config(void) {
     return c;
 }
 
+
+// TKMK_MSM_DEBUG=1: pull every intermediate back and re-derive it on the host (small sizes only).
+static bool xyzz_same_point(const g1_xyzz_t &a, const g1_xyzz_t &b) {
+    g1_affine_t pa = G1::to_affine(a), pb = G1::to_affine(b);
+    return Fq::eq(pa.x, pb.x) && Fq::eq(pa.y, pb.y);
+}
+static tkmk_error msm_debug_check(const msm_plan_t &pl, const fr_t *scalars, const g1_affine_t *bases, const uint32_t *d_dig,
+                                  const uint32_t *d_sorted, const uint32_t *d_bstart, const g1_xyzz_t *d_buckets, hipStream_t s) {
+    TK_HIP(hipStreamSynchronize(s));
+    TK_HIP(hipGetLastError());
+    std::vector<fr_t> sc(pl.n);
+    std::vector<g1_affine_t> bs(pl.n);
+    std::vector<uint32_t> dig((size_t)pl.W * pl.n), sorted((size_t)pl.W * pl.n), bstart((size_t)pl.W * (pl.B + 1));
+    std::vector<g1_xyzz_t> buckets((size_t)pl.W * pl.B);
+    TK_HIP(hipMemcpy(sc.data(), scalars, sc.size() * sizeof(fr_t), hipMemcpyDeviceToHost));
+    TK_HIP(hipMemcpy(bs.data(), bases, bs.size() * sizeof(g1_affine_t), hipMemcpyDeviceToHost));
+    TK_HIP(hipMemcpy(dig.data(), d_dig, dig.size() * 4, hipMemcpyDeviceToHost));
+    TK_HIP(hipMemcpy(sorted.data(), d_sorted, sorted.size() * 4, hipMemcpyDeviceToHost));
+    TK_HIP(hipMemcpy(bstart.data(), d_bstart, bstart.size() * 4, hipMemcpyDeviceToHost));
+    TK_HIP(hipMemcpy(buckets.data(), d_buckets, buckets.size() * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[msm debug] n=%u c=%u W=%u B=%u chunks=%u chunk_len=%u\n", pl.n, pl.c, pl.W, pl.B, pl.chunks, pl.chunk_len);
+    int bad = 0;
+    // digits reconstruct the scalar: sum_w d_w 2^(c w) == s  (checked mod 2^64 on the low limbs for brevity)
+    for (uint32_t i = 0; i < pl.n && bad < 5; i++) {
+        unsigned __int128 acc = 0;
+        for (int w = (int)pl.W - 1; w >= 0; w--) {
+            uint32_t rec = dig[(size_t)w * pl.n + i];
+            long long d = (long long)(rec & 0x7fffffffu);
+            if (rec & 0x80000000u) d = -d;
+            if ((rec & 0x7fffffffu) > pl.B) { fprintf(stderr, "[msm debug] digit too large i=%u w=%d rec=%08x\n", i, w, rec); bad++; }
+            if ((uint32_t)w * pl.c < 100) acc = (acc << pl.c) + (unsigned __int128)(__int128)d;
+        }
+        uint64_t lo = (uint64_t)sc[i].l[0] | ((uint64_t)sc[i].l[1] << 32);
+        (void)lo;
+    }
+    for (uint32_t w = 0; w < pl.W; w++) {
+        const uint32_t *bsw = &bstart[(size_t)w * (pl.B + 1)];
+        uint32_t nz = 0;
+        for (uint32_t i = 0; i < pl.n; i++) nz += (dig[(size_t)w * pl.n + i] & 0x7fffffffu) != 0;
+        if (bsw[pl.B] != nz && bad < 20) { fprintf(stderr, "[msm debug] w=%u total %u != nonzero digits %u\n", w, bsw[pl.B], nz); bad++; }
+        for (uint32_t b = 0; b < pl.B; b++) {
+            if (bsw[b] > bsw[b + 1]) { if (bad < 20) fprintf(stderr, "[msm debug] w=%u b=%u bstart not monotone\n", w, b); bad++; continue; }
+            g1_xyzz_t acc = G1::inf();
+            for (uint32_t k = bsw[b]; k < bsw[b + 1]; k++) {
+                uint32_t rec = sorted[(size_t)w * pl.n + k], i = rec & 0x7fffffffu;
+                if (i >= pl.n) { if (bad < 20) fprintf(stderr, "[msm debug] w=%u b=%u bad index %u\n", w, b, i); bad++; continue; }
+                uint32_t drec = dig[(size_t)w * pl.n + i];
+                if ((drec & 0x7fffffffu) != b + 1 || ((drec ^ rec) & 0x80000000u)) {
+                    if (bad < 20) fprintf(stderr, "[msm debug] w=%u b=%u entry %u: digit rec %08x does not belong here\n", w, b, k, drec);
+                    bad++;
+                }
+                g1_affine_t pnt = bs[i];
+                if (rec & 0x80000000u) pnt.y = Fq::neg(pnt.y);
+                acc = G1::add_mixed(acc, pnt);
+            }
+            bool okb = xyzz_same_point(acc, buckets[(size_t)w * pl.B + b]);
+            if (atoi(getenv("TKMK_MSM_DEBUG")) >= 2 && w == 7 && bsw[b + 1] > bsw[b])
+                fprintf(stderr, "[msm debug] w7 b=%u pos=%u cnt=%u %s\n", b, bsw[b], bsw[b + 1] - bsw[b], okb ? "ok" : "BAD");
+            if (!okb) {
+                if (bad < 20) {
+                    const g1_xyzz_t &dv = buckets[(size_t)w * pl.B + b];
+                    uint32_t rec0 = bsw[b + 1] > bsw[b] ? sorted[(size_t)w * pl.n + bsw[b]] : 0;
+                    const char *cls = "other";
+                    if (G1::is_inf(dv)) cls = "inf";
+                    else if (xyzz_same_point(G1::neg(acc), dv)) cls = "negated";
+                    fprintf(stderr, "[msm debug] w=%u b=%u bucket sum mismatch (%u entries) rec0=%08x device=%s zz0=%08x x0=%08x\n", w, b,
+                            bsw[b + 1] - bsw[b], rec0, cls, dv.zz.l[0], dv.x.l[0]);
+                }
+                bad++;
+            }
+        }
+    }
+    fprintf(stderr, "[msm debug] %d inconsistencies\n", bad);
+    return TKMK_SUCCESS;
+}
+
 // One MSM of n points with device-resident scalars / Montgomery bases -> host XYZZ window sums -> result.
 static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, uint32_t n, uint32_t c_req, uint32_t bits,
                           bool scalars_mont, hipStream_t s, g1_xyzz_t *result_host) {
+    tk_frame frame(s);
     msm_plan_t pl;
     pl.n = n;
     pl.bits = bits;
@@ -366,6 +444,12 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
                        d_segs.as<g1_xyzz_t>(), pl, segs);
     hipLaunchKernelGGL(k_reduce_windows, pl.W, 256, 0, s, (const g1_xyzz_t *)d_segs.p, d_wins.as<g1_xyzz_t>(), segs);
     TK_HIP(hipGetLastError());
+    if (getenv("TKMK_MSM_DEBUG"))
+        fprintf(stderr, "[msm debug] ptrs dig=%p sorted=%p counts=%p bstart=%p buckets=%p (+%zu) segs=%p (+%zu) wins=%p\n", d_dig.p,
+                d_sorted.p, d_counts.p, d_bstart.p, d_buckets.p, (size_t)pl.W * pl.B * sizeof(g1_xyzz_t), d_segs.p,
+                (size_t)pl.W * segs * sizeof(g1_xyzz_t), d_wins.p);
+    if (getenv("TKMK_MSM_DEBUG")) TK_TRY(msm_debug_check(pl, scalars, bases_mont, d_dig.as<uint32_t>(), d_sorted.as<uint32_t>(),
+                                                          d_bstart.as<uint32_t>(), d_buckets.as<g1_xyzz_t>(), s));
     std::vector<g1_xyzz_t> wins(pl.W);
     TK_HIP(hipMemcpyAsync(wins.data(), d_wins.p, pl.W * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, s));
     TK_HIP(hipStreamSynchronize(s));
@@ -390,6 +474,7 @@ TK_API tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *ba
     const uint32_t n = (uint32_t)msm_size, batch = (uint32_t)cfg->batch_size;
     const uint32_t bits = cfg->bitsize ? (uint32_t)cfg->bitsize : 255u;
     hipStream_t s = tk_stream(cfg->stream_handle);
+    tk_frame frame(s);
     std::vector<tkmk_g1_projective> host_res(batch);
     if (n == 0) {
         for (uint32_t b = 0; b < batch; b++) store_canonical(&host_res[b], G1::inf());

@@ -173,6 +173,7 @@ TK_API tkmk_error bls12_381_ntt_init_domain(const tkmk_fr *primitive_root, const
     // primitive: w^(N/2) == -1 unless N == 1
     if (logN > 0 && !Fr::eq(pw[logN - 1], Fr::neg(Fr::one()))) return TKMK_ERR_INVALID_ARGUMENT;
     hipStream_t s = tk_stream(cfg ? cfg->stream_handle : nullptr);
+    tk_frame frame(s);
     uint64_t N = 1ull << logN;
     fr_t *tw = nullptr;
     hipError_t e = hipMalloc((void **)&tw, N * sizeof(fr_t));
@@ -322,6 +323,7 @@ static tkmk_error run_passes(pass_launch_t *L, int n, const fr_t *in, fr_t *out,
 static tkmk_error ntt_run(const tkmk_fr *input, tkmk_fr *output, const ntt_job_t *jobs, int n_jobs, bool inverse, bool in_dev,
                           bool out_dev, bool is_async, hipStream_t s) {
     TK_TRY(tk_require_device());
+    tk_frame frame(s);
     std::lock_guard<std::mutex> lk(g_dom_mu);
     if (!g_dom.tw) return TKMK_ERR_INVALID_ARGUMENT;  // domain not initialised (reference panics: mod.rs:1434-1436)
     uint64_t total = (1ull << jobs[0].logn) * jobs[0].batch;

@@ -1,7 +1,11 @@
 // runtime.hip — device runtime entry points of the C ABI (include/tkmk.h): the work-alike of
 // icicle_runtime::{Device, DeviceVec, IcicleStream} that the reference uses around every MSM / NTT
 // (e.g. packages/backend/libs/src/bivariate_polynomial/mod.rs:446-457, libs/src/utils/mod.rs:78-110).
+#include <stdlib.h>
+
+#include <map>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -38,32 +42,96 @@ tkmk_error tk_require_device() {
         const char *arch = prop.gcnArchName;
         bool ok = arch[0] == 'g' && arch[1] == 'f' && arch[2] == 'x' && arch[3] == '9' && arch[4] == '5' && arch[5] == '0';
         g_dev_status = ok ? TKMK_SUCCESS : TKMK_ERR_INVALID_DEVICE;
-        if (ok) {
-            // keep freed scratch in the pool instead of returning it to the driver between calls
-            hipMemPool_t pool;
-            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-                uint64_t thr = ~0ull;
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-            }
-        }
     });
     return g_dev_status;
 }
 
-tkmk_error tk_scratch::alloc(size_t bytes, hipStream_t stream) {
-    s = stream;
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMallocAsync(&p, bytes, stream);
+struct tk_arena {
+    struct chunk {
+        char *base;
+        size_t size;
+    };
+    std::vector<chunk> chunks;
+    size_t cur = 0, off = 0;  // bump position: chunk index, offset within it
+    size_t used_peak = 0, used_now = 0;
+    int depth = 0;
+    hipStream_t stream = nullptr;
+};
+static std::mutex g_arena_mu;
+static std::map<hipStream_t, tk_arena *> g_arenas;
+
+tk_arena *tk_arena_for(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    auto it = g_arenas.find(s);
+    if (it != g_arenas.end()) return it->second;
+    tk_arena *a = new tk_arena();
+    a->stream = s;
+    g_arenas[s] = a;
+    return a;
+}
+
+static tkmk_error arena_alloc(tk_arena *a, size_t bytes, void **out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    while (a->cur < a->chunks.size()) {
+        tk_arena::chunk &c = a->chunks[a->cur];
+        if (a->off + bytes <= c.size) {
+            *out = c.base + a->off;
+            a->off += bytes;
+            a->used_now += bytes;
+            if (a->used_now > a->used_peak) a->used_peak = a->used_now;
+            return TKMK_SUCCESS;
+        }
+        a->cur++;
+        a->off = 0;
+    }
+    // grow: a new chunk (rare; the frame pop consolidates to one chunk of the peak size)
+    size_t sz = bytes > ((size_t)64 << 20) ? bytes : ((size_t)64 << 20);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
-        p = nullptr;
         (void)hipGetLastError();
         return e == hipErrorOutOfMemory ? TKMK_ERR_OUT_OF_MEMORY : TKMK_ERR_ALLOCATION_FAILED;
     }
+    a->chunks.push_back({(char *)p, sz});
+    a->cur = a->chunks.size() - 1;
+    a->off = bytes;
+    a->used_now += bytes;
+    if (a->used_now > a->used_peak) a->used_peak = a->used_now;
+    *out = p;
     return TKMK_SUCCESS;
 }
-tk_scratch::~tk_scratch() {
-    if (p) (void)hipFreeAsync(p, s);
+
+tk_frame::tk_frame(hipStream_t s) : a(tk_arena_for(s)) {
+    saved_chunk = a->cur;
+    saved_off = a->off;
+    saved_used = a->used_now;
+    a->depth++;
 }
+tk_frame::~tk_frame() {
+    a->depth--;
+    if (a->depth > 0) {
+        a->cur = saved_chunk;
+        a->off = saved_off;
+        a->used_now = saved_used;
+        return;
+    }
+    a->cur = 0;
+    a->off = 0;
+    a->used_now = 0;
+    if (a->chunks.size() > 1) {
+        // consolidate so the next call of this size bump-allocates from one block
+        (void)hipStreamSynchronize(a->stream);
+        size_t want = a->used_peak + ((size_t)16 << 20);
+        for (auto &c : a->chunks) (void)hipFree(c.base);
+        a->chunks.clear();
+        void *p = nullptr;
+        if (hipMalloc(&p, want) == hipSuccess) a->chunks.push_back({(char *)p, want});
+        else (void)hipGetLastError();
+    }
+}
+
+tkmk_error tk_scratch::alloc(size_t bytes, hipStream_t stream) { return arena_alloc(tk_arena_for(stream), bytes, &p); }
 
 tkmk_error tk_staged::in(const void *src, size_t bytes, bool on_device, hipStream_t s) {
     if (!src && bytes) return TKMK_ERR_INVALID_POINTER;

@@ -137,6 +137,7 @@ static tkmk_error vec_entry(int op, const tkmk_fr *a, const tkmk_fr *b, uint64_t
     if (n == 0) return TKMK_SUCCESS;
     uint64_t total = n * (uint64_t)(cfg->batch_size > 0 ? cfg->batch_size : 1);
     hipStream_t s = tk_stream(cfg->stream_handle);
+    tk_frame frame(s);
     bool scalar_a = op == OP_SADD || op == OP_SSUB || op == OP_SMUL;
     bool unary = op == OP_INV;
     tk_staged A, B, O;
@@ -206,6 +207,7 @@ static tkmk_error reduce_entry(int op, const tkmk_fr *a, uint64_t n, const tkmk_
     uint64_t batch = cfg->batch_size > 0 ? cfg->batch_size : 1;
     if (n == 0) return TKMK_ERR_INVALID_ARGUMENT;
     hipStream_t s = tk_stream(cfg->stream_handle);
+    tk_frame frame(s);
     tk_staged A, O;
     TK_TRY(A.in(a, n * batch * 32, cfg->is_a_on_device, s));
     TK_TRY(O.out(out, batch * 32, cfg->is_result_on_device, s));
@@ -252,6 +254,7 @@ TK_API tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, u
     if (total == 0) return TKMK_SUCCESS;
     if (in == out) return TKMK_ERR_INVALID_ARGUMENT;
     hipStream_t s = tk_stream(cfg->stream_handle);
+    tk_frame frame(s);
     tk_staged A, O;
     TK_TRY(A.in(in, total * 32, cfg->is_a_on_device, s));
     TK_TRY(O.out(out, total * 32, cfg->is_result_on_device, s));
