@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — headline measurement of the hot path on MI355X (one process per GPU).
+
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
+  N = 1 : BASELINE.json configs[1] — one 2^24-point G1 Pippenger MSM.  (Curve: BLS12-381, the only curve
+          the reference uses — SURVEY.md §0.2; BASELINE.json's "BN254" has no reference counterpart.)
+  N > 1 : the same per-GPU shard on every rank (weak scaling, SURVEY.md §8e: the MSM shards by points),
+          partial results exchanged with ONE RCCL all_gather of 144-byte points, then summed by a
+          world_size-point MSM with unit scalars on every rank.
+Inputs are generated on the device from a seed: scalars = splitmix64 stream mod r,
+bases P_i = [h_i]G.  Prints ONE JSON line (rank 0).
+
+value = "MSM field-adds/sec": group additions per second at the algorithmic count SURVEY.md §8d fixes for
+this config (ceil(255/16) = 16 bucket-accumulate adds per point, independent of the window width the
+kernel actually picks, so the figure is points/s x 16 and cannot be inflated by doing more work).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tokamak-zk-evm_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ADDS_PER_POINT = 16              # SURVEY.md §8d cfg 2: N * ceil(b/c) at c = 16, b = 255
+ALG_BYTES_PER_POINT = 32 + 96    # each scalar and base read once
+SEED = 0x746F6B616D616B00
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--logn", type=int, default=24, help="log2 of points per GPU (default: BASELINE configs[1])")
+    ap.add_argument("--cpu-sample-logn", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+
+    import torch
+    import tkmk
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    tkmk.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n = 1 << args.logn
+    # --- synthetic inputs, generated in HBM (untimed) ---
+    scalars = tkmk.fr_random_device(SEED + 2 + 16 * rank, n)
+    h = tkmk.fr_random_device(SEED + 3 + 16 * rank, n)
+    g = np.frombuffer(bytes(_generator()), np.uint8).copy()
+    bases = tkmk.g1_batch_scalar_mul_device(h, g, n)
+    h.free()
+    ones = np.zeros(32 * world, np.uint8)
+    ones[0::32] = 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tkmk.synchronize()
+
+    def step():
+        part = tkmk.msm(scalars, bases)                      # 144-byte canonical projective, on the host
+        if dist is None:
+            return part
+        mine = torch.from_numpy(part).cuda()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)                      # RCCL over xGMI: world x 144 B
+        pts = torch.stack(gathered).cpu().numpy()
+        aff = np.concatenate([tkmk.projective_to_affine_bytes(p) for p in pts])
+        return tkmk.msm(ones, aff)                           # sum of the partial results, on the GPU
+
+    for _ in range(args.warmup):
+        step()
+    tkmk.profile_enable(True)
+    tkmk.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tkmk.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
+    sections = {}
+    for name in ("convert_bases", "digits", "hist", "scan", "scatter", "accumulate", "reduce_segments", "reduce_windows"):
+        ms, cnt = tkmk.profile_get("msm." + name)
+        if cnt:
+            sections[name] = round(ms / cnt, 4)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        points_per_s = n * world * args.steps / elapsed
+        value = points_per_s * ADDS_PER_POINT
+        # dominant kernel: k_accumulate (one launch per MSM of n points)
+        launches = acc_cnt if acc_cnt else 1
+        kernel_ms = acc_ms / launches if acc_cnt else float("nan")
+        alg_bytes = n * ALG_BYTES_PER_POINT
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = _traffic_from_profiles(args.logn)
+        out = {
+            "metric": "MSM field-adds/sec",
+            "value": value,
+            "unit": "group-adds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (381-bit Fq / 255-bit Fr modular integer arithmetic)",
+            "data": "synthetic",
+            "config": {"workload": "2^%d-point BLS12-381 G1 Pippenger MSM per GPU (BASELINE.json configs[1]), inputs resident in HBM"
+                                   % args.logn,
+                       "points_per_gpu": n, "sharding": "points" if world > 1 else "none"},
+            "points_per_s": points_per_s,
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "integer-VALU bound by construction (SURVEY.md §8d): ~375 int mul-adds per algorithmic byte"},
+            "kernel_ms": sections,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = _cpu_baseline(tkmk, args.cpu_sample_logn)
+        out["result_x_lo"] = int.from_bytes(bytes(result[:8]), "little")
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _generator():
+    # standard G1 generator, u32 LE limbs (reference pin: setup/mpc-setup/src/conversions.rs:68-79)
+    x = [0xdb22c6bb, 0xfb3af00a, 0xf97a1aef, 0x6c55e83f, 0x171bac58, 0xa14e3a3f, 0x9774b905, 0xc3688c4f, 0x4fa9ac0f,
+         0x2695638c, 0x3197d794, 0x17f1d3a7]
+    y = [1187375073, 212476713, 2726857444, 3493644100, 738505709, 14358731, 3587181302, 4243972245, 1948093156,
+         2694721773, 3819610353, 146011265]
+    return b"".join(int(v).to_bytes(4, "little") for v in x + y)
+
+
+def _traffic_from_profiles(logn):
+    """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC summary (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+        key = "msm_accumulate_2^%d" % logn
+        return t.get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def _cpu_baseline(tkmk, sample_logn):
+    """The oracle's Pippenger (a C port; the reference's Rust+ICICLE CPU path cannot be built offline) on a
+    bounded sample of the same workload, all host threads, checked against the GPU on that sample."""
+    import oracle
+    m = 1 << sample_logn
+    s = tkmk.fr_random_device(SEED + 2, m)
+    hh = tkmk.fr_random_device(SEED + 3, m)
+    g = np.frombuffer(bytes(_generator()), np.uint8).copy()
+    b = tkmk.g1_batch_scalar_mul_device(hh, g, m)
+    sh, bh = s.to_host(), b.to_host()
+    t0 = time.perf_counter()
+    want = oracle.g1_msm(sh, bh)
+    dt = time.perf_counter() - t0
+    got = tkmk.projective_to_affine_bytes(tkmk.msm(s, b))
+    return {"value": m / dt * ADDS_PER_POINT, "unit": "group-adds/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": "one 2^%d-point MSM (first 2^%d points of the benchmark stream), %.2f s" % (sample_logn, sample_logn, dt),
+            "points_per_s": m / dt, "matches_gpu": bool((got == want).all())}
+
+
+if __name__ == "__main__":
+    main()

@@ -205,6 +205,18 @@ tkmk_error tkmk_fr_random_device(uint64_t seed, uint64_t first, uint64_t n, tkmk
 tkmk_error tkmk_g1_batch_scalar_mul_device(const tkmk_fr *scalars_dev, const tkmk_g1_affine *base_host,
                                            uint64_t n, tkmk_g1_affine *out_dev, tkmk_stream s);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement hooks (no reference counterpart; the reference's `timing` feature wraps host spans:
+ * libs/src/lib.rs:11-141).  When enabled, launchers bracket each kernel with HIP events recorded on the
+ * launch stream; names: "msm.digits|hist|scan|scatter|accumulate|reduce_segments|reduce_windows|
+ * convert_bases", "ntt.pass<k>".  Enabling it adds one stream synchronisation per call.
+ * --------------------------------------------------------------------------------------------- */
+tkmk_error tkmk_profile_enable(int on);
+tkmk_error tkmk_profile_reset(void);
+tkmk_error tkmk_profile_get(const char *name, double *sum_ms, int *count);
+/* arithmetic micro-benchmarks (kind 0 Fr mul, 1 Fq mul, 2 v_mad_u64_u32, 3 G1 mixed add, 4 Fr add+sub, 5 Fq sqr) */
+tkmk_error tkmk_diag_bench(int kind, uint32_t iters, uint32_t blocks, int reps, float *ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
+#include <utility>
+#include <vector>
+
 #include "../../include/tkmk.h"
 #include "ec.h"
 
@@ -59,6 +63,18 @@ struct tk_staged {
     tkmk_error in(const void *src, size_t bytes, bool on_device, hipStream_t s);     // for inputs
     tkmk_error out(void *dst, size_t bytes, bool on_device, hipStream_t s);          // for outputs
     tkmk_error copy_back(void *dst, size_t bytes, bool on_device, hipStream_t s);
+};
+
+// Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).  Off unless
+// tkmk_profile_enable(1); when on, tk_prof::mark(name) brackets the kernels launched since the last mark.
+struct tk_prof {
+    hipStream_t s;
+    bool on;
+    std::vector<std::pair<std::string, hipEvent_t>> ev;
+    explicit tk_prof(hipStream_t stream);
+    ~tk_prof();
+    void mark(const char *name);  // ends the section `name` (sections start at the previous mark)
+    void finish();                // synchronises and publishes the section times
 };
 
 static inline unsigned tk_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

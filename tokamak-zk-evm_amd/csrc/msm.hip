@@ -421,7 +421,9 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
     TK_TRY(d_segs.alloc((size_t)pl.W * segs * sizeof(g1_xyzz_t), s));
     TK_TRY(d_wins.alloc((size_t)pl.W * sizeof(g1_xyzz_t), s));
 
+    tk_prof prof(s);
     hipLaunchKernelGGL(k_digits, tk_div_up(n, 256), 256, 0, s, scalars, d_dig.as<uint32_t>(), pl, scalars_mont ? 1 : 0);
+    prof.mark("msm.digits");
     size_t lds = (size_t)pl.B * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -430,9 +432,12 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
         attr_set = true;
     }
     hipLaunchKernelGGL(k_hist, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, d_counts.as<uint32_t>(), pl);
+    prof.mark("msm.hist");
     hipLaunchKernelGGL(k_scan, pl.W, 1024, 0, s, d_counts.as<uint32_t>(), d_bstart.as<uint32_t>(), pl);
+    prof.mark("msm.scan");
     hipLaunchKernelGGL(k_scatter, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, (const uint32_t *)d_counts.p,
                        d_sorted.as<uint32_t>(), pl);
+    prof.mark("msm.scatter");
     static const bool inline_mul = getenv("TKMK_MSM_INLINE") && atoi(getenv("TKMK_MSM_INLINE")) != 0;
     if (inline_mul)
         hipLaunchKernelGGL(k_accumulate<ec<Fq>>, tk_div_up((size_t)pl.W * pl.B, 256), 256, 0, s, bases_mont,
@@ -440,9 +445,12 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
     else
         hipLaunchKernelGGL(k_accumulate<G1K>, tk_div_up((size_t)pl.W * pl.B, 256), 256, 0, s, bases_mont,
                            (const uint32_t *)d_sorted.p, (const uint32_t *)d_bstart.p, d_buckets.as<g1_xyzz_t>(), pl);
+    prof.mark("msm.accumulate");
     hipLaunchKernelGGL(k_reduce_segments, tk_div_up((size_t)pl.W * segs, 128), 128, 0, s, (const g1_xyzz_t *)d_buckets.p,
                        d_segs.as<g1_xyzz_t>(), pl, segs);
+    prof.mark("msm.reduce_segments");
     hipLaunchKernelGGL(k_reduce_windows, pl.W, 256, 0, s, (const g1_xyzz_t *)d_segs.p, d_wins.as<g1_xyzz_t>(), segs);
+    prof.mark("msm.reduce_windows");
     TK_HIP(hipGetLastError());
     if (getenv("TKMK_MSM_DEBUG"))
         fprintf(stderr, "[msm debug] ptrs dig=%p sorted=%p counts=%p bstart=%p buckets=%p (+%zu) segs=%p (+%zu) wins=%p\n", d_dig.p,
@@ -453,6 +461,7 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
     std::vector<g1_xyzz_t> wins(pl.W);
     TK_HIP(hipMemcpyAsync(wins.data(), d_wins.p, pl.W * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, s));
     TK_HIP(hipStreamSynchronize(s));
+    prof.finish();
     // Horner over windows on the host: acc = 2^c * acc + W_w
     g1_xyzz_t acc = G1::inf();
     for (int w = (int)pl.W - 1; w >= 0; w--) {
@@ -501,8 +510,11 @@ TK_API tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *ba
             tk_scratch d_bm;
             if (!cfg->are_points_montgomery_form) {
                 TK_TRY(d_bm.alloc(n_bases * 96, s));
+                tk_prof prof(s);
                 hipLaunchKernelGGL(k_convert_bases, tk_div_up(n_bases, 256), 256, 0, s, (const g1_affine_t *)P.dev,
                                    d_bm.as<g1_affine_t>(), (uint64_t)n_bases);
+                prof.mark("msm.convert_bases");
+                prof.finish();
                 TK_HIP(hipGetLastError());
                 bm = d_bm.as<g1_affine_t>();
             }

@@ -13,6 +13,8 @@
 //
 // Arithmetic intensity is ~20 integer mul-adds per byte: the kernel is bound by v_mad_u64_u32 issue,
 // not by HBM; no MFMA (integer modular arithmetic, not a dense contraction).
+#include <stdio.h>
+
 #include <mutex>
 
 #include "common.h"
@@ -308,6 +310,7 @@ static tkmk_error run_passes(pass_launch_t *L, int n, const fr_t *in, fr_t *out,
         }
     }
     const fr_t *src = in;
+    tk_prof prof(s);
     for (int k = 0; k < n; k++) {
         fr_t *dst = ((n - 1 - k) % 2 == 0) ? out : A;
         if (k == 0 && B) dst = B;
@@ -315,8 +318,12 @@ static tkmk_error run_passes(pass_launch_t *L, int n, const fr_t *in, fr_t *out,
         hipLaunchKernelGGL(k_ntt_pass, (unsigned)L[k].p.tiles, NTT_THREADS, 0, s, L[k].p, src, dst, tw, L[k].pre, L[k].post,
                            L[k].post_const, L[k].post_mode);
         TK_HIP(hipGetLastError());
+        char name[32];
+        snprintf(name, sizeof name, "ntt.pass%d", k);
+        prof.mark(name);
         src = dst;
     }
+    prof.finish();
     return TKMK_SUCCESS;
 }
 

@@ -5,6 +5,7 @@
 
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -313,3 +314,51 @@ TK_API const char *tkmk_error_string(tkmk_error e) {
     }
 }
 TK_API int tkmk_is_hip_build(void) { return 1; }
+
+// ---- event profiler ----
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::map<std::string, std::pair<double, int>> g_prof;  // name -> (sum ms, count)
+
+tk_prof::tk_prof(hipStream_t stream) : s(stream), on(g_prof_on) {
+    if (on) mark("");
+}
+tk_prof::~tk_prof() {
+    for (auto &e : ev) (void)hipEventDestroy(e.second);
+}
+void tk_prof::mark(const char *name) {
+    if (!on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    ev.emplace_back(name, e);
+}
+void tk_prof::finish() {
+    if (!on || ev.size() < 2) return;
+    (void)hipEventSynchronize(ev.back().second);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (size_t i = 1; i < ev.size(); i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[i - 1].second, ev[i].second) != hipSuccess) continue;
+        auto &slot = g_prof[ev[i].first];
+        slot.first += ms;
+        slot.second += 1;
+    }
+}
+TK_API tkmk_error tkmk_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.clear();
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_profile_get(const char *name, double *sum_ms, int *count) {
+    if (!name || !sum_ms || !count) return TKMK_ERR_INVALID_POINTER;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto it = g_prof.find(name);
+    *sum_ms = it == g_prof.end() ? 0.0 : it->second.first;
+    *count = it == g_prof.end() ? 0 : it->second.second;
+    return TKMK_SUCCESS;
+}

@@ -87,7 +87,8 @@ SYMBOLS = [
     "bls12_381_ntt", "tkmk_bintt", "tkmk_vecops_default_config", "bls12_381_vector_add", "bls12_381_vector_sub",
     "bls12_381_vector_mul", "bls12_381_vector_div", "bls12_381_vector_inv", "bls12_381_scalar_add_vec",
     "bls12_381_scalar_sub_vec", "bls12_381_scalar_mul_vec", "bls12_381_vector_sum", "bls12_381_vector_product",
-    "bls12_381_matrix_transpose", "tkmk_fr_random_device", "tkmk_g1_batch_scalar_mul_device",
+    "bls12_381_matrix_transpose", "tkmk_fr_random_device", "tkmk_g1_batch_scalar_mul_device", "tkmk_profile_enable",
+    "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench",
 ]
 
 
@@ -364,3 +365,18 @@ def diag_bench(kind, iters, blocks, reps=3):
     _check(lib().tkmk_diag_bench(int(kind), ctypes.c_uint32(iters), ctypes.c_uint32(blocks), int(reps), ctypes.byref(ms)),
            "tkmk_diag_bench")
     return ms.value
+
+
+def profile_enable(on=True):
+    _check(lib().tkmk_profile_enable(1 if on else 0), "tkmk_profile_enable")
+
+
+def profile_reset():
+    _check(lib().tkmk_profile_reset(), "tkmk_profile_reset")
+
+
+def profile_get(name):
+    """(sum of ms, launches) of one kernel section since the last reset"""
+    ms, cnt = ctypes.c_double(), ctypes.c_int()
+    _check(lib().tkmk_profile_get(name.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "tkmk_profile_get")
+    return ms.value, cnt.value
