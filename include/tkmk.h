@@ -216,6 +216,8 @@ tkmk_error tkmk_profile_reset(void);
 tkmk_error tkmk_profile_get(const char *name, double *sum_ms, int *count);
 /* arithmetic micro-benchmarks (kind 0 Fr mul, 1 Fq mul, 2 v_mad_u64_u32, 3 G1 mixed add, 4 Fr add+sub, 5 Fq sqr) */
 tkmk_error tkmk_diag_bench(int kind, uint32_t iters, uint32_t blocks, int reps, float *ms_out);
+/* out[i] = a[i]*b[i] through the device Montgomery product; field 0 = Fr (32 B), 1 = Fq (48 B); device pointers */
+tkmk_error tkmk_diag_field_mul(int field, const void *a_dev, const void *b_dev, void *out_dev, uint64_t n);
 
 #ifdef __cplusplus
 }

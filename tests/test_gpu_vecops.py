@@ -69,3 +69,17 @@ def test_large_mul_linearity(gpu, oracle):
     assert (lhs.to_host() == rhs.to_host()).all()
     # and the device generator equals the oracle stream
     assert (a.to_host(32 * 1000) == oracle.fr_random(21, 1000)).all()
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_device_montgomery_product_edges(gpu, oracle, field):
+    """the hand-scheduled v_mad_u64_u32 product (csrc/ff.h mul_ps) on carry-heavy operands"""
+    import random
+    rnd = random.Random(99)
+    width, mod, omul = (32, oracle.R_MOD, oracle.fr_mul) if field == 0 else (48, oracle.P_MOD, oracle.fq_mul)
+    edge = [0, 1, 2, mod - 1, mod - 2, (mod - 1) // 2, (1 << (mod.bit_length() - 1)), (1 << 32) - 1, (1 << 64) - 1,
+            ((1 << (mod.bit_length() - 1)) - 1), mod >> 1, 0xFFFFFFFF00000000FFFFFFFF % mod]
+    a = [x for x in edge for _ in edge] + [rnd.randrange(mod) for _ in range(5000)]
+    b = [y for _ in edge for y in edge] + [rnd.randrange(mod) for _ in range(5000)]
+    A, B = oracle.to_bytes(a, width), oracle.to_bytes(b, width)
+    assert (gpu.diag_field_mul(field, A, B) == omul(A, B)).all()

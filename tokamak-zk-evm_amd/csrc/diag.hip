@@ -63,6 +63,55 @@ __global__ __launch_bounds__(256) void k_diag(uint32_t iters, uint32_t *sink) {
     }
 }
 
+// Raw issue-rate probes: 8 independent chains of one instruction each (inline asm so nothing is folded).
+#define PROBE_KERNEL(NAME, TYPE, ASM_LINE)                                                            \
+    __global__ __launch_bounds__(256) void NAME(uint32_t iters, uint32_t *sink) {                     \
+        uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;                                           \
+        TYPE acc[8];                                                                                  \
+        uint32_t x = t | 1, y = t * 2654435761u + 1;                                                  \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) acc[k] = k + t;                                 \
+        for (uint32_t i = 0; i < iters; i++) {                                                        \
+            _Pragma("unroll") for (int k = 0; k < 8; k++)                                             \
+                asm volatile(ASM_LINE : "+v"(acc[k]) : "v"(x), "v"(y) : "vcc");                       \
+        }                                                                                             \
+        TYPE s = 0;                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) s ^= acc[k];                                    \
+        if (s == 0x12345) sink[t] = (uint32_t)s;                                                      \
+    }
+PROBE_KERNEL(k_probe_add_co, uint32_t, "v_add_co_u32 %0, vcc, %1, %0")
+PROBE_KERNEL(k_probe_addc, uint32_t, "v_addc_co_u32 %0, vcc, %1, %0, vcc")
+PROBE_KERNEL(k_probe_add, uint32_t, "v_add_u32 %0, %1, %0")
+PROBE_KERNEL(k_probe_add3, uint32_t, "v_add3_u32 %0, %1, %2, %0")
+PROBE_KERNEL(k_probe_mov, uint32_t, "v_mov_b32 %0, %1")
+PROBE_KERNEL(k_probe_cndmask, uint32_t, "v_cndmask_b32 %0, %1, %0, vcc")
+PROBE_KERNEL(k_probe_mul_lo, uint32_t, "v_mul_lo_u32 %0, %1, %0")
+PROBE_KERNEL(k_probe_mul_hi, uint32_t, "v_mul_hi_u32 %0, %1, %0")
+PROBE_KERNEL(k_probe_mad24, uint32_t, "v_mad_u32_u24 %0, %1, %2, %0")
+PROBE_KERNEL(k_probe_lshl_add_u64, uint64_t, "v_lshl_add_u64 %0, %0, 0, %0")
+PROBE_KERNEL(k_probe_mad_u64, uint64_t, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
+PROBE_KERNEL(k_probe_fma64, uint64_t, "v_fma_f64 %0, %0, %0, %0")
+PROBE_KERNEL(k_probe_mad_i32_i24, uint32_t, "v_mad_i32_i24 %0, %1, %2, %0")
+PROBE_KERNEL(k_probe_alignbit, uint32_t, "v_alignbit_b32 %0, %1, %0, 3")
+PROBE_KERNEL(k_probe_mad_u32_u16, uint32_t, "v_mad_u32_u16 %0, %1, %2, %0")
+// the product step of the Montgomery multiplier: mad into a 64-bit pair + addc into a third word
+__global__ __launch_bounds__(256) void k_probe_mad_pair(uint32_t iters, uint32_t *sink) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t acc[8];
+    uint32_t c2[8];
+    uint32_t x = t | 1, y = t * 2654435761u + 1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = k + t, c2[k] = k;
+    for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc[k]), "+v"(c2[k]) : "v"(x), "v"(y) : "vcc");
+    }
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s ^= acc[k] + c2[k];
+    if (s == 0x12345) sink[t] = (uint32_t)s;
+}
+
 // Runs `reps` launches of (blocks x 256) threads, `iters` operations per thread; returns mean ms per launch.
 TK_API tkmk_error tkmk_diag_bench(int kind, uint32_t iters, uint32_t blocks, int reps, float *ms_out) {
     if (!ms_out || reps < 1) return TKMK_ERR_INVALID_ARGUMENT;
@@ -79,7 +128,24 @@ TK_API tkmk_error tkmk_diag_bench(int kind, uint32_t iters, uint32_t blocks, int
             case 2: hipLaunchKernelGGL(k_diag<2>, blocks, 256, 0, 0, iters, sink); break;
             case 3: hipLaunchKernelGGL(k_diag<3>, blocks, 256, 0, 0, iters, sink); break;
             case 4: hipLaunchKernelGGL(k_diag<4>, blocks, 256, 0, 0, iters, sink); break;
-            default: hipLaunchKernelGGL(k_diag<5>, blocks, 256, 0, 0, iters, sink); break;
+            case 5: hipLaunchKernelGGL(k_diag<5>, blocks, 256, 0, 0, iters, sink); break;
+            case 100: hipLaunchKernelGGL(k_probe_add_co, blocks, 256, 0, 0, iters, sink); break;
+            case 101: hipLaunchKernelGGL(k_probe_addc, blocks, 256, 0, 0, iters, sink); break;
+            case 102: hipLaunchKernelGGL(k_probe_add, blocks, 256, 0, 0, iters, sink); break;
+            case 103: hipLaunchKernelGGL(k_probe_add3, blocks, 256, 0, 0, iters, sink); break;
+            case 104: hipLaunchKernelGGL(k_probe_mov, blocks, 256, 0, 0, iters, sink); break;
+            case 105: hipLaunchKernelGGL(k_probe_cndmask, blocks, 256, 0, 0, iters, sink); break;
+            case 106: hipLaunchKernelGGL(k_probe_mul_lo, blocks, 256, 0, 0, iters, sink); break;
+            case 107: hipLaunchKernelGGL(k_probe_mul_hi, blocks, 256, 0, 0, iters, sink); break;
+            case 108: hipLaunchKernelGGL(k_probe_mad24, blocks, 256, 0, 0, iters, sink); break;
+            case 109: hipLaunchKernelGGL(k_probe_lshl_add_u64, blocks, 256, 0, 0, iters, sink); break;
+            case 110: hipLaunchKernelGGL(k_probe_mad_u64, blocks, 256, 0, 0, iters, sink); break;
+            case 111: hipLaunchKernelGGL(k_probe_mad_pair, blocks, 256, 0, 0, iters, sink); break;
+            case 112: hipLaunchKernelGGL(k_probe_fma64, blocks, 256, 0, 0, iters, sink); break;
+            case 113: hipLaunchKernelGGL(k_probe_mad_i32_i24, blocks, 256, 0, 0, iters, sink); break;
+            case 114: hipLaunchKernelGGL(k_probe_alignbit, blocks, 256, 0, 0, iters, sink); break;
+            case 115: hipLaunchKernelGGL(k_probe_mad_u32_u16, blocks, 256, 0, 0, iters, sink); break;
+            default: break;
         }
     };
     launch();
@@ -94,5 +160,26 @@ TK_API tkmk_error tkmk_diag_bench(int kind, uint32_t iters, uint32_t blocks, int
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(sink);
+    return TKMK_SUCCESS;
+}
+
+// out[i] = a[i] * b[i] (plain in / plain out) through the device Montgomery product — lets the gpu test tier
+// compare the hand-scheduled product against the oracle on edge values.  field 0 = Fr, 1 = Fq.
+template <class F>
+__global__ __launch_bounds__(256) void k_diag_mul(const typename F::E *a, const typename F::E *b, typename F::E *out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    tk_store(out + i, F::mul(F::to_mont(F::canon(tk_load(a + i))), F::canon(tk_load(b + i))));
+}
+TK_API tkmk_error tkmk_diag_field_mul(int field, const void *a_dev, const void *b_dev, void *out_dev, uint64_t n) {
+    TK_TRY(tk_require_device());
+    if (n == 0) return TKMK_SUCCESS;
+    if (!a_dev || !b_dev || !out_dev) return TKMK_ERR_INVALID_POINTER;
+    if (field == 0)
+        hipLaunchKernelGGL(k_diag_mul<Fr>, tk_div_up(n, 256), 256, 0, 0, (const fr_t *)a_dev, (const fr_t *)b_dev, (fr_t *)out_dev, n);
+    else
+        hipLaunchKernelGGL(k_diag_mul<Fq>, tk_div_up(n, 256), 256, 0, 0, (const fq_t *)a_dev, (const fq_t *)b_dev, (fq_t *)out_dev, n);
+    TK_HIP(hipGetLastError());
+    TK_HIP(hipDeviceSynchronize());
     return TKMK_SUCCESS;
 }

@@ -88,7 +88,7 @@ SYMBOLS = [
     "bls12_381_vector_mul", "bls12_381_vector_div", "bls12_381_vector_inv", "bls12_381_scalar_add_vec",
     "bls12_381_scalar_sub_vec", "bls12_381_scalar_mul_vec", "bls12_381_vector_sum", "bls12_381_vector_product",
     "bls12_381_matrix_transpose", "tkmk_fr_random_device", "tkmk_g1_batch_scalar_mul_device", "tkmk_profile_enable",
-    "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench",
+    "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench", "tkmk_diag_field_mul",
 ]
 
 
@@ -380,3 +380,12 @@ def profile_get(name):
     ms, cnt = ctypes.c_double(), ctypes.c_int()
     _check(lib().tkmk_profile_get(name.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "tkmk_profile_get")
     return ms.value, cnt.value
+
+
+def diag_field_mul(field, a, b):
+    """element-wise a*b through the device Montgomery product (field 0 = Fr, 1 = Fq); host arrays in/out"""
+    width = 32 if field == 0 else 48
+    da, db = DeviceBuffer.from_host(a), DeviceBuffer.from_host(b)
+    do = DeviceBuffer(a.size)
+    _check(lib().tkmk_diag_field_mul(int(field), _p(da), _p(db), _p(do), ctypes.c_uint64(a.size // width)), "tkmk_diag_field_mul")
+    return do.to_host()
