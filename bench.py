@@ -50,6 +50,7 @@ def main():
 
     import torch
     import tkmk
+    from tkmk import sharding
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -67,8 +68,6 @@ def main():
     g = np.frombuffer(bytes(_generator()), np.uint8).copy()
     bases = tkmk.g1_batch_scalar_mul_device(h, g, n)
     h.free()
-    ones = np.zeros(32 * world, np.uint8)
-    ones[0::32] = 1
 
     def barrier():
         if dist is not None:
@@ -77,15 +76,7 @@ def main():
         tkmk.synchronize()
 
     def step():
-        part = tkmk.msm(scalars, bases)                      # 144-byte canonical projective, on the host
-        if dist is None:
-            return part
-        mine = torch.from_numpy(part).cuda()
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)                      # RCCL over xGMI: world x 144 B
-        pts = torch.stack(gathered).cpu().numpy()
-        aff = np.concatenate([tkmk.projective_to_affine_bytes(p) for p in pts])
-        return tkmk.msm(ones, aff)                           # sum of the partial results, on the GPU
+        return sharding.msm_sharded(tkmk, dist, scalars, bases, device="cuda")   # 144-byte canonical projective
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,75 @@
+"""not-gpu tier: the N > 1 path (point-sharded MSM + one all_gather of 144-byte partials) with world_size 2 over
+gloo on the CPU.  The per-rank MSM and the final combine are played by the ORACLE here (test-only stand-ins: the
+product's msm needs a GPU); what is under test is the product's sharding / gather plumbing
+(tokamak-zk-evm_amd/tkmk/sharding.py) and that shard sums recombine to the full MSM."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tokamak-zk-evm_amd"))
+    import torch.distributed as dist
+    import oracle
+    from tkmk import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = oracle.fr_random(5, n)
+        p = oracle.g1_random_bases(6, n)
+        lo, hi = sharding.shard_range(n, rank, world)
+        part_aff = oracle.g1_msm(s[32 * lo:32 * hi].copy(), p[96 * lo:96 * hi].copy(), threads=1)
+        part = np.zeros(144, np.uint8)           # canonical projective as the C ABI returns it
+        if part_aff.any():
+            part[:96] = part_aff
+            part[96] = 1
+        else:
+            part[48] = 1
+        gathered = sharding.gather_partials(dist, part, device="cpu")
+        assert gathered.shape == (world, 144)
+        assert (gathered[rank] == part).all()
+        total = np.zeros(96, np.uint8)
+        for g in gathered:
+            aff = g[:96].copy() if g[96:].any() else np.zeros(96, np.uint8)
+            total = oracle.g1_add(total, aff)
+        q.put((rank, bool((total == oracle.g1_msm(s, p, threads=1)).all())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    sys.path.insert(0, os.path.join(ROOT, "tokamak-zk-evm_amd"))
+    from tkmk import sharding
+    for n in (0, 1, 7, 8, 1000, (1 << 28) + 3):
+        for world in (1, 2, 3, 8):
+            rs = [sharding.shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_point_sharded_msm_world2_gloo():
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, n = 2, 301      # odd size: ragged shards
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res == {0: True, 1: True}
