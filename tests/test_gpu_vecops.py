@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 def _edge_vec(oracle, seed, n):
     v = oracle.to_ints(oracle.fr_random(seed, n), 32)
-    v[:4] = [0, 1, oracle.R_MOD - 1, 2]
+    edge = [0, 1, oracle.R_MOD - 1, 2][:n]
+    v[:len(edge)] = edge
     return oracle.to_bytes(v, 32)
 
 

@@ -93,6 +93,54 @@ PROBE_KERNEL(k_probe_fma64, uint64_t, "v_fma_f64 %0, %0, %0, %0")
 PROBE_KERNEL(k_probe_mad_i32_i24, uint32_t, "v_mad_i32_i24 %0, %1, %2, %0")
 PROBE_KERNEL(k_probe_alignbit, uint32_t, "v_alignbit_b32 %0, %1, %0, 3")
 PROBE_KERNEL(k_probe_mad_u32_u16, uint32_t, "v_mad_u32_u16 %0, %1, %2, %0")
+// cndmask variants: VOP2 with VCC written once per iteration by a compare; VOP3 with an SGPR-pair mask
+__global__ __launch_bounds__(256) void k_probe_cndmask_real(uint32_t iters, uint32_t *sink) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc[8];
+    uint32_t x = t | 1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = k + t;
+    for (uint32_t i = 0; i < iters; i++) {
+        asm volatile("v_cmp_lt_u32 vcc, %8, %0\n\t"
+                     "v_cndmask_b32 %0, %8, %0, vcc\n\tv_cndmask_b32 %1, %8, %1, vcc\n\tv_cndmask_b32 %2, %8, %2, vcc\n\t"
+                     "v_cndmask_b32 %3, %8, %3, vcc\n\tv_cndmask_b32 %4, %8, %4, vcc\n\tv_cndmask_b32 %5, %8, %5, vcc\n\t"
+                     "v_cndmask_b32 %6, %8, %6, vcc\n\tv_cndmask_b32 %7, %8, %7, vcc"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(x) : "vcc");
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s ^= acc[k];
+    if (s == 0x12345) sink[t] = s;
+}
+__global__ __launch_bounds__(256) void k_probe_and_addc(uint32_t iters, uint32_t *sink) {
+    // the mask-and-add alternative: 8 x (v_and with mask, v_addc)
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc[8];
+    uint32_t x = t | 1, m = 0u - (t & 1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = k + t;
+    for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t tmp;
+            asm volatile("v_and_b32 %1, %2, %3\n\tv_addc_co_u32 %0, vcc, %1, %0, vcc" : "+v"(acc[k]), "=&v"(tmp) : "v"(x), "v"(m) : "vcc");
+        }
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s ^= acc[k];
+    if (s == 0x12345) sink[t] = s;
+}
+PROBE_KERNEL(k_probe_sub, uint32_t, "v_sub_u32 %0, %1, %0")
+PROBE_KERNEL(k_probe_and, uint32_t, "v_and_b32 %0, %1, %0")
+PROBE_KERNEL(k_probe_lshr, uint32_t, "v_lshrrev_b32 %0, 29, %0")
+PROBE_KERNEL(k_probe_lshr64, uint64_t, "v_lshrrev_b64 %0, 29, %0")
+PROBE_KERNEL(k_probe_and_or, uint32_t, "v_and_or_b32 %0, %1, %2, %0")
+PROBE_KERNEL(k_probe_bfe, uint32_t, "v_bfe_u32 %0, %0, 3, 29")
+PROBE_KERNEL(k_probe_lshl_add, uint32_t, "v_lshl_add_u32 %0, %1, 3, %0")
+PROBE_KERNEL(k_probe_mul_u32_u24, uint32_t, "v_mul_u32_u24 %0, %1, %0")
+
 // the product step of the Montgomery multiplier: mad into a 64-bit pair + addc into a third word
 __global__ __launch_bounds__(256) void k_probe_mad_pair(uint32_t iters, uint32_t *sink) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -145,6 +193,16 @@ TK_API tkmk_error tkmk_diag_bench(int kind, uint32_t iters, uint32_t blocks, int
             case 113: hipLaunchKernelGGL(k_probe_mad_i32_i24, blocks, 256, 0, 0, iters, sink); break;
             case 114: hipLaunchKernelGGL(k_probe_alignbit, blocks, 256, 0, 0, iters, sink); break;
             case 115: hipLaunchKernelGGL(k_probe_mad_u32_u16, blocks, 256, 0, 0, iters, sink); break;
+            case 116: hipLaunchKernelGGL(k_probe_cndmask_real, blocks, 256, 0, 0, iters, sink); break;
+            case 117: hipLaunchKernelGGL(k_probe_and_addc, blocks, 256, 0, 0, iters, sink); break;
+            case 118: hipLaunchKernelGGL(k_probe_sub, blocks, 256, 0, 0, iters, sink); break;
+            case 119: hipLaunchKernelGGL(k_probe_and, blocks, 256, 0, 0, iters, sink); break;
+            case 120: hipLaunchKernelGGL(k_probe_lshr, blocks, 256, 0, 0, iters, sink); break;
+            case 121: hipLaunchKernelGGL(k_probe_lshr64, blocks, 256, 0, 0, iters, sink); break;
+            case 122: hipLaunchKernelGGL(k_probe_and_or, blocks, 256, 0, 0, iters, sink); break;
+            case 123: hipLaunchKernelGGL(k_probe_bfe, blocks, 256, 0, 0, iters, sink); break;
+            case 124: hipLaunchKernelGGL(k_probe_lshl_add, blocks, 256, 0, 0, iters, sink); break;
+            case 125: hipLaunchKernelGGL(k_probe_mul_u32_u24, blocks, 256, 0, 0, iters, sink); break;
             default: break;
         }
     };

@@ -87,36 +87,67 @@ struct ff {
         }
         return br;
     }
-    // a in [0, 2p) -> [0, p)
+    // a in [0, 2p) -> [0, p).  Branch-free WITHOUT v_cndmask: on gfx950 a VCC-masked v_cndmask_b32 issues at
+    // ~16 cycles per wave (profiles/r01_valu_issue_probes.json) against ~3 + ~4.7 for v_and + v_addc_co, so the
+    // select is done arithmetically: t = a - p; r = t + (p & -borrow).  On the device add / sub / reduce are
+    // single inline-asm carry chains with the modulus as VOP2 literals (generated: field_params.h); hipcc
+    // lowers the portable u64 form to v_lshl_add_u64 plus a zero-extending v_mov per limb.
     static FF_HD E reduce_once(const E &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        E r = a;
+        P::reduce_once_asm(r.l);
+        return r;
+#else
         E t;
         uint32_t br = sub_raw(t, a, modulus());
+        uint32_t mask = 0u - br;
         E r;
-#pragma unroll
-        for (int i = 0; i < N; i++) r.l[i] = br ? a.l[i] : t.l[i];
+        uint32_t c = 0;
+        for (int i = 0; i < N; i++) {
+            uint64_t s = (uint64_t)t.l[i] + (P::MOD[i] & mask) + c;
+            r.l[i] = (uint32_t)s;
+            c = (uint32_t)(s >> 32);
+        }
         return r;
+#endif
     }
     static FF_HD E add(const E &a, const E &b) {  // inputs < p; sum < 2p < 2^(32N)
+#if defined(__HIP_DEVICE_COMPILE__)
+        E r = a;
+        P::add_mod_asm(r.l, b.l);
+        return r;
+#else
         E s;
         add_raw(s, a, b);
         return reduce_once(s);
+#endif
     }
     static FF_HD E sub(const E &a, const E &b) {
-        E d, dp;
-        uint32_t br = sub_raw(d, a, b);
-        add_raw(dp, d, modulus());
-        E r;
-#pragma unroll
-        for (int i = 0; i < N; i++) r.l[i] = br ? dp.l[i] : d.l[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        E r = a;
+        P::sub_mod_asm(r.l, b.l);
         return r;
+#else
+        E d;
+        uint32_t br = sub_raw(d, a, b);
+        uint32_t mask = 0u - br;
+        E r;
+        uint32_t c = 0;
+        for (int i = 0; i < N; i++) {
+            uint64_t s = (uint64_t)d.l[i] + (P::MOD[i] & mask) + c;
+            r.l[i] = (uint32_t)s;
+            c = (uint32_t)(s >> 32);
+        }
+        return r;
+#endif
     }
     static FF_HD E neg(const E &a) {
         E d;
         sub_raw(d, modulus(), a);
+        uint32_t mask = is_zero(a) ? 0u : 0xffffffffu;
         E r;
-        bool z = is_zero(a);
 #pragma unroll
-        for (int i = 0; i < N; i++) r.l[i] = z ? 0u : d.l[i];
+        for (int i = 0; i < N; i++) r.l[i] = d.l[i] & mask;
         return r;
     }
     static FF_HD E dbl(const E &a) { return add(a, a); }
