@@ -96,7 +96,8 @@ def main():
 
     acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
     sections = {}
-    for name in ("convert_bases", "digits", "hist", "scan", "scatter", "accumulate", "reduce_segments", "reduce_windows"):
+    for name in ("convert_bases", "digits", "hist", "scan", "scatter", "accumulate", "combine", "reduce_segments",
+                 "reduce_windows"):
         ms, cnt = tkmk.profile_get("msm." + name)
         if cnt:
             sections[name] = round(ms / cnt, 4)

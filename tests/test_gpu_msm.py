@@ -115,3 +115,37 @@ def test_msm_linearity_2_20(gpu, oracle):
     k = oracle.fr_random(64, 1)
     mka = _msm_affine(gpu, gpu.scalar_mul(k, a), p)
     assert (mka == oracle.g1_scalar_mul(k, ma)).all()
+
+
+def test_msm_skewed_witness_like_scalars(gpu, oracle):
+    """Real binding MSMs take raw witness values: mostly 0 / 1 / small -> one giant bucket in
+    the low window, empty high windows.  Exercises the chunk head / tail fragments and the big-bucket combine."""
+    import random
+    rnd = random.Random(5)
+    n = 30000
+    vals = []
+    for i in range(n):
+        u = rnd.random()
+        if u < 0.55:
+            vals.append(1)
+        elif u < 0.75:
+            vals.append(0)
+        elif u < 0.9:
+            vals.append(rnd.randrange(1 << 16))
+        elif u < 0.97:
+            vals.append(rnd.randrange(1 << 128))
+        else:
+            vals.append(rnd.randrange(oracle.R_MOD))
+    s = oracle.to_bytes(vals, 32)
+    h = gpu.fr_random_device(91, n)
+    p = gpu.g1_batch_scalar_mul_device(h, oracle.g1_generator(), n)
+    ph = p.to_host()
+    assert (_msm_affine(gpu, s, p) == oracle.g1_msm(s, ph)).all()
+    # every scalar equal: a single bucket per window holds all n entries (n / 64 fragments -> big path)
+    same = oracle.to_bytes([0xABCDEF] * n, 32)
+    assert (_msm_affine(gpu, same, p) == oracle.g1_msm(same, ph)).all()
+    # bucket boundaries exactly on chunk boundaries: 64 / 128 / 192 copies of three digits
+    vals = [3] * 64 + [5] * 128 + [9] * 192 + [7] * 1
+    s2 = oracle.to_bytes(vals, 32)
+    assert (_msm_affine(gpu, s2, gpu.DeviceBuffer.from_host(ph[:96 * len(vals)].copy()), c=4)
+            == oracle.g1_msm(s2, ph[:96 * len(vals)].copy())).all()

@@ -8,7 +8,8 @@
 //   k_hist            per (window, chunk) workgroup: LDS-privatised bucket histogram (<= 128 KiB of LDS)
 //   k_scan            per window: chunk-exclusive cursors + bucket start offsets
 //   k_scatter         per (window, chunk): LDS cursors, ds_add_rtn ranks -> bucket-sorted point indices
-//   k_accumulate      one lane per bucket: XYZZ accumulator in VGPRs += gathered affine bases (8M+2S each)
+//   k_accumulate_chunks  one lane per 64-entry chunk of the sorted list: XYZZ accumulator in VGPRs += gathered
+//                     affine bases (8M+2S each); k_combine / k_combine_big sum each bucket's chunk fragments
 //   k_reduce_segments / k_reduce_windows   sum_v v*B_v per window via 16-bucket running sums
 //   host              Horner over the W window sums (W*c doublings) + one inversion -> canonical result
 // Sorting by bucket instead of atomically adding points: there are no 384-bit atomics, and the sorted
@@ -168,28 +169,125 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint32_t *__restrict__ d
     }
 }
 
-// one lane per (window, bucket): sum of the bucket's (signed) bases.  GK = ec<FqK> (out-of-line product)
-// or ec<Fq> (fully inlined): selected at run time by TKMK_MSM_INLINE for A/B measurements.
-template <class GK>
-__global__ __launch_bounds__(256) void k_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
-                                                   const uint32_t *__restrict__ bstart, g1_xyzz_t *__restrict__ buckets,
-                                                   msm_plan_t pl) {
-    using XA = typename GK::X;
-    using AA = typename GK::A;
+// ---- bucket accumulation, balanced by construction -------------------------------------------------
+// The window's bucket-sorted list is cut into chunks of MSM_CHUNK consecutive entries and every lane sums
+// exactly one chunk (an XYZZ accumulator in VGPRs += gathered affine base, 8M + 2S per entry), whatever
+// the bucket sizes are: real prover inputs are heavily skewed (witness wires are mostly 0/1: SURVEY.md
+// Appendix B) and one-lane-per-bucket would serialise a 10^5-entry bucket on a single lane.
+// A chunk intersects buckets in at most: one HEAD fragment (a bucket that covers the chunk start but is not
+// wholly inside the chunk), any number of whole buckets (written straight to buckets[]), one TAIL fragment
+// (a bucket that starts inside and runs past the chunk end).  k_combine then sums each bucket's fragments
+// (tail of its first chunk, heads of the following chunks); buckets with more than MSM_BIG fragments are
+// queued for k_combine_big (one workgroup per bucket, LDS tree).
+#define MSM_CHUNK 64
+#define MSM_BIG 48
+
+__device__ __forceinline__ uint32_t bucket_of(const uint32_t *__restrict__ bs, uint32_t B, uint32_t pos) {
+    // largest b in [0, B) with bs[b] <= pos  (bs is non-decreasing, bs[0] = 0)
+    uint32_t lo = 0, hi = B;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (bs[mid] <= pos) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_accumulate_chunks(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
+                                                          const uint32_t *__restrict__ bstart, g1_xyzz_t *__restrict__ buckets,
+                                                          g1_xyzz_t *__restrict__ frag_head, g1_xyzz_t *__restrict__ frag_tail,
+                                                          msm_plan_t pl, uint32_t chunks_per_window) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= pl.W * chunks_per_window) return;
+    uint32_t w = gid / chunks_per_window, t = gid - w * chunks_per_window;
+    const uint32_t *bs = bstart + (uint64_t)w * (pl.B + 1);
+    const uint32_t total = bs[pl.B];
+    uint32_t lo = t * MSM_CHUNK;
+    if (lo >= total) return;
+    uint32_t hi = lo + MSM_CHUNK < total ? lo + MSM_CHUNK : total;
+    const uint32_t *s = sorted + (uint64_t)w * pl.n;
+    uint32_t b = bucket_of(bs, pl.B, lo);
+    uint32_t bend = bs[b + 1];           // end of the current bucket (> lo by construction of bucket_of,
+    while (bend <= lo) bend = bs[++b + 1];  //  except across empty buckets sharing the same offset)
+    uint32_t seg_lo = lo;
+    g1_xyzz_t acc = G1::inf();
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t rec = s[k];
+        g1_affine_t p = tk_load(bases + (rec & 0x7fffffffu));
+        if (rec & 0x80000000u) p.y = Fq::neg(p.y);
+        acc = G1::add_mixed(acc, p);
+        if (k + 1 == bend || k + 1 == hi) {  // the segment [seg_lo, k+1) of bucket b ends here
+            uint32_t bbeg = bs[b];
+            bool whole = seg_lo == bbeg && k + 1 == bend;
+            g1_xyzz_t *dst;
+            if (whole) dst = buckets + (uint64_t)w * pl.B + b;
+            else if (seg_lo == lo) dst = frag_head + (uint64_t)w * chunks_per_window + t;
+            else dst = frag_tail + (uint64_t)w * chunks_per_window + t;
+            tk_store(dst, acc);
+            acc = G1::inf();
+            seg_lo = k + 1;
+            if (k + 1 < hi) {
+                do { b++; bend = bs[b + 1]; } while (bend <= k + 1);
+            }
+        }
+    }
+}
+
+// one lane per (window, bucket): gather the bucket's fragments.  big[0] = count, big[1 + i] = w * B + b
+__global__ __launch_bounds__(256) void k_combine(const uint32_t *__restrict__ bstart, g1_xyzz_t *__restrict__ buckets,
+                                                const g1_xyzz_t *__restrict__ frag_head, const g1_xyzz_t *__restrict__ frag_tail,
+                                                msm_plan_t pl, uint32_t chunks_per_window, uint32_t *__restrict__ big,
+                                                uint32_t big_cap) {
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= pl.W * pl.B) return;
     uint32_t w = gid / pl.B, b = gid - w * pl.B;
     const uint32_t *bs = bstart + (uint64_t)w * (pl.B + 1);
-    uint32_t lo = bs[b], hi = bs[b + 1];
-    const uint32_t *s = sorted + (uint64_t)w * pl.n;
-    XA acc = GK::inf();
-    for (uint32_t k = lo; k < hi; k++) {
-        uint32_t rec = s[k];
-        AA p = tk_load(reinterpret_cast<const AA *>(bases) + (rec & 0x7fffffffu));
-        if (rec & 0x80000000u) p.y = Fq::neg(p.y);
-        acc = GK::add_mixed(acc, p);
+    uint32_t sb = bs[b], eb = bs[b + 1];
+    if (eb == sb) return;  // buckets[] was zeroed = infinity
+    uint32_t t0 = sb / MSM_CHUNK, t1 = (eb - 1) / MSM_CHUNK;
+    if (t0 == t1) return;  // wholly inside one chunk: already written
+    if (t1 - t0 > MSM_BIG) {
+        uint32_t slot = atomicAdd(&big[0], 1u);
+        if (slot < big_cap) big[1 + slot] = gid;
+        return;
     }
-    tk_store(reinterpret_cast<XA *>(buckets) + gid, acc);
+    const g1_xyzz_t *fh = frag_head + (uint64_t)w * chunks_per_window, *ft = frag_tail + (uint64_t)w * chunks_per_window;
+    g1_xyzz_t acc = tk_load(sb == t0 * MSM_CHUNK ? fh + t0 : ft + t0);
+    for (uint32_t t = t0 + 1; t <= t1; t++) acc = G1::add(acc, tk_load(fh + t));
+    tk_store(buckets + gid, acc);
+}
+
+// grid-stride over the queued big buckets, one workgroup each: 256 lanes sum strided fragments, LDS tree
+__global__ __launch_bounds__(256) void k_combine_big(const uint32_t *__restrict__ bstart, g1_xyzz_t *__restrict__ buckets,
+                                                    const g1_xyzz_t *__restrict__ frag_head, const g1_xyzz_t *__restrict__ frag_tail,
+                                                    msm_plan_t pl, uint32_t chunks_per_window, const uint32_t *__restrict__ big,
+                                                    uint32_t big_cap) {
+    __shared__ g1_xyzz_t sh[256];
+    uint32_t count = big[0] < big_cap ? big[0] : big_cap;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        uint32_t gid = big[1 + i];
+        uint32_t w = gid / pl.B, b = gid - w * pl.B;
+        const uint32_t *bs = bstart + (uint64_t)w * (pl.B + 1);
+        uint32_t sb = bs[b], eb = bs[b + 1];
+        uint32_t t0 = sb / MSM_CHUNK, t1 = (eb - 1) / MSM_CHUNK;
+        const g1_xyzz_t *fh = frag_head + (uint64_t)w * chunks_per_window, *ft = frag_tail + (uint64_t)w * chunks_per_window;
+        g1_xyzz_t acc = G1::inf();
+        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) {
+            const g1_xyzz_t *src = (t == t0 && sb != t0 * MSM_CHUNK) ? ft + t : fh + t;
+            acc = G1::add(acc, tk_load(src));
+        }
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (uint32_t st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) {
+                acc = G1::add(acc, sh[threadIdx.x + st]);
+                sh[threadIdx.x] = acc;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) tk_store(buckets + gid, acc);
+        __syncthreads();
+    }
 }
 
 #define MSM_SEG 16
@@ -438,15 +536,22 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
     hipLaunchKernelGGL(k_scatter, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, (const uint32_t *)d_counts.p,
                        d_sorted.as<uint32_t>(), pl);
     prof.mark("msm.scatter");
-    // default: fully inlined products (61.6 ms vs 77.0 ms per 2^24-point launch for the out-of-line flavour)
-    static const bool inline_mul = !(getenv("TKMK_MSM_INLINE") && atoi(getenv("TKMK_MSM_INLINE")) == 0);
-    if (inline_mul)
-        hipLaunchKernelGGL(k_accumulate<ec<Fq>>, tk_div_up((size_t)pl.W * pl.B, 256), 256, 0, s, bases_mont,
-                           (const uint32_t *)d_sorted.p, (const uint32_t *)d_bstart.p, d_buckets.as<g1_xyzz_t>(), pl);
-    else
-        hipLaunchKernelGGL(k_accumulate<G1K>, tk_div_up((size_t)pl.W * pl.B, 256), 256, 0, s, bases_mont,
-                           (const uint32_t *)d_sorted.p, (const uint32_t *)d_bstart.p, d_buckets.as<g1_xyzz_t>(), pl);
+    const uint32_t cpw = (n + MSM_CHUNK - 1) / MSM_CHUNK;  // chunks per window (upper bound: all digits non-zero)
+    const uint32_t big_cap = 1u << 16;
+    tk_scratch d_fh, d_ft, d_big;
+    TK_TRY(d_fh.alloc((size_t)pl.W * cpw * sizeof(g1_xyzz_t), s));
+    TK_TRY(d_ft.alloc((size_t)pl.W * cpw * sizeof(g1_xyzz_t), s));
+    TK_TRY(d_big.alloc((size_t)(big_cap + 1) * 4, s));
+    TK_HIP(hipMemsetAsync(d_buckets.p, 0, (size_t)pl.W * pl.B * sizeof(g1_xyzz_t), s));  // empty bucket = infinity
+    TK_HIP(hipMemsetAsync(d_big.p, 0, 4, s));
+    hipLaunchKernelGGL(k_accumulate_chunks, tk_div_up((size_t)pl.W * cpw, 256), 256, 0, s, bases_mont, (const uint32_t *)d_sorted.p,
+                       (const uint32_t *)d_bstart.p, d_buckets.as<g1_xyzz_t>(), d_fh.as<g1_xyzz_t>(), d_ft.as<g1_xyzz_t>(), pl, cpw);
     prof.mark("msm.accumulate");
+    hipLaunchKernelGGL(k_combine, tk_div_up((size_t)pl.W * pl.B, 256), 256, 0, s, (const uint32_t *)d_bstart.p, d_buckets.as<g1_xyzz_t>(),
+                       (const g1_xyzz_t *)d_fh.p, (const g1_xyzz_t *)d_ft.p, pl, cpw, d_big.as<uint32_t>(), big_cap);
+    hipLaunchKernelGGL(k_combine_big, 1024, 256, 0, s, (const uint32_t *)d_bstart.p, d_buckets.as<g1_xyzz_t>(),
+                       (const g1_xyzz_t *)d_fh.p, (const g1_xyzz_t *)d_ft.p, pl, cpw, (const uint32_t *)d_big.p, big_cap);
+    prof.mark("msm.combine");
     hipLaunchKernelGGL(k_reduce_segments, tk_div_up((size_t)pl.W * segs, 128), 128, 0, s, (const g1_xyzz_t *)d_buckets.p,
                        d_segs.as<g1_xyzz_t>(), pl, segs);
     prof.mark("msm.reduce_segments");
