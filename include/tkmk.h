@@ -74,6 +74,9 @@ tkmk_error tkmk_memcpy_d2h(void *dst, const void *src, size_t bytes);   /* copy_
 tkmk_error tkmk_memcpy_d2d(void *dst, const void *src, size_t bytes);   /* DeviceVec::copy */
 tkmk_error tkmk_memcpy_h2d_async(void *dst, const void *src, size_t bytes, tkmk_stream s);
 tkmk_error tkmk_memcpy_d2h_async(void *dst, const void *src, size_t bytes, tkmk_stream s);
+/* strided device copy: `rows` rows of width_bytes (sub-grid gather of the CRS / coefficient box in encode_poly,
+ * libs/src/iotools/mod.rs:2061-2088) */
+tkmk_error tkmk_memcpy_2d_d2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows);
 tkmk_error tkmk_memset(void *ptr, int value, size_t bytes);
 tkmk_error tkmk_stream_create(tkmk_stream *s);            /* IcicleStream::create */
 tkmk_error tkmk_stream_synchronize(tkmk_stream s);        /* IcicleStream::synchronize */
@@ -204,6 +207,39 @@ tkmk_error tkmk_fr_random_device(uint64_t seed, uint64_t first, uint64_t n, tkmk
 /* out[i] = [scalars[i]] base  (affine results); all pointers device except `base` (host) */
 tkmk_error tkmk_g1_batch_scalar_mul_device(const tkmk_fr *scalars_dev, const tkmk_g1_affine *base_host,
                                            uint64_t n, tkmk_g1_affine *out_dev, tkmk_stream s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bivariate coefficient-matrix helpers — device-resident replacements for the HOST loops of
+ * DensePolynomialExt (libs/src/bivariate_polynomial/mod.rs), which copy the whole matrix D->H first
+ * (SURVEY.md §8 rows a10-a12).  No ICICLE symbol corresponds to these; a maintainer calls them from
+ * the same Rust methods.  Element (ix, iy) at ix*y_size + iy.  All matrix pointers are DEVICE pointers;
+ * scalars (x, y, factors) are host pointers; kernels are enqueued on `stream` (results written to host
+ * outputs imply a stream synchronisation).
+ * --------------------------------------------------------------------------------------------- */
+/* find_degree (mod.rs:1480-1515): largest row / column index with a non-zero coefficient, -1 if none */
+tkmk_error tkmk_poly_find_degree(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, int64_t *x_degree,
+                                 int64_t *y_degree, tkmk_stream stream);
+/* dst (dx x dy) = zeros with src (sx x sy) placed at (off_x, off_y), clipped: resize (mod.rs:1784-1806) is
+ * off = (0,0); mul_monomial (mod.rs:1820-1844) is off = (x_exponent, y_exponent) */
+tkmk_error tkmk_poly_place(const tkmk_fr *src_dev, uint32_t sx, uint32_t sy, tkmk_fr *dst_dev, uint32_t dx, uint32_t dy,
+                           uint32_t off_x, uint32_t off_y, tkmk_stream stream);
+/* dst[i][j] = src[i][j] * factor_x^i * factor_y^j (_scale_coeffs, mod.rs:1567-1613; NULL factor = 1); in place ok */
+tkmk_error tkmk_poly_scale_coeffs(const tkmk_fr *src_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *factor_x,
+                                  const tkmk_fr *factor_y, tkmk_fr *dst_dev, tkmk_stream stream);
+/* eval_x / eval_y / eval (mod.rs:1719-1750): out_dev has y_size / x_size elements; out_host one */
+tkmk_error tkmk_poly_eval_x(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, tkmk_fr *out_dev,
+                            tkmk_stream stream);
+tkmk_error tkmk_poly_eval_y(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *y, tkmk_fr *out_dev,
+                            tkmk_stream stream);
+tkmk_error tkmk_poly_eval(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, const tkmk_fr *y,
+                          tkmk_fr *out_host, tkmk_stream stream);
+/* div_by_vanishing_opt (mod.rs:2284-2410): P = Q_X (X^c - 1) + Q_Y (Y^d - 1); c | x_size, d | y_size, powers of two;
+ * quo_x is x_size x y_size, quo_y is c x y_size */
+tkmk_error tkmk_poly_div_by_vanishing_opt(const tkmk_fr *p_dev, uint32_t x_size, uint32_t y_size, uint32_t c, uint32_t d,
+                                          tkmk_fr *quo_x_dev, tkmk_fr *quo_y_dev, tkmk_stream stream);
+/* div_by_ruffini (mod.rs:2412-2477): P = Q_X (X - x) + Q_Y (Y - y) + r; q_x is x_size x y_size, q_y has y_size elements */
+tkmk_error tkmk_poly_div_by_ruffini(const tkmk_fr *p_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, const tkmk_fr *y,
+                                    tkmk_fr *q_x_dev, tkmk_fr *q_y_dev, tkmk_fr *r_host, tkmk_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart; the reference's `timing` feature wraps host spans:

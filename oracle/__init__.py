@@ -32,6 +32,8 @@ def lib():
         _LIB.tko_get_root_of_unity.restype = ctypes.c_int
         _LIB.tko_g1_on_curve.restype = ctypes.c_int
         _LIB.tko_num_threads.restype = ctypes.c_int
+        _LIB.tko_poly_mul_monomial.restype = ctypes.c_int
+        _LIB.tko_poly_div_by_vanishing_opt.restype = ctypes.c_int
     return _LIB
 
 
@@ -202,6 +204,73 @@ def g1_proj_to_affine(p144):
     out = np.empty(96, np.uint8)
     lib().tko_g1_proj_to_affine(_p(p144), _p(out))
     return out
+
+
+def poly_find_degree(c, xs, ys):
+    xd, yd = ctypes.c_int64(), ctypes.c_int64()
+    lib().tko_poly_find_degree(_p(c), _sz(xs), _sz(ys), ctypes.byref(xd), ctypes.byref(yd))
+    return xd.value, yd.value
+
+
+def poly_resized_dims(tx, ty):
+    nx, ny = ctypes.c_size_t(), ctypes.c_size_t()
+    lib().tko_poly_resized_dims(_sz(tx), _sz(ty), ctypes.byref(nx), ctypes.byref(ny))
+    return nx.value, ny.value
+
+
+def poly_resize(c, xs, ys, tx, ty):
+    nx, ny = poly_resized_dims(tx, ty)
+    out = np.empty(32 * nx * ny, np.uint8)
+    lib().tko_poly_resize(_p(c), _sz(xs), _sz(ys), _sz(nx), _sz(ny), _p(out))
+    return out, nx, ny
+
+
+def poly_mul_monomial(c, xs, ys, x_degree, y_degree, ex, ey):
+    nx, ny = poly_resized_dims(x_degree + 1 + ex, y_degree + 1 + ey)
+    out = np.empty(32 * nx * ny, np.uint8)
+    if lib().tko_poly_mul_monomial(_p(c), _sz(xs), _sz(ys), _sz(ex), _sz(ey), _sz(nx), _sz(ny), _p(out)) != 0:
+        raise ValueError("mul_monomial: source does not fit (the reference would panic)")
+    return out, nx, ny
+
+
+def poly_scale_coeffs(c, xs, ys, fx=None, fy=None):
+    out = np.empty_like(c)
+    lib().tko_poly_scale_coeffs(_p(c), _sz(xs), _sz(ys), _p(fx), _p(fy), _p(out))
+    return out
+
+
+def poly_eval(c, xs, ys, x, y):
+    out = np.empty(32, np.uint8)
+    lib().tko_poly_eval(_p(c), _sz(xs), _sz(ys), _p(x), _p(y), _p(out))
+    return out
+
+
+def poly_eval_x(c, xs, ys, x):
+    out = np.empty(32 * ys, np.uint8)
+    lib().tko_poly_eval_x(_p(c), _sz(xs), _sz(ys), _p(x), _p(out))
+    return out
+
+
+def poly_eval_y(c, xs, ys, y):
+    out = np.empty(32 * xs, np.uint8)
+    lib().tko_poly_eval_y(_p(c), _sz(xs), _sz(ys), _p(y), _p(out))
+    return out
+
+
+def poly_div_by_vanishing_opt(p, xs, ys, c, d):
+    qx = np.empty(32 * xs * ys, np.uint8)
+    qy = np.empty(32 * c * ys, np.uint8)
+    if lib().tko_poly_div_by_vanishing_opt(_p(p), _sz(xs), _sz(ys), _sz(c), _sz(d), _p(qx), _p(qy)) != 0:
+        raise ValueError("div_by_vanishing_opt: bad shape")
+    return qx, qy
+
+
+def poly_div_by_ruffini(p, xs, ys, x, y):
+    qx = np.empty(32 * xs * ys, np.uint8)
+    qy = np.empty(32 * ys, np.uint8)
+    r = np.empty(32, np.uint8)
+    lib().tko_poly_div_by_ruffini(_p(p), _sz(xs), _sz(ys), _p(x), _p(y), _p(qx), _p(qy), _p(r))
+    return qx, qy, r
 
 
 def num_threads():

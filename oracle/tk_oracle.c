@@ -756,3 +756,196 @@ void tko_g1_proj_to_affine(const uint8_t *p144, uint8_t *out96) {
     fq_store(out96, &x);
     fq_store(out96 + 48, &y);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Bivariate coefficient-matrix routines: restatements of the HOST loops of DensePolynomialExt
+ * (packages/backend/libs/src/bivariate_polynomial/mod.rs).  Element (ix,iy) at ix*ys + iy.
+ * ------------------------------------------------------------------------------------------ */
+/* find_degree, mod.rs:1480-1515 */
+void tko_poly_find_degree(const uint8_t *c, size_t xs, size_t ys, int64_t *xd, int64_t *yd) {
+    static const uint8_t zero[32] = {0};
+    *xd = -1;
+    *yd = -1;
+    for (size_t i = 0; i < xs; i++)
+        for (size_t j = 0; j < ys; j++)
+            if (memcmp(c + 32 * (i * ys + j), zero, 32)) {
+                if ((int64_t)i > *xd) *xd = (int64_t)i;
+                if ((int64_t)j > *yd) *yd = (int64_t)j;
+            }
+}
+/* _find_size_as_twopower, mod.rs:72-86 */
+static size_t pow2_at_least(size_t t) {
+    size_t p = 1;
+    while (p < t) p <<= 1;
+    return p;
+}
+void tko_poly_resized_dims(size_t tx, size_t ty, size_t *nx, size_t *ny) {
+    *nx = pow2_at_least(tx);
+    *ny = pow2_at_least(ty);
+}
+/* resize, mod.rs:1784-1806: copy the common top-left block into a zeroed nx x ny matrix (nx, ny already rounded) */
+void tko_poly_resize(const uint8_t *c, size_t xs, size_t ys, size_t nx, size_t ny, uint8_t *out) {
+    memset(out, 0, 32 * nx * ny);
+    size_t rx = xs < nx ? xs : nx, ry = ys < ny ? ys : ny;
+    for (size_t i = 0; i < rx; i++) memcpy(out + 32 * ny * i, c + 32 * ys * i, 32 * ry);
+}
+/* mul_monomial, mod.rs:1820-1844: out is nx x ny (caller rounds (x_degree+1+ex, y_degree+1+ey) up to powers of two) */
+int tko_poly_mul_monomial(const uint8_t *c, size_t xs, size_t ys, size_t ex, size_t ey, size_t nx, size_t ny, uint8_t *out) {
+    if (xs + ex > nx || ys + ey > ny) return -1; /* the reference slice copy would panic */
+    memset(out, 0, 32 * nx * ny);
+    for (size_t i = 0; i < xs; i++) memcpy(out + 32 * (ny * (i + ex) + ey), c + 32 * ys * i, 32 * ys);
+    return 0;
+}
+/* _scale_coeffs (both axes), mod.rs:1567-1613: out[i][j] = c[i][j] * fx^i * fy^j */
+void tko_poly_scale_coeffs(const uint8_t *c, size_t xs, size_t ys, const uint8_t *fx, const uint8_t *fy, uint8_t *out) {
+    tko_init();
+    fr_t gx = fr_R1, gy = fr_R1;
+    if (fx) fr_load(&gx, fx);
+    if (fy) fr_load(&gy, fy);
+    fr_t px = fr_R1;
+    for (size_t i = 0; i < xs; i++) {
+        fr_t py = px;
+        for (size_t j = 0; j < ys; j++) {
+            fr_t v;
+            fr_load(&v, c + 32 * (i * ys + j));
+            fr_mul(&v, &v, &py);
+            fr_store(out + 32 * (i * ys + j), &v);
+            fr_mul(&py, &py, &gy);
+        }
+        fr_mul(&px, &px, &gx);
+    }
+}
+/* eval, mod.rs:1719-1750: P(x, y) by Horner over both axes */
+void tko_poly_eval(const uint8_t *c, size_t xs, size_t ys, const uint8_t *x, const uint8_t *y, uint8_t *out) {
+    tko_init();
+    fr_t vx, vy, acc;
+    fr_load(&vx, x);
+    fr_load(&vy, y);
+    memset(&acc, 0, sizeof acc);
+    for (size_t i = xs; i-- > 0;) {
+        fr_t row, t;
+        memset(&row, 0, sizeof row);
+        for (size_t j = ys; j-- > 0;) {
+            fr_load(&t, c + 32 * (i * ys + j));
+            fr_mul(&row, &row, &vy);
+            fr_add(&row, &row, &t);
+        }
+        fr_mul(&acc, &acc, &vx);
+        fr_add(&acc, &acc, &row);
+    }
+    fr_store(out, &acc);
+}
+/* eval_x (out: ys values) / eval_y (out: xs values), mod.rs:1719-1740 */
+void tko_poly_eval_x(const uint8_t *c, size_t xs, size_t ys, const uint8_t *x, uint8_t *out) {
+    tko_init();
+    fr_t vx;
+    fr_load(&vx, x);
+    for (size_t j = 0; j < ys; j++) {
+        fr_t acc, t;
+        memset(&acc, 0, sizeof acc);
+        for (size_t i = xs; i-- > 0;) {
+            fr_load(&t, c + 32 * (i * ys + j));
+            fr_mul(&acc, &acc, &vx);
+            fr_add(&acc, &acc, &t);
+        }
+        fr_store(out + 32 * j, &acc);
+    }
+}
+void tko_poly_eval_y(const uint8_t *c, size_t xs, size_t ys, const uint8_t *y, uint8_t *out) {
+    tko_init();
+    fr_t vy;
+    fr_load(&vy, y);
+    for (size_t i = 0; i < xs; i++) {
+        fr_t acc, t;
+        memset(&acc, 0, sizeof acc);
+        for (size_t j = ys; j-- > 0;) {
+            fr_load(&t, c + 32 * (i * ys + j));
+            fr_mul(&acc, &acc, &vy);
+            fr_add(&acc, &acc, &t);
+        }
+        fr_store(out + 32 * i, &acc);
+    }
+}
+/* div_by_vanishing_opt, mod.rs:2284-2410, statement for statement (after its optimize_size):
+ * p is xs x ys with c | xs, d | ys; quo_x is xs x ys, quo_y is c x ys */
+int tko_poly_div_by_vanishing_opt(const uint8_t *p, size_t xs, size_t ys, size_t c, size_t d, uint8_t *quo_x, uint8_t *quo_y) {
+    tko_init();
+    if (!c || !d || xs % c || ys % d) return -1;
+    size_t m = xs / c;
+    fr_t *P = (fr_t *)malloc(sizeof(fr_t) * xs * ys), *acc = (fr_t *)calloc(c * ys, sizeof(fr_t));
+    fr_t *qy = (fr_t *)calloc(c * ys, sizeof(fr_t)), *qx = (fr_t *)calloc(xs * ys, sizeof(fr_t));
+    for (size_t i = 0; i < xs * ys; i++) fr_load(&P[i], p + 32 * i);
+    for (size_t bx = 0; bx < m; bx++)
+        for (size_t lx = 0; lx < c; lx++)
+            for (size_t y = 0; y < ys; y++) fr_add(&acc[lx * ys + y], &acc[lx * ys + y], &P[(bx * c + lx) * ys + y]);
+    if (ys > d)
+        for (size_t x = 0; x < c; x++)
+            for (size_t y = 0; y < ys - d; y++) {
+                fr_t prev;
+                memset(&prev, 0, sizeof prev);
+                if (y >= d) prev = qy[x * ys + y - d];
+                fr_sub(&qy[x * ys + y], &prev, &acc[x * ys + y]);
+            }
+    fr_t *b = P; /* b_coeffs_vec = p_coeffs_vec */
+    if (ys > d)
+        for (size_t x = 0; x < c; x++)
+            for (size_t y = 0; y < ys - d; y++) {
+                fr_t co = qy[x * ys + y];
+                fr_add(&b[x * ys + y], &b[x * ys + y], &co);
+                fr_sub(&b[x * ys + y + d], &b[x * ys + y + d], &co);
+            }
+    if (xs > c)
+        for (size_t x = 0; x < xs - c; x++)
+            for (size_t y = 0; y < ys; y++) {
+                fr_t prev;
+                memset(&prev, 0, sizeof prev);
+                if (x >= c) prev = qx[(x - c) * ys + y];
+                fr_sub(&qx[x * ys + y], &prev, &b[x * ys + y]);
+            }
+    for (size_t i = 0; i < xs * ys; i++) fr_store(quo_x + 32 * i, &qx[i]);
+    for (size_t i = 0; i < c * ys; i++) fr_store(quo_y + 32 * i, &qy[i]);
+    free(P);
+    free(acc);
+    free(qy);
+    free(qx);
+    return 0;
+}
+/* _div_uni_coeffs_by_ruffini, mod.rs:2460-2477 (Montgomery values; q has len entries) */
+static void ruffini_uni(const fr_t *co, size_t len, const fr_t *x, fr_t *q, fr_t *r) {
+    memset(q, 0, sizeof(fr_t) * len);
+    if (len < 2) {
+        *r = co[0];
+        return;
+    }
+    fr_t b = co[len - 1], t;
+    q[len - 2] = b;
+    for (size_t i = 3; i < len + 1; i++) {
+        fr_mul(&t, &b, x);
+        fr_add(&b, &co[len - i + 1], &t);
+        q[len - i] = b;
+    }
+    fr_mul(&t, &b, x);
+    fr_add(r, &co[0], &t);
+}
+/* div_by_ruffini, mod.rs:2412-2458: q_x is xs x ys, q_y has ys entries, r one */
+void tko_poly_div_by_ruffini(const uint8_t *p, size_t xs, size_t ys, const uint8_t *x, const uint8_t *y, uint8_t *q_x,
+                             uint8_t *q_y, uint8_t *r) {
+    tko_init();
+    fr_t vx, vy;
+    fr_load(&vx, x);
+    fr_load(&vy, y);
+    fr_t *col = (fr_t *)malloc(sizeof(fr_t) * xs), *q = (fr_t *)malloc(sizeof(fr_t) * (xs > ys ? xs : ys));
+    fr_t *rx = (fr_t *)malloc(sizeof(fr_t) * ys);
+    for (size_t j = 0; j < ys; j++) {
+        for (size_t i = 0; i < xs; i++) fr_load(&col[i], p + 32 * (i * ys + j));
+        ruffini_uni(col, xs, &vx, q, &rx[j]);
+        for (size_t i = 0; i < xs; i++) fr_store(q_x + 32 * (i * ys + j), &q[i]);
+    }
+    fr_t rem;
+    ruffini_uni(rx, ys, &vy, q, &rem);
+    for (size_t j = 0; j < ys; j++) fr_store(q_y + 32 * j, &q[j]);
+    fr_store(r, &rem);
+    free(col);
+    free(q);
+    free(rx);
+}

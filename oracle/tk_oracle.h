@@ -89,6 +89,19 @@ void tko_g1_msm(const uint8_t *s, const uint8_t *p, size_t n, int threads, uint8
 /* homogeneous projective (X/Z, Y/Z) -> affine, 144 B -> 96 B (ICICLE G1Projective -> G1Affine) */
 void tko_g1_proj_to_affine(const uint8_t *p144, uint8_t *out96);
 
+/* ---- bivariate coefficient-matrix routines (DensePolynomialExt host loops; element (ix,iy) at ix*ys+iy) ---- */
+void tko_poly_find_degree(const uint8_t *c, size_t xs, size_t ys, int64_t *xd, int64_t *yd);
+void tko_poly_resized_dims(size_t tx, size_t ty, size_t *nx, size_t *ny);
+void tko_poly_resize(const uint8_t *c, size_t xs, size_t ys, size_t nx, size_t ny, uint8_t *out);
+int tko_poly_mul_monomial(const uint8_t *c, size_t xs, size_t ys, size_t ex, size_t ey, size_t nx, size_t ny, uint8_t *out);
+void tko_poly_scale_coeffs(const uint8_t *c, size_t xs, size_t ys, const uint8_t *fx, const uint8_t *fy, uint8_t *out);
+void tko_poly_eval(const uint8_t *c, size_t xs, size_t ys, const uint8_t *x, const uint8_t *y, uint8_t *out);
+void tko_poly_eval_x(const uint8_t *c, size_t xs, size_t ys, const uint8_t *x, uint8_t *out);
+void tko_poly_eval_y(const uint8_t *c, size_t xs, size_t ys, const uint8_t *y, uint8_t *out);
+int tko_poly_div_by_vanishing_opt(const uint8_t *p, size_t xs, size_t ys, size_t c, size_t d, uint8_t *quo_x, uint8_t *quo_y);
+void tko_poly_div_by_ruffini(const uint8_t *p, size_t xs, size_t ys, const uint8_t *x, const uint8_t *y, uint8_t *q_x,
+                             uint8_t *q_y, uint8_t *r);
+
 int tko_num_threads(void);
 
 #ifdef __cplusplus

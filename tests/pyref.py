@@ -72,3 +72,23 @@ def bintt(mat, xs, ys, inverse=False, cx=1, cy=1):
 
 def pt_to_int(p):
     return (0, 0) if p is None else p
+
+
+# ---- bivariate coefficient matrices as {(i, j): coeff} dense lists, element (i, j) at i*ys + j ----
+def poly_eval(m, xs, ys, x, y):
+    return sum(m[i * ys + j] * pow(x, i, R) * pow(y, j, R) for i in range(xs) for j in range(ys)) % R
+
+
+def poly_mul_dense(a, axs, ays, b, bxs, bys, oxs, oys):
+    out = [0] * (oxs * oys)
+    for i in range(axs):
+        for j in range(ays):
+            v = a[i * ays + j]
+            if not v:
+                continue
+            for k in range(bxs):
+                for l in range(bys):
+                    w = b[k * bys + l]
+                    if w:
+                        out[(i + k) * oys + (j + l)] = (out[(i + k) * oys + (j + l)] + v * w) % R
+    return out

@@ -1,0 +1,167 @@
+"""gpu tier: the device-resident DensePolynomialExt work-alike (tkmk/poly.py over tkmk_poly_*) and encode_poly
+(tkmk/sigma.py) vs the oracle's restatement of the reference's host loops, bit-exact.
+Cases follow libs/src/tests.rs (resize / monomial / scale / eval / mul / div_by_vanishing / div_by_ruffini) and the
+prover's shapes (4096x256 ... 8192x512)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P(gpu):
+    gpu.init_ntt_domain_for_size(1 << 23)
+    from tkmk.poly import DensePolynomialExt
+    return DensePolynomialExt
+
+
+def _sparse_box(oracle, seed, xs, ys, xdeg, ydeg):
+    """random coefficients inside the (xdeg, ydeg) box, zero outside"""
+    m = oracle.fr_random(seed, xs * ys).reshape(xs, ys, 32).copy()
+    m[xdeg + 1:, :, :] = 0
+    m[:, ydeg + 1:, :] = 0
+    return m.reshape(-1).copy()
+
+
+@pytest.mark.parametrize("xs,ys,xd,yd", [(8, 16, 5, 9), (1, 64, 0, 10), (64, 1, 33, 0), (512, 256, 300, 129), (4096, 256, 4095, 255)])
+def test_find_degree_and_optimize_size(P, gpu, oracle, xs, ys, xd, yd):
+    m = _sparse_box(oracle, xs + ys, xs, ys, xd, yd)
+    p = P.from_coeffs(m, xs, ys)
+    assert p.degree() == (xs - 1, ys - 1)                    # from_coeffs claims the full box (mod.rs:1546-1547)
+    assert p.find_degree() == oracle.poly_find_degree(m, xs, ys) == (xd, yd)
+    p.optimize_size()
+    want, nx, ny = oracle.poly_resize(m, xs, ys, xd + 1, yd + 1)
+    assert (p.x_size, p.y_size, p.x_degree, p.y_degree) == (nx, ny, xd, yd)
+    assert (p.copy_coeffs() == want).all()
+    z = P.from_coeffs(np.zeros(32 * 16, np.uint8), 4, 4)
+    assert z.find_degree() == (-1, -1)
+    z.optimize_size()                                        # zero polynomial keeps its size (mod.rs:1814-1816)
+    assert (z.x_size, z.y_size) == (4, 4)
+
+
+def test_resize_and_mul_monomial(P, gpu, oracle):
+    xs, ys = 32, 64
+    m = _sparse_box(oracle, 7, xs, ys, 20, 40)
+    p = P.from_coeffs(m, xs, ys)
+    q = p.clone()
+    q.resize(33, 5)                                          # grow x to 64, truncate y to 8
+    want, nx, ny = oracle.poly_resize(m, xs, ys, 33, 5)
+    assert (q.x_size, q.y_size) == (nx, ny) == (64, 8) and (q.copy_coeffs() == want).all()
+    p.optimize_size()                                        # 32 x 64, degree (20, 40)
+    for ex, ey in ((70, 0), (32, 64), (0, 64)):              # shifts the reference's slice copy can hold (mod.rs:1834-1838)
+        sh = p.mul_monomial(ex, ey)
+        want, nx, ny = oracle.poly_mul_monomial(p.copy_coeffs(), p.x_size, p.y_size, 20, 40, ex, ey)
+        assert (sh.x_size, sh.y_size) == (nx, ny) and (sh.copy_coeffs() == want).all()
+    with pytest.raises(ValueError):
+        p.mul_monomial(70, 3)                                # 64 + 3 columns do not fit the 64-column target: reference panics
+    with pytest.raises(ValueError):
+        P.from_coeffs(m, xs, ys).resize(0, 4)
+    with pytest.raises(ValueError):
+        P.from_coeffs(m[:32 * 24], 3, 8)
+
+
+@pytest.mark.parametrize("xs,ys", [(4, 8), (1, 16), (256, 64), (4096, 256)])
+def test_scale_coeffs_and_eval(P, gpu, oracle, xs, ys):
+    m = oracle.fr_random(100 + xs, xs * ys)
+    p = P.from_coeffs(m, xs, ys)
+    fx, fy, x, y = (oracle.fr_random(200 + k, 1) for k in range(4))
+    assert (p.scale_coeffs_x(fx).copy_coeffs() == oracle.poly_scale_coeffs(m, xs, ys, fx, None)).all()
+    assert (p.scale_coeffs_y(fy).copy_coeffs() == oracle.poly_scale_coeffs(m, xs, ys, None, fy)).all()
+    assert (p.eval(x, y) == oracle.poly_eval(m, xs, ys, x, y)).all()
+    ex = p.eval_x(x)
+    assert (ex.x_size, ex.y_size) == (1, ys) and (ex.copy_coeffs() == oracle.poly_eval_x(m, xs, ys, x)).all()
+    ey = p.eval_y(y)
+    assert (ey.x_size, ey.y_size) == (xs, 1) and (ey.copy_coeffs() == oracle.poly_eval_y(m, xs, ys, y)).all()
+
+
+def test_coset_evals_equal_scaled_coefficients(P, gpu, oracle):
+    # libs/src/tests.rs:134-180 on the device-resident object
+    xs, ys = 16, 8
+    p = P.from_coeffs(oracle.fr_random(5, xs * ys), xs, ys)
+    cx, cy = oracle.fr_random(6, 1), oracle.fr_random(7, 1)
+    a = p.to_rou_evals(cx, cy).to_host()
+    b = p.scale_coeffs_x(cx).scale_coeffs_y(cy).to_rou_evals().to_host()
+    assert (a == b).all()
+    back = P.from_rou_evals(a, xs, ys, cx, cy)
+    assert (back.copy_coeffs() == p.copy_coeffs()).all()
+
+
+@pytest.mark.parametrize("ax,ay,bx,by", [(3, 2, 4, 5), (0, 7, 9, 0), (0, 0, 5, 5), (0, 0, 0, 0), (100, 30, 27, 33)])
+def test_mul_vs_oracle(P, gpu, oracle, ax, ay, bx, by):
+    # _mul (mod.rs:1846-1996) == inverse NTT of the pointwise product on the oracle
+    axs, ays = 1 << max(ax, 1).bit_length(), 1 << max(ay, 1).bit_length()
+    bxs, bys = 1 << max(bx, 1).bit_length(), 1 << max(by, 1).bit_length()
+    a = _sparse_box(oracle, 11, axs, ays, ax, ay)
+    b = _sparse_box(oracle, 12, bxs, bys, bx, by)
+    c = P.from_coeffs(a, axs, ays) * P.from_coeffs(b, bxs, bys)
+    x, y = oracle.fr_random(13, 1), oracle.fr_random(14, 1)
+    want = oracle.fr_mul(oracle.poly_eval(a, axs, ays, x, y), oracle.poly_eval(b, bxs, bys, x, y))
+    assert (c.eval(x, y) == want).all()
+    cd = c.find_degree()
+    assert cd == (ax + bx, ay + by)
+    if ax + ay and bx + by:
+        nx, ny = oracle.poly_resized_dims(ax + bx + 1, ay + by + 1)
+        ra, _, _ = oracle.poly_resize(a, axs, ays, nx, ny)
+        rb, _, _ = oracle.poly_resize(b, bxs, bys, nx, ny)
+        prod = oracle.bintt(oracle.fr_mul(oracle.bintt(ra, nx, ny), oracle.bintt(rb, nx, ny)), nx, ny, inverse=True)
+        assert (c.x_size, c.y_size) == (nx, ny) and (c.copy_coeffs() == prod).all()
+
+
+@pytest.mark.parametrize("xs,ys,c,d", [(8, 8, 4, 4), (16, 4, 4, 2), (64, 32, 16, 8), (8192, 512, 4096, 256)])
+def test_div_by_vanishing_opt(P, gpu, oracle, xs, ys, c, d):
+    if xs * ys <= 4096:
+        m = oracle.fr_random(300 + xs, xs * ys)
+        p = P.from_coeffs(m, xs, ys)
+        qx, qy = p.div_by_vanishing_opt(c, d)
+        wx, wy = oracle.poly_div_by_vanishing_opt(m, xs, ys, c, d)
+        assert (qx.copy_coeffs() == wx).all() and (qy.copy_coeffs() == wy).all()
+        assert qx.degree() == (xs - c - 1, ys - 1) and qy.degree() == (c - 1, ys - d - 1)
+    else:
+        # production shape (prove0: p0 on 8192x512 divided by X^4096-1, Y^256-1): build P from known quotients on the
+        # device and recover them.  P = QX*(X^c-1) + QY*(Y^d-1) via shifted copies.
+        qxm = _sparse_box(oracle, 31, xs, ys, xs - c - 1, ys - 1)
+        qym = _sparse_box(oracle, 32, c, ys, c - 1, ys - d - 1)
+        qx, qy = P.from_coeffs(qxm, xs, ys), P.from_coeffs(qym, c, ys)
+        qx.optimize_size()                        # 4096 x 512
+        qy.optimize_size()                        # 4096 x 256
+        p = (qx.mul_monomial(c, 0) - qx) + (qy.mul_monomial(0, d) - qy)
+        rx, ry = p.div_by_vanishing_opt(c, d)
+        assert (rx.copy_coeffs() == qxm).all() and (ry.copy_coeffs() == qym).all()
+    with pytest.raises(ValueError):
+        P.from_coeffs(oracle.fr_random(1, 64), 8, 8).div_by_vanishing_opt(3, 4)
+
+
+@pytest.mark.parametrize("xs,ys", [(1, 1), (1, 8), (8, 1), (2, 2), (64, 32), (4096, 256)])
+def test_div_by_ruffini(P, gpu, oracle, xs, ys):
+    m = oracle.fr_random(400 + xs + ys, xs * ys)
+    x, y = oracle.fr_random(41, 1), oracle.fr_random(42, 1)
+    qx, qy, r = P.from_coeffs(m, xs, ys).div_by_ruffini(x, y)
+    wx, wy, wr = oracle.poly_div_by_ruffini(m, xs, ys, x, y)
+    assert (qx.copy_coeffs() == wx).all() and (qy.copy_coeffs() == wy).all() and (r == wr).all()
+    assert (qy.x_size, qy.y_size) == (1, ys)
+
+
+def test_encode_poly_commit_identity(P, gpu, oracle):
+    """Sigma1.encode_poly on a device-resident fixed-tau CRS: == [P(tau_x, tau_y)]G, trimmed to the degree box, zero
+    polynomial -> G1serde::zero(), too-large degree -> error (libs/src/iotools/mod.rs:2047-2058, 2112)."""
+    from tkmk.sigma import Sigma1
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pins.json")))
+    R = oracle.R_MOD
+    tx, ty = int(pins["tau_x"], 16), int(pins["tau_y"], 16)
+    g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
+    rs_x, rs_y = 32, 16
+    mon = [pow(tx, i, R) * pow(ty, j, R) % R for i in range(rs_x) for j in range(rs_y)]
+    crs = gpu.g1_batch_scalar_mul_device(gpu.DeviceBuffer.from_host(oracle.to_bytes(mon, 32)), g, rs_x * rs_y)
+    sigma = Sigma1(crs, rs_x, rs_y)
+    TX, TY = oracle.to_bytes([tx], 32), oracle.to_bytes([ty], 32)
+    for xs, ys, xd, yd in ((32, 16, 31, 15), (32, 16, 20, 9), (64, 32, 17, 3), (4, 4, 0, 0)):
+        m = _sparse_box(oracle, xs + xd, xs, ys, xd, yd)
+        got = sigma.encode_poly(P.from_coeffs(m, xs, ys))
+        val = oracle.poly_eval(m, xs, ys, TX, TY)
+        assert (got == oracle.g1_scalar_mul(val, g)).all()
+    assert (sigma.encode_poly(P.from_coeffs(np.zeros(32 * 16, np.uint8), 4, 4)) == 0).all()
+    with pytest.raises(ValueError):
+        sigma.encode_poly(P.from_coeffs(oracle.fr_random(3, 64 * 16), 64, 16))

@@ -1,0 +1,367 @@
+// poly.hip — device-resident bookkeeping of the bivariate coefficient matrix behind the tkmk_poly_* entries
+// (include/tkmk.h).  The reference does all of this on the HOST after copying the whole matrix D->H
+// ("resize operands" alone was 6.6 s of a 21 s GPU prove before their fix):
+//   find_degree              packages/backend/libs/src/bivariate_polynomial/mod.rs:1480-1515
+//   resize / mul_monomial    :1784-1806 / :1820-1844   (both are "place src at an offset into a zero matrix")
+//   _scale_coeffs            :1567-1613
+//   eval_x / eval_y / eval   :1719-1750
+//   div_by_vanishing_opt     :2284-2410
+//   div_by_ruffini           :2412-2477
+// Matrix layout: element (ix, iy) at ix*y_size + iy, plain little-endian Fr.  All kernels are HBM-streaming
+// except the two synthetic divisions, which are first-order linear recurrences along one axis.
+#include "common.h"
+
+// ---- find_degree: largest row / column index holding a non-zero coefficient (-1 if none) ----
+__global__ __launch_bounds__(256) void k_find_degree(const fr_t *__restrict__ c, uint32_t xs, uint32_t ys, int *__restrict__ out) {
+    __shared__ int sx[256], sy[256];
+    int mx = -1, my = -1;
+    uint64_t total = (uint64_t)xs * ys;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        if (!Fr::is_zero(tk_load(c + e))) {
+            int i = (int)(e / ys), j = (int)(e - (uint64_t)i * ys);
+            mx = i > mx ? i : mx;
+            my = j > my ? j : my;
+        }
+    }
+    sx[threadIdx.x] = mx;
+    sy[threadIdx.x] = my;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sx[threadIdx.x] = max(sx[threadIdx.x], sx[threadIdx.x + s]);
+            sy[threadIdx.x] = max(sy[threadIdx.x], sy[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (sx[0] >= 0) atomicMax(out, sx[0]);
+        if (sy[0] >= 0) atomicMax(out + 1, sy[0]);
+    }
+}
+
+// dst (dx x dy) = zero matrix with src (sx x sy) placed at (ox, oy); source elements falling outside are dropped
+__global__ __launch_bounds__(256) void k_place(const fr_t *__restrict__ src, uint32_t sx, uint32_t sy, fr_t *__restrict__ dst,
+                                              uint32_t dx, uint32_t dy, uint32_t ox, uint32_t oy) {
+    uint64_t total = (uint64_t)dx * dy;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t i = (uint32_t)(e / dy), j = (uint32_t)(e - (uint64_t)i * dy);
+        fr_t v = Fr::zero();
+        if (i >= ox && j >= oy && i - ox < sx && j - oy < sy) v = tk_load(src + (uint64_t)(i - ox) * sy + (j - oy));
+        tk_store(dst + e, v);
+    }
+}
+
+// pw[i] = g^i (Montgomery), i < n
+__global__ __launch_bounds__(256) void k_powers(fr_t *__restrict__ out, fr_t g, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tk_store(out + i, Fr::pow_u64(g, i));
+}
+
+// dst[i][j] = src[i][j] * px[i] * py[j]   (px / py may be null = all ones)
+__global__ __launch_bounds__(256) void k_scale(const fr_t *__restrict__ src, fr_t *__restrict__ dst, uint32_t xs, uint32_t ys,
+                                              const fr_t *__restrict__ px, const fr_t *__restrict__ py) {
+    uint64_t total = (uint64_t)xs * ys;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t i = (uint32_t)(e / ys), j = (uint32_t)(e - (uint64_t)i * ys);
+        fr_t v = Fr::canon(tk_load(src + e));
+        if (px) v = Fr::mul(v, tk_load(px + i));
+        if (py) v = Fr::mul(v, tk_load(py + j));
+        tk_store(dst + e, v);
+    }
+}
+
+// out[i] = sum_j m[i][j] * w[j]   (one workgroup per row; w Montgomery, result plain)
+__global__ __launch_bounds__(256) void k_row_dot(const fr_t *__restrict__ m, uint32_t ys, const fr_t *__restrict__ w,
+                                                fr_t *__restrict__ out) {
+    __shared__ fr_t sh[256];
+    const fr_t *row = m + (uint64_t)blockIdx.x * ys;
+    fr_t acc = Fr::zero();
+    for (uint32_t j = threadIdx.x; j < ys; j += 256) acc = Fr::add(acc, Fr::mul(Fr::canon(tk_load(row + j)), tk_load(w + j)));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            acc = Fr::add(acc, sh[threadIdx.x + s]);
+            sh[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tk_store(out + blockIdx.x, acc);
+}
+// part[chunk][j] = sum_{i in chunk} m[i][j] * w[i]   (grid: (ceil(ys/256), chunks))
+__global__ __launch_bounds__(256) void k_col_dot_partial(const fr_t *__restrict__ m, uint32_t xs, uint32_t ys,
+                                                        const fr_t *__restrict__ w, fr_t *__restrict__ part, uint32_t rows_per_chunk) {
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ys) return;
+    uint32_t i0 = blockIdx.y * rows_per_chunk, i1 = i0 + rows_per_chunk < xs ? i0 + rows_per_chunk : xs;
+    fr_t acc = Fr::zero();
+    for (uint32_t i = i0; i < i1; i++) acc = Fr::add(acc, Fr::mul(Fr::canon(tk_load(m + (uint64_t)i * ys + j)), tk_load(w + i)));
+    tk_store(part + (uint64_t)blockIdx.y * ys + j, acc);
+}
+__global__ __launch_bounds__(256) void k_col_sum(const fr_t *__restrict__ part, uint32_t chunks, uint32_t ys, fr_t *__restrict__ out) {
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ys) return;
+    fr_t acc = Fr::zero();
+    for (uint32_t k = 0; k < chunks; k++) acc = Fr::add(acc, tk_load(part + (uint64_t)k * ys + j));
+    tk_store(out + j, acc);
+}
+
+// ---- div_by_vanishing_opt: P = Q_X (X^c - 1) + Q_Y (Y^d - 1), coefficient recurrences (mod.rs:2308-2367) ----
+// acc[lx][y] = sum_b p[b*c + lx][y]
+__global__ __launch_bounds__(256) void k_dvo_fold(const fr_t *__restrict__ p, uint32_t xs, uint32_t ys, uint32_t c,
+                                                 fr_t *__restrict__ acc) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)c * ys) return;
+    uint32_t lx = (uint32_t)(e / ys), y = (uint32_t)(e - (uint64_t)lx * ys);
+    fr_t s = Fr::zero();
+    for (uint32_t bx = 0; bx * c < xs; bx++) s = Fr::add(s, Fr::canon(tk_load(p + ((uint64_t)bx * c + lx) * ys + y)));
+    tk_store(acc + e, s);
+}
+// quo_y[x][y] = quo_y[x][y-d] - acc[x][y] for y < ys - d (0 elsewhere): one lane per (x, y mod d), serial over y/d
+__global__ __launch_bounds__(256) void k_dvo_quo_y(const fr_t *__restrict__ acc, uint32_t c, uint32_t ys, uint32_t d,
+                                                  fr_t *__restrict__ qy) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)c * d) return;
+    uint32_t x = (uint32_t)(e / d), r = (uint32_t)(e - (uint64_t)x * d);
+    fr_t prev = Fr::zero();
+    for (uint32_t y = r; y < ys; y += d) {
+        fr_t v = Fr::zero();
+        if (y + d < ys) {  // y < ys - d
+            v = Fr::sub(prev, tk_load(acc + (uint64_t)x * ys + y));
+            prev = v;
+        }
+        tk_store(qy + (uint64_t)x * ys + y, v);
+    }
+}
+// b = p with, for x < c:  b[x][y] += q[x][y] (y < ys-d)  and  b[x][y] -= q[x][y-d] (y >= d, y-d < ys-d)
+// quo_x[x][y] = quo_x[x-c][y] - b[x][y] for x < xs - c (0 elsewhere): one lane per (x mod c, y), serial over x/c
+__global__ __launch_bounds__(256) void k_dvo_quo_x(const fr_t *__restrict__ p, const fr_t *__restrict__ qy, uint32_t xs, uint32_t ys,
+                                                  uint32_t c, uint32_t d, fr_t *__restrict__ qx) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)c * ys) return;
+    uint32_t lx = (uint32_t)(e / ys), y = (uint32_t)(e - (uint64_t)lx * ys);
+    fr_t prev = Fr::zero();
+    for (uint32_t x = lx; x < xs; x += c) {
+        fr_t v = Fr::zero();
+        if (x + c < xs) {  // x < xs - c
+            fr_t b = Fr::canon(tk_load(p + (uint64_t)x * ys + y));
+            if (x < c && ys > d) {
+                if (y + d < ys) b = Fr::add(b, tk_load(qy + (uint64_t)x * ys + y));
+                if (y >= d) b = Fr::sub(b, tk_load(qy + (uint64_t)x * ys + y - d));  // q[y-d] is defined for y-d < ys-d
+            }
+            v = Fr::sub(prev, b);
+            prev = v;
+        }
+        tk_store(qx + (uint64_t)x * ys + y, v);
+    }
+}
+
+// ---- div_by_ruffini: P = Q_X (X - x) + R_X(Y),  R_X = Q_Y (Y - y) + R_Y  (mod.rs:2412-2477) ----
+// one lane per Y index: Horner recurrence down the X axis; xm = x in Montgomery form
+__global__ __launch_bounds__(256) void k_ruffini_x(const fr_t *__restrict__ p, uint32_t xs, uint32_t ys, fr_t xm, fr_t *__restrict__ qx,
+                                                  fr_t *__restrict__ rx) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ys) return;
+    if (xs < 2) {  // _div_uni_coeffs_by_ruffini: len < 2 -> quotient (0), remainder = the coefficient
+        tk_store(qx + j, Fr::zero());
+        tk_store(rx + j, Fr::canon(tk_load(p + j)));
+        return;
+    }
+    fr_t b = Fr::canon(tk_load(p + (uint64_t)(xs - 1) * ys + j));
+    tk_store(qx + (uint64_t)(xs - 1) * ys + j, Fr::zero());
+    tk_store(qx + (uint64_t)(xs - 2) * ys + j, b);
+    for (uint32_t i = xs - 2; i >= 1; i--) {
+        b = Fr::add(Fr::canon(tk_load(p + (uint64_t)i * ys + j)), Fr::mul(b, xm));
+        tk_store(qx + (uint64_t)(i - 1) * ys + j, b);
+    }
+    tk_store(rx + j, Fr::add(Fr::canon(tk_load(p + j)), Fr::mul(b, xm)));
+}
+// single lane: univariate division of r (length n) by (Y - y); out: q (length n, top = 0), rem
+__global__ void k_ruffini_y(const fr_t *__restrict__ r, uint32_t n, fr_t ym, fr_t *__restrict__ q, fr_t *__restrict__ rem) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (n < 2) {
+        tk_store(q, Fr::zero());
+        tk_store(rem, tk_load(r));
+        return;
+    }
+    fr_t b = tk_load(r + n - 1);
+    tk_store(q + n - 1, Fr::zero());
+    tk_store(q + n - 2, b);
+    for (uint32_t i = n - 2; i >= 1; i--) {
+        b = Fr::add(tk_load(r + i), Fr::mul(b, ym));
+        tk_store(q + i - 1, b);
+    }
+    tk_store(rem, Fr::add(tk_load(r), Fr::mul(b, ym)));
+}
+
+// ---------------------------------------------------------------------------------------------------
+static unsigned stream_grid(uint64_t n) {
+    uint64_t g = (n + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    return (unsigned)(g ? g : 1);
+}
+static fr_t fr_in(const tkmk_fr *x) {
+    fr_t r;
+    for (int i = 0; i < 8; i++) r.l[i] = x->limbs[i];
+    return Fr::canon(r);
+}
+static bool fr_is_one(const fr_t &x) {
+    fr_t o = Fr::zero();
+    o.l[0] = 1;
+    return Fr::eq(x, o);
+}
+
+TK_API tkmk_error tkmk_poly_find_degree(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, int64_t *x_degree,
+                                        int64_t *y_degree, tkmk_stream stream) {
+    if (!coeffs_dev || !x_degree || !y_degree) return TKMK_ERR_INVALID_POINTER;
+    if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    tk_scratch d;
+    TK_TRY(d.alloc(8, s));
+    int init[2] = {-1, -1}, res[2];
+    TK_HIP(hipMemcpyAsync(d.p, init, 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_find_degree, stream_grid((uint64_t)x_size * y_size), 256, 0, s, (const fr_t *)coeffs_dev, x_size, y_size,
+                       d.as<int>());
+    TK_HIP(hipGetLastError());
+    TK_HIP(hipMemcpyAsync(res, d.p, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    *x_degree = res[0];
+    *y_degree = res[1];
+    return TKMK_SUCCESS;
+}
+
+TK_API tkmk_error tkmk_poly_place(const tkmk_fr *src_dev, uint32_t sx, uint32_t sy, tkmk_fr *dst_dev, uint32_t dx, uint32_t dy,
+                                  uint32_t off_x, uint32_t off_y, tkmk_stream stream) {
+    if (!src_dev || !dst_dev) return TKMK_ERR_INVALID_POINTER;
+    if (!sx || !sy || !dx || !dy || (const void *)src_dev == (void *)dst_dev) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    hipLaunchKernelGGL(k_place, stream_grid((uint64_t)dx * dy), 256, 0, s, (const fr_t *)src_dev, sx, sy, (fr_t *)dst_dev, dx, dy, off_x,
+                       off_y);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
+
+static tkmk_error powers_table(tk_scratch &t, const fr_t &g_plain, uint64_t n, hipStream_t s) {
+    TK_TRY(t.alloc(n * sizeof(fr_t), s));
+    hipLaunchKernelGGL(k_powers, tk_div_up(n, 256), 256, 0, s, t.as<fr_t>(), Fr::to_mont(g_plain), n);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
+
+TK_API tkmk_error tkmk_poly_scale_coeffs(const tkmk_fr *src_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *factor_x,
+                                         const tkmk_fr *factor_y, tkmk_fr *dst_dev, tkmk_stream stream) {
+    if (!src_dev || !dst_dev) return TKMK_ERR_INVALID_POINTER;
+    if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    tk_scratch tx, ty;
+    const fr_t *px = nullptr, *py = nullptr;
+    if (factor_x && !fr_is_one(fr_in(factor_x))) {
+        TK_TRY(powers_table(tx, fr_in(factor_x), x_size, s));
+        px = tx.as<fr_t>();
+    }
+    if (factor_y && !fr_is_one(fr_in(factor_y))) {
+        TK_TRY(powers_table(ty, fr_in(factor_y), y_size, s));
+        py = ty.as<fr_t>();
+    }
+    hipLaunchKernelGGL(k_scale, stream_grid((uint64_t)x_size * y_size), 256, 0, s, (const fr_t *)src_dev, (fr_t *)dst_dev, x_size, y_size,
+                       px, py);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
+
+// out_dev[j] = P(x, Y) coefficients (y_size values)
+TK_API tkmk_error tkmk_poly_eval_x(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, tkmk_fr *out_dev,
+                                   tkmk_stream stream) {
+    if (!coeffs_dev || !x || !out_dev) return TKMK_ERR_INVALID_POINTER;
+    if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    tk_scratch tx, part;
+    TK_TRY(powers_table(tx, fr_in(x), x_size, s));
+    uint32_t rows_per_chunk = 64, chunks = (x_size + rows_per_chunk - 1) / rows_per_chunk;
+    TK_TRY(part.alloc((size_t)chunks * y_size * sizeof(fr_t), s));
+    hipLaunchKernelGGL(k_col_dot_partial, dim3(tk_div_up(y_size, 256), chunks), 256, 0, s, (const fr_t *)coeffs_dev, x_size, y_size,
+                       (const fr_t *)tx.p, part.as<fr_t>(), rows_per_chunk);
+    hipLaunchKernelGGL(k_col_sum, tk_div_up(y_size, 256), 256, 0, s, (const fr_t *)part.p, chunks, y_size, (fr_t *)out_dev);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
+// out_dev[i] = P(X, y) coefficients (x_size values)
+TK_API tkmk_error tkmk_poly_eval_y(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *y, tkmk_fr *out_dev,
+                                   tkmk_stream stream) {
+    if (!coeffs_dev || !y || !out_dev) return TKMK_ERR_INVALID_POINTER;
+    if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    tk_scratch ty;
+    TK_TRY(powers_table(ty, fr_in(y), y_size, s));
+    hipLaunchKernelGGL(k_row_dot, x_size, 256, 0, s, (const fr_t *)coeffs_dev, y_size, (const fr_t *)ty.p, (fr_t *)out_dev);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
+// *out (host) = P(x, y)
+TK_API tkmk_error tkmk_poly_eval(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, const tkmk_fr *y,
+                                 tkmk_fr *out_host, tkmk_stream stream) {
+    if (!coeffs_dev || !x || !y || !out_host) return TKMK_ERR_INVALID_POINTER;
+    if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    tk_scratch tx, ty, rows, res;
+    TK_TRY(powers_table(tx, fr_in(x), x_size, s));
+    TK_TRY(powers_table(ty, fr_in(y), y_size, s));
+    TK_TRY(rows.alloc((size_t)x_size * sizeof(fr_t), s));
+    TK_TRY(res.alloc(sizeof(fr_t), s));
+    hipLaunchKernelGGL(k_row_dot, x_size, 256, 0, s, (const fr_t *)coeffs_dev, y_size, (const fr_t *)ty.p, rows.as<fr_t>());
+    hipLaunchKernelGGL(k_row_dot, 1, 256, 0, s, (const fr_t *)rows.p, x_size, (const fr_t *)tx.p, res.as<fr_t>());
+    TK_HIP(hipGetLastError());
+    TK_HIP(hipMemcpyAsync(out_host, res.p, sizeof(fr_t), hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    return TKMK_SUCCESS;
+}
+
+// p: x_size x y_size with c | x_size, d | y_size (the reference optimize_size()s first).  quo_x: x_size x y_size,
+// quo_y: c x y_size.  In place is not allowed.
+TK_API tkmk_error tkmk_poly_div_by_vanishing_opt(const tkmk_fr *p_dev, uint32_t x_size, uint32_t y_size, uint32_t c, uint32_t d,
+                                                 tkmk_fr *quo_x_dev, tkmk_fr *quo_y_dev, tkmk_stream stream) {
+    if (!p_dev || !quo_x_dev || !quo_y_dev) return TKMK_ERR_INVALID_POINTER;
+    if (!c || !d || (c & (c - 1)) || (d & (d - 1)) || !x_size || !y_size || x_size % c || y_size % d) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    tk_scratch acc;
+    TK_TRY(acc.alloc((size_t)c * y_size * sizeof(fr_t), s));
+    hipLaunchKernelGGL(k_dvo_fold, tk_div_up((uint64_t)c * y_size, 256), 256, 0, s, (const fr_t *)p_dev, x_size, y_size, c, acc.as<fr_t>());
+    hipLaunchKernelGGL(k_dvo_quo_y, tk_div_up((uint64_t)c * d, 256), 256, 0, s, (const fr_t *)acc.p, c, y_size, d, (fr_t *)quo_y_dev);
+    hipLaunchKernelGGL(k_dvo_quo_x, tk_div_up((uint64_t)c * y_size, 256), 256, 0, s, (const fr_t *)p_dev, (const fr_t *)quo_y_dev, x_size,
+                       y_size, c, d, (fr_t *)quo_x_dev);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
+
+// q_x: x_size x y_size, q_y: y_size values (1 x y_size), *r_host = P(x, y)
+TK_API tkmk_error tkmk_poly_div_by_ruffini(const tkmk_fr *p_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, const tkmk_fr *y,
+                                           tkmk_fr *q_x_dev, tkmk_fr *q_y_dev, tkmk_fr *r_host, tkmk_stream stream) {
+    if (!p_dev || !x || !y || !q_x_dev || !q_y_dev || !r_host) return TKMK_ERR_INVALID_POINTER;
+    if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    tk_scratch rx, rem;
+    TK_TRY(rx.alloc((size_t)y_size * sizeof(fr_t), s));
+    TK_TRY(rem.alloc(sizeof(fr_t), s));
+    hipLaunchKernelGGL(k_ruffini_x, tk_div_up(y_size, 256), 256, 0, s, (const fr_t *)p_dev, x_size, y_size, Fr::to_mont(fr_in(x)),
+                       (fr_t *)q_x_dev, rx.as<fr_t>());
+    hipLaunchKernelGGL(k_ruffini_y, 1, 64, 0, s, (const fr_t *)rx.p, y_size, Fr::to_mont(fr_in(y)), (fr_t *)q_y_dev, rem.as<fr_t>());
+    TK_HIP(hipGetLastError());
+    TK_HIP(hipMemcpyAsync(r_host, rem.p, sizeof(fr_t), hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    return TKMK_SUCCESS;
+}

@@ -253,6 +253,17 @@ TK_API tkmk_error tkmk_memcpy_h2d_async(void *dst, const void *src, size_t bytes
 TK_API tkmk_error tkmk_memcpy_d2h_async(void *dst, const void *src, size_t bytes, tkmk_stream s) {
     return copy_async(dst, src, bytes, hipMemcpyDeviceToHost, s);
 }
+TK_API tkmk_error tkmk_memcpy_2d_d2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows) {
+    if (width_bytes == 0 || rows == 0) return TKMK_SUCCESS;
+    if (!dst || !src) return TKMK_ERR_INVALID_POINTER;
+    if (dst_pitch < width_bytes || src_pitch < width_bytes) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    if (hipMemcpy2D(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_ERR_COPY_FAILED;
+    }
+    return TKMK_SUCCESS;
+}
 TK_API tkmk_error tkmk_memset(void *ptr, int value, size_t bytes) {
     if (bytes == 0) return TKMK_SUCCESS;
     if (!ptr) return TKMK_ERR_INVALID_POINTER;

@@ -81,14 +81,16 @@ class VecOpsConfig(ctypes.Structure):
 SYMBOLS = [
     "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
     "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
-    "tkmk_memcpy_d2h_async", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
+    "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
     "tkmk_device_synchronize", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm",
     "tkmk_ntt_default_config", "bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain",
     "bls12_381_ntt", "tkmk_bintt", "tkmk_vecops_default_config", "bls12_381_vector_add", "bls12_381_vector_sub",
     "bls12_381_vector_mul", "bls12_381_vector_div", "bls12_381_vector_inv", "bls12_381_scalar_add_vec",
     "bls12_381_scalar_sub_vec", "bls12_381_scalar_mul_vec", "bls12_381_vector_sum", "bls12_381_vector_product",
     "bls12_381_matrix_transpose", "tkmk_fr_random_device", "tkmk_g1_batch_scalar_mul_device", "tkmk_profile_enable",
-    "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench", "tkmk_diag_field_mul",
+    "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench", "tkmk_diag_field_mul", "tkmk_poly_find_degree",
+    "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
+    "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini",
 ]
 
 
