@@ -226,6 +226,9 @@ tkmk_error tkmk_poly_place(const tkmk_fr *src_dev, uint32_t sx, uint32_t sy, tkm
 /* dst[i][j] = src[i][j] * factor_x^i * factor_y^j (_scale_coeffs, mod.rs:1567-1613; NULL factor = 1); in place ok */
 tkmk_error tkmk_poly_scale_coeffs(const tkmk_fr *src_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *factor_x,
                                   const tkmk_fr *factor_y, tkmk_fr *dst_dev, tkmk_stream stream);
+/* dst[i][j] = evals[i][j] * (w_x^i - 1): PolyExpr::MulXMinusOne on the evaluation domain (mod.rs:372-378, 504-518) */
+tkmk_error tkmk_poly_mul_x_minus_one_evals(const tkmk_fr *evals_dev, uint32_t x_size, uint32_t y_size, tkmk_fr *dst_dev,
+                                           tkmk_stream stream);
 /* eval_x / eval_y / eval (mod.rs:1719-1750): out_dev has y_size / x_size elements; out_host one */
 tkmk_error tkmk_poly_eval_x(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, tkmk_fr *out_dev,
                             tkmk_stream stream);

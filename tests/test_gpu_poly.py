@@ -165,3 +165,33 @@ def test_encode_poly_commit_identity(P, gpu, oracle):
     assert (sigma.encode_poly(P.from_coeffs(np.zeros(32 * 16, np.uint8), 4, 4)) == 0).all()
     with pytest.raises(ValueError):
         sigma.encode_poly(P.from_coeffs(oracle.fr_random(3, 64 * 16), 64, 16))
+
+
+def test_polyexpr_fused_equals_coefficient_route(P, gpu, oracle):
+    """PolyExpr (mod.rs:141-436; reference test libs/src/tests.rs:1240-1276): fused evaluation-domain route ==
+    coefficient route == the expression evaluated at a random point with the oracle."""
+    from tkmk.poly import PolyExpr
+    xs, ys = 16, 8
+    A = P.from_coeffs(_sparse_box(oracle, 1, xs, ys, 9, 5), xs, ys)
+    B = P.from_coeffs(_sparse_box(oracle, 2, xs, ys, 6, 7), xs, ys)
+    C = P.from_coeffs(_sparse_box(oracle, 3, xs, ys, 3, 2), xs, ys)
+    s1, s2 = oracle.fr_random(4, 1), oracle.fr_random(5, 1)
+    E = PolyExpr
+    expr = E.sub(E.add(E.mul(E.poly(A), E.poly(B)), E.scale(s1, E.mul_x_minus_one(E.poly(C)))),
+                 E.weighted_sum([(s2, E.mul(E.poly(A), E.poly(C))), (s1, E.poly(B)), (s2, E.scalar(s1))]))
+    assert expr.degree_bound() == (15, 12)
+    fused = expr.evaluate_fused()
+    coeff = expr.evaluate_coeffs()
+    assert (fused.x_size, fused.y_size) == (16, 16)
+    x, y = oracle.fr_random(6, 1), oracle.fr_random(7, 1)
+    ev = lambda p: oracle.poly_eval(p.copy_coeffs(), p.x_size, p.y_size, x, y)
+    a, b, c = ev(A), ev(B), ev(C)
+    one = oracle.to_bytes([1], 32)
+    xm1 = oracle.fr_sub(x, one)
+    want = oracle.fr_sub(oracle.fr_add(oracle.fr_mul(a, b), oracle.fr_mul(s1, oracle.fr_mul(c, xm1))),
+                         oracle.fr_add(oracle.fr_add(oracle.fr_mul(s2, oracle.fr_mul(a, c)), oracle.fr_mul(s1, b)), oracle.fr_mul(s2, s1)))
+    assert (ev(fused) == want).all() and (ev(coeff) == want).all()
+    big = expr.evaluate_fused_with_domain(64, 32)
+    assert (big.x_size, big.y_size) == (64, 32) and (ev(big) == want).all()
+    with pytest.raises(ValueError):
+        expr.evaluate_fused_with_domain(8, 16)

@@ -57,14 +57,14 @@ __global__ __launch_bounds__(256) void k_powers(fr_t *__restrict__ out, fr_t g, 
     if (i < n) tk_store(out + i, Fr::pow_u64(g, i));
 }
 
-// dst[i][j] = src[i][j] * px[i] * py[j]   (px / py may be null = all ones)
+// dst[i][j] = src[i][j] * px[i] * py[j]   (px / py may be null = all ones); x_minus_one: use (px[i] - 1) instead
 __global__ __launch_bounds__(256) void k_scale(const fr_t *__restrict__ src, fr_t *__restrict__ dst, uint32_t xs, uint32_t ys,
-                                              const fr_t *__restrict__ px, const fr_t *__restrict__ py) {
+                                              const fr_t *__restrict__ px, const fr_t *__restrict__ py, int x_minus_one) {
     uint64_t total = (uint64_t)xs * ys;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t i = (uint32_t)(e / ys), j = (uint32_t)(e - (uint64_t)i * ys);
         fr_t v = Fr::canon(tk_load(src + e));
-        if (px) v = Fr::mul(v, tk_load(px + i));
+        if (px) v = Fr::mul(v, x_minus_one ? Fr::sub(tk_load(px + i), Fr::one()) : tk_load(px + i));
         if (py) v = Fr::mul(v, tk_load(py + j));
         tk_store(dst + e, v);
     }
@@ -269,7 +269,26 @@ TK_API tkmk_error tkmk_poly_scale_coeffs(const tkmk_fr *src_dev, uint32_t x_size
         py = ty.as<fr_t>();
     }
     hipLaunchKernelGGL(k_scale, stream_grid((uint64_t)x_size * y_size), 256, 0, s, (const fr_t *)src_dev, (fr_t *)dst_dev, x_size, y_size,
-                       px, py);
+                       px, py, 0);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
+
+// dst[i][j] = evals[i][j] * (w_x^i - 1): the evaluation-domain form of "multiply by (X - 1)" used by
+// PolyExpr::MulXMinusOne (mod.rs:372-378, x_minus_one_evals :504-518); w_x = root of unity of order x_size
+TK_API tkmk_error tkmk_poly_mul_x_minus_one_evals(const tkmk_fr *evals_dev, uint32_t x_size, uint32_t y_size, tkmk_fr *dst_dev,
+                                                  tkmk_stream stream) {
+    if (!evals_dev || !dst_dev) return TKMK_ERR_INVALID_POINTER;
+    if (!x_size || !y_size || (x_size & (x_size - 1))) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    tkmk_fr w;
+    TK_TRY(bls12_381_get_root_of_unity(x_size, &w));
+    tk_scratch tx;
+    TK_TRY(powers_table(tx, fr_in(&w), x_size, s));
+    hipLaunchKernelGGL(k_scale, stream_grid((uint64_t)x_size * y_size), 256, 0, s, (const fr_t *)evals_dev, (fr_t *)dst_dev, x_size, y_size,
+                       (const fr_t *)tx.p, (const fr_t *)nullptr, 1);
     TK_HIP(hipGetLastError());
     return TKMK_SUCCESS;
 }

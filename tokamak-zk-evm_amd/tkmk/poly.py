@@ -220,3 +220,135 @@ class DensePolynomialExt:
         tkmk._check(tkmk.lib().tkmk_poly_div_by_ruffini(tkmk._p(self.poly), self.x_size, self.y_size, _fr(x), _fr(y), tkmk._p(qx),
                                                        tkmk._p(qy), tkmk._p(r), None), "tkmk_poly_div_by_ruffini")
         return (DensePolynomialExt.from_coeffs(qx, self.x_size, self.y_size), DensePolynomialExt.from_coeffs(qy, 1, self.y_size), r)
+
+
+def _next_pow2(n):
+    return 1 if n <= 1 else 1 << (n - 1).bit_length()
+
+
+class PolyExpr:
+    """Work-alike of the reference's fused expression evaluator (mod.rs:141-436): NTT every distinct leaf once
+    (cache keyed by object identity and domain), evaluate the tree with pointwise device ops, one inverse NTT.
+    Temporaries are reused in place instead of allocating a fresh 256 MiB buffer per node."""
+
+    def __init__(self, kind, *args):
+        self.kind, self.args = kind, args
+
+    poly = classmethod(lambda cls, p: cls("poly", p))
+    scalar = classmethod(lambda cls, s: cls("scalar", np.ascontiguousarray(s)))
+    add = classmethod(lambda cls, a, b: cls("add", a, b))
+    sub = classmethod(lambda cls, a, b: cls("sub", a, b))
+    mul = classmethod(lambda cls, a, b: cls("mul", a, b))
+    scale = classmethod(lambda cls, s, e: cls("scale", np.ascontiguousarray(s), e))
+    mul_x_minus_one = classmethod(lambda cls, e: cls("xm1", e))
+
+    @classmethod
+    def weighted_sum(cls, terms):
+        return cls("sum", [cls.scale(s, e) for s, e in terms])
+
+    # -- coefficient route (mod.rs:190-218) --
+    def evaluate_coeffs(self):
+        k, a = self.kind, self.args
+        if k == "poly":
+            return a[0].clone()
+        if k == "scalar":
+            return DensePolynomialExt.from_coeffs(a[0], 1, 1)
+        if k == "add":
+            return a[0].evaluate_coeffs() + a[1].evaluate_coeffs()
+        if k == "sub":
+            return a[0].evaluate_coeffs() - a[1].evaluate_coeffs()
+        if k == "mul":
+            return a[0].evaluate_coeffs() * a[1].evaluate_coeffs()
+        if k == "scale":
+            return a[1].evaluate_coeffs().scalar_mul(a[0])
+        if k == "xm1":
+            p = a[0].evaluate_coeffs()
+            p.optimize_size()
+            return p.mul_monomial(1, 0) - p if p.x_degree >= 0 else p
+        terms = a[0]
+        if not terms:
+            return DensePolynomialExt.zero()
+        acc = terms[0].evaluate_coeffs()
+        for t in terms[1:]:
+            acc = acc + t.evaluate_coeffs()
+        return acc
+
+    # -- fused route (mod.rs:220-436) --
+    def degree_bound(self):
+        k, a = self.kind, self.args
+        if k == "poly":
+            return a[0].find_degree()
+        if k == "scalar":
+            return (0, 0) if a[0].any() else (-1, -1)
+        if k in ("add", "sub"):
+            l, r = a[0].degree_bound(), a[1].degree_bound()
+            return max(l[0], r[0]), max(l[1], r[1])
+        if k == "mul":
+            l, r = a[0].degree_bound(), a[1].degree_bound()
+            return (-1, -1) if min(l + r) < 0 else (l[0] + r[0], l[1] + r[1])
+        if k == "scale":
+            return a[1].degree_bound() if a[0].any() else (-1, -1)
+        if k == "xm1":
+            d = a[0].degree_bound()
+            return (-1, -1) if min(d) < 0 else (d[0] + 1, d[1])
+        out = (-1, -1)
+        for t in a[0]:
+            d = t.degree_bound()
+            out = (max(out[0], d[0]), max(out[1], d[1]))
+        return out
+
+    def evaluate_fused(self):
+        xd, yd = self.degree_bound()
+        return self.evaluate_fused_with_domain(_next_pow2(xd + 1) if xd >= 0 else 1, _next_pow2(yd + 1) if yd >= 0 else 1)
+
+    def evaluate_fused_with_domain(self, target_x_size, target_y_size):
+        if not _is_pow2(target_x_size) or not _is_pow2(target_y_size):
+            raise ValueError("Fused polynomial expression domains must be powers of two.")
+        xd, yd = self.degree_bound()
+        if (_next_pow2(xd + 1) if xd >= 0 else 1) > target_x_size or (_next_pow2(yd + 1) if yd >= 0 else 1) > target_y_size:
+            raise ValueError("Fused polynomial expression domain is too small for the expression degree.")
+        cache = {}
+        evals, _ = self._on_domain(target_x_size, target_y_size, cache)
+        return DensePolynomialExt.from_rou_evals(evals, target_x_size, target_y_size)
+
+    def _on_domain(self, xs, ys, cache):
+        """-> (DeviceBuffer of evaluations, owned): owned buffers are temporaries that may be overwritten in place"""
+        k, a = self.kind, self.args
+        n = xs * ys
+        if k == "poly":
+            key = (id(a[0]), xs, ys)
+            if key not in cache:
+                r = a[0].clone()
+                r.resize(xs, ys)
+                cache[key] = tkmk.bintt(r.poly, xs, ys, out=r.poly)
+            return cache[key], False
+        if k == "scalar":
+            return tkmk.DeviceBuffer.from_host(np.tile(a[0], n)), True
+        if k in ("add", "sub", "mul"):
+            l, lo = a[0]._on_domain(xs, ys, cache)
+            r, ro = a[1]._on_domain(xs, ys, cache)
+            fn = {"add": tkmk.vec_add, "sub": tkmk.vec_sub, "mul": tkmk.vec_mul}[k]
+            out = l if lo else (r if ro else None)
+            return fn(l, r, out=out), True
+        if k == "scale":
+            e, eo = a[1]._on_domain(xs, ys, cache)
+            one = np.zeros(32, np.uint8)
+            one[0] = 1
+            if (a[0] == one).all():
+                return e, eo
+            return tkmk.scalar_mul(tkmk.DeviceBuffer.from_host(a[0]), e, out=e if eo else None), True
+        if k == "xm1":
+            e, eo = a[0]._on_domain(xs, ys, cache)
+            out = e if eo else tkmk.DeviceBuffer(32 * n)
+            tkmk._check(tkmk.lib().tkmk_poly_mul_x_minus_one_evals(tkmk._p(e), xs, ys, tkmk._p(out), None), "tkmk_poly_mul_x_minus_one_evals")
+            return out, True
+        acc = None
+        for t in a[0]:
+            e, eo = t._on_domain(xs, ys, cache)
+            if acc is None:
+                acc = e if eo else tkmk.vec_add(e, tkmk.DeviceBuffer.from_host(np.zeros(32 * n, np.uint8)))
+            else:
+                tkmk.vec_add(acc, e, out=acc)
+        if acc is None:
+            acc = tkmk.DeviceBuffer.from_host(np.zeros(32 * n, np.uint8))
+        return acc, True
