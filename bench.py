@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--logn", type=int, default=24, help="log2 of points per GPU (default: BASELINE configs[1])")
     ap.add_argument("--cpu-sample-logn", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
+    ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --dist-backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -53,13 +55,18 @@ def main():
     from tkmk import sharding
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    tkmk.set_device(local_rank)
+    dev = 0 if args.share_gpu0 else local_rank
+    torch.cuda.set_device(dev)
+    tkmk.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    comm_device = "cuda" if args.dist_backend == "nccl" else "cpu"
 
     n = 1 << args.logn
     # --- synthetic inputs, generated in HBM (untimed) ---
@@ -76,7 +83,7 @@ def main():
         tkmk.synchronize()
 
     def step():
-        return sharding.msm_sharded(tkmk, dist, scalars, bases, device="cuda")   # 144-byte canonical projective
+        return sharding.msm_sharded(tkmk, dist, scalars, bases, device=comm_device)   # 144-byte canonical projective
 
     for _ in range(args.warmup):
         step()
@@ -90,7 +97,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tkmk.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -107,8 +114,8 @@ def main():
         points_per_s = n * world * args.steps / elapsed
         value = points_per_s * ADDS_PER_POINT
         # dominant kernel: k_accumulate (one launch per MSM of n points)
-        launches = acc_cnt if acc_cnt else 1
-        kernel_ms = acc_ms / launches if acc_cnt else float("nan")
+        # one big launch per step (for N > 1 the world-point combine MSM adds a negligible second one)
+        kernel_ms = acc_ms / args.steps if acc_cnt else float("nan")
         alg_bytes = n * ALG_BYTES_PER_POINT
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = _traffic_from_profiles(args.logn)
@@ -129,7 +136,7 @@ def main():
                                    % args.logn,
                        "points_per_gpu": n, "sharding": "points" if world > 1 else "none"},
             "points_per_s": points_per_s,
-            "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer-VALU bound by construction (SURVEY.md §8d): ~375 int mul-adds per algorithmic byte"},
@@ -153,7 +160,7 @@ def _generator():
 
 
 def _traffic_from_profiles(logn):
-    """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC summary (profiles/), or None."""
+    """HBM bytes per k_accumulate_chunks launch from the committed rocprofv3 PMC summary (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(path))

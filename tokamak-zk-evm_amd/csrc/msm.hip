@@ -6,7 +6,7 @@
 //   k_convert_bases   plain affine -> Montgomery affine, once per call (skipped for Montgomery input)
 //   k_digits          scalar -> W signed c-bit digits (|d| <= 2^(c-1)), coalesced [w][i] u32 records
 //   k_hist            per (window, chunk) workgroup: LDS-privatised bucket histogram (<= 128 KiB of LDS)
-//   k_scan            per window: chunk-exclusive cursors + bucket start offsets
+//   k_scan_local/apply  chunk-exclusive cursors + bucket start offsets (two-level scan over 1024-bucket groups)
 //   k_scatter         per (window, chunk): LDS cursors, ds_add_rtn ranks -> bucket-sorted point indices
 //   k_accumulate_chunks  one lane per 64-entry chunk of the sorted list: XYZZ accumulator in VGPRs += gathered
 //                     affine bases (8M+2S each); k_combine / k_combine_big sum each bucket's chunk fragments
@@ -111,40 +111,51 @@ __global__ __launch_bounds__(1024) void k_hist(const uint32_t *__restrict__ dig,
     for (uint32_t b = threadIdx.x; b < pl.B; b += blockDim.x) c[(uint64_t)b * pl.chunks + ch] = hist[b];
 }
 
-// grid (W), 1024 threads.  counts[w][b][chunk] -> exclusive cursor (absolute position in the window's
-// sorted list); bstart[w][b] for b in [0, B]
-__global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ counts, uint32_t *__restrict__ bstart, msm_plan_t pl) {
+// counts[w][b][chunk] -> exclusive cursors (absolute position in the window's sorted list) and bstart[w][b],
+// b in [0, B], in two launches over (ceil(B/1024), W) workgroups:
+//   k_scan_local : one lane per bucket sums its chunks; workgroup-exclusive scan; group total -> gtot[w][grp]
+//   k_scan_apply : adds the exclusive prefix of the (<= 32) group totals, writes bstart and the cursors
+__global__ __launch_bounds__(1024) void k_scan_local(const uint32_t *__restrict__ counts, uint32_t *__restrict__ local,
+                                                    uint32_t *__restrict__ gtot, msm_plan_t pl) {
     __shared__ uint32_t part[1024];
-    const uint32_t w = blockIdx.x, t = threadIdx.x;
-    uint32_t *c = counts + (uint64_t)w * pl.B * pl.chunks;
-    uint32_t *bs = bstart + (uint64_t)w * (pl.B + 1);
-    // each thread owns a contiguous range of buckets
-    uint32_t per = (pl.B + blockDim.x - 1) / blockDim.x;
-    uint32_t b0 = t * per, b1 = b0 + per;
-    if (b0 > pl.B) b0 = pl.B;
-    if (b1 > pl.B) b1 = pl.B;
+    const uint32_t w = blockIdx.y, t = threadIdx.x, b = blockIdx.x * 1024 + t;
     uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++)
-        for (uint32_t k = 0; k < pl.chunks; k++) sum += c[(uint64_t)b * pl.chunks + k];
+    if (b < pl.B) {
+        const uint32_t *c = counts + ((uint64_t)w * pl.B + b) * pl.chunks;
+        for (uint32_t k = 0; k < pl.chunks; k++) sum += c[k];
+    }
     part[t] = sum;
     __syncthreads();
-    // exclusive scan of part[] (Hillis-Steele, 1024 entries)
-    for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
         uint32_t v = t >= off ? part[t - off] : 0;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    uint32_t run = part[t] - sum;
-    for (uint32_t b = b0; b < b1; b++) {
+    if (b < pl.B) local[(uint64_t)w * pl.B + b] = part[t] - sum;  // exclusive within the group
+    if (t == 1023) gtot[w * gridDim.x + blockIdx.x] = part[t];
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(uint32_t *__restrict__ counts, const uint32_t *__restrict__ local,
+                                                    const uint32_t *__restrict__ gtot, uint32_t *__restrict__ bstart, msm_plan_t pl) {
+    const uint32_t w = blockIdx.y, t = threadIdx.x, b = blockIdx.x * 1024 + t;
+    uint32_t base = 0, total = 0;
+    for (uint32_t g = 0; g < gridDim.x; g++) {
+        uint32_t v = gtot[w * gridDim.x + g];
+        if (g < blockIdx.x) base += v;
+        total += v;
+    }
+    uint32_t *bs = bstart + (uint64_t)w * (pl.B + 1);
+    if (b < pl.B) {
+        uint32_t run = base + local[(uint64_t)w * pl.B + b];
         bs[b] = run;
+        uint32_t *c = counts + ((uint64_t)w * pl.B + b) * pl.chunks;
         for (uint32_t k = 0; k < pl.chunks; k++) {
-            uint32_t v = c[(uint64_t)b * pl.chunks + k];
-            c[(uint64_t)b * pl.chunks + k] = run;
+            uint32_t v = c[k];
+            c[k] = run;
             run += v;
         }
     }
-    if (t == blockDim.x - 1) bs[pl.B] = part[t];
+    if (blockIdx.x == 0 && t == 0) bs[pl.B] = total;
 }
 
 // grid (chunks, W); dynamic LDS = B * 4 bytes.  sorted[w][pos] = point index | sign
@@ -531,7 +542,14 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
     }
     hipLaunchKernelGGL(k_hist, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, d_counts.as<uint32_t>(), pl);
     prof.mark("msm.hist");
-    hipLaunchKernelGGL(k_scan, pl.W, 1024, 0, s, d_counts.as<uint32_t>(), d_bstart.as<uint32_t>(), pl);
+    const uint32_t groups = (pl.B + 1023) / 1024;
+    tk_scratch d_local, d_gtot;
+    TK_TRY(d_local.alloc((size_t)pl.W * pl.B * 4, s));
+    TK_TRY(d_gtot.alloc((size_t)pl.W * groups * 4, s));
+    hipLaunchKernelGGL(k_scan_local, dim3(groups, pl.W), 1024, 0, s, (const uint32_t *)d_counts.p, d_local.as<uint32_t>(),
+                       d_gtot.as<uint32_t>(), pl);
+    hipLaunchKernelGGL(k_scan_apply, dim3(groups, pl.W), 1024, 0, s, d_counts.as<uint32_t>(), (const uint32_t *)d_local.p,
+                       (const uint32_t *)d_gtot.p, d_bstart.as<uint32_t>(), pl);
     prof.mark("msm.scan");
     hipLaunchKernelGGL(k_scatter, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, (const uint32_t *)d_counts.p,
                        d_sorted.as<uint32_t>(), pl);

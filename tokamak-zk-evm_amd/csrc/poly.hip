@@ -157,24 +157,43 @@ __global__ __launch_bounds__(256) void k_dvo_quo_x(const fr_t *__restrict__ p, c
 }
 
 // ---- div_by_ruffini: P = Q_X (X - x) + R_X(Y),  R_X = Q_Y (Y - y) + R_Y  (mod.rs:2412-2477) ----
-// one lane per Y index: Horner recurrence down the X axis; xm = x in Montgomery form
-__global__ __launch_bounds__(256) void k_ruffini_x(const fr_t *__restrict__ p, uint32_t xs, uint32_t ys, fr_t xm, fr_t *__restrict__ qx,
-                                                  fr_t *__restrict__ rx) {
+// Along X every column is the Horner recurrence B_k = c_k + x B_{k+1} (B_len = 0), with q[k-1] = B_k and remainder B_0
+// (_div_uni_coeffs_by_ruffini, mod.rs:2460-2477).  The reference runs it serially per column (rayon over columns);
+// here the rows are cut into segments of L: (1) local Horner per (segment, column) with zero carry-in,
+// (2) a short serial pass over the segments per column propagates the carries with x^L, (3) each segment reruns
+// its recurrence from the true carry-in and writes q.  Critical path 2L + len/L steps instead of len.
+__global__ __launch_bounds__(256) void k_ruffini_local(const fr_t *__restrict__ p, uint32_t xs, uint32_t ys, fr_t xm, uint32_t L,
+                                                      fr_t *__restrict__ H) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, sgm = blockIdx.y;
+    if (j >= ys) return;
+    uint32_t lo = sgm * L, hi = lo + L < xs ? lo + L : xs;
+    fr_t h = Fr::zero();
+    for (uint32_t k = hi; k-- > lo;) h = Fr::add(Fr::canon(tk_load(p + (uint64_t)k * ys + j)), Fr::mul(h, xm));
+    tk_store(H + (uint64_t)sgm * ys + j, h);
+}
+// carry[s][j] = B at the first row above segment s;  xLm = x^L (Montgomery)
+__global__ __launch_bounds__(256) void k_ruffini_carry(const fr_t *__restrict__ H, uint32_t S, uint32_t ys, fr_t xLm,
+                                                      fr_t *__restrict__ carry) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ys) return;
-    if (xs < 2) {  // _div_uni_coeffs_by_ruffini: len < 2 -> quotient (0), remainder = the coefficient
-        tk_store(qx + j, Fr::zero());
-        tk_store(rx + j, Fr::canon(tk_load(p + j)));
-        return;
+    fr_t run = Fr::zero();
+    for (uint32_t sgm = S; sgm-- > 0;) {
+        tk_store(carry + (uint64_t)sgm * ys + j, run);
+        run = Fr::add(tk_load(H + (uint64_t)sgm * ys + j), Fr::mul(run, xLm));
     }
-    fr_t b = Fr::canon(tk_load(p + (uint64_t)(xs - 1) * ys + j));
-    tk_store(qx + (uint64_t)(xs - 1) * ys + j, Fr::zero());
-    tk_store(qx + (uint64_t)(xs - 2) * ys + j, b);
-    for (uint32_t i = xs - 2; i >= 1; i--) {
-        b = Fr::add(Fr::canon(tk_load(p + (uint64_t)i * ys + j)), Fr::mul(b, xm));
-        tk_store(qx + (uint64_t)(i - 1) * ys + j, b);
+}
+__global__ __launch_bounds__(256) void k_ruffini_apply(const fr_t *__restrict__ p, const fr_t *__restrict__ carry, uint32_t xs, uint32_t ys,
+                                                      fr_t xm, uint32_t L, fr_t *__restrict__ qx, fr_t *__restrict__ rx) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, sgm = blockIdx.y;
+    if (j >= ys) return;
+    uint32_t lo = sgm * L, hi = lo + L < xs ? lo + L : xs;
+    fr_t b = tk_load(carry + (uint64_t)sgm * ys + j);
+    if (hi == xs) tk_store(qx + (uint64_t)(xs - 1) * ys + j, Fr::zero());  // top quotient row
+    for (uint32_t k = hi; k-- > lo;) {
+        b = Fr::add(Fr::canon(tk_load(p + (uint64_t)k * ys + j)), Fr::mul(b, xm));
+        if (k >= 1) tk_store(qx + (uint64_t)(k - 1) * ys + j, b);
+        else tk_store(rx + j, b);
     }
-    tk_store(rx + j, Fr::add(Fr::canon(tk_load(p + j)), Fr::mul(b, xm)));
 }
 // single lane: univariate division of r (length n) by (Y - y); out: q (length n, top = 0), rem
 __global__ void k_ruffini_y(const fr_t *__restrict__ r, uint32_t n, fr_t ym, fr_t *__restrict__ q, fr_t *__restrict__ rem) {
@@ -376,8 +395,23 @@ TK_API tkmk_error tkmk_poly_div_by_ruffini(const tkmk_fr *p_dev, uint32_t x_size
     tk_scratch rx, rem;
     TK_TRY(rx.alloc((size_t)y_size * sizeof(fr_t), s));
     TK_TRY(rem.alloc(sizeof(fr_t), s));
-    hipLaunchKernelGGL(k_ruffini_x, tk_div_up(y_size, 256), 256, 0, s, (const fr_t *)p_dev, x_size, y_size, Fr::to_mont(fr_in(x)),
-                       (fr_t *)q_x_dev, rx.as<fr_t>());
+    const fr_t xm = Fr::to_mont(fr_in(x));
+    if (x_size < 2) {
+        // _div_uni_coeffs_by_ruffini with len < 2: quotient (0), remainder = the coefficient
+        TK_HIP(hipMemsetAsync(q_x_dev, 0, (size_t)y_size * sizeof(fr_t), s));
+        TK_HIP(hipMemcpyAsync(rx.p, p_dev, (size_t)y_size * sizeof(fr_t), hipMemcpyDeviceToDevice, s));
+    } else {
+        const uint32_t L = x_size >= 128 ? 64 : x_size, S = (x_size + L - 1) / L;
+        tk_scratch H, carry;
+        TK_TRY(H.alloc((size_t)S * y_size * sizeof(fr_t), s));
+        TK_TRY(carry.alloc((size_t)S * y_size * sizeof(fr_t), s));
+        dim3 grid(tk_div_up(y_size, 256), S);
+        hipLaunchKernelGGL(k_ruffini_local, grid, 256, 0, s, (const fr_t *)p_dev, x_size, y_size, xm, L, H.as<fr_t>());
+        hipLaunchKernelGGL(k_ruffini_carry, tk_div_up(y_size, 256), 256, 0, s, (const fr_t *)H.p, S, y_size, Fr::pow_u64(xm, L),
+                           carry.as<fr_t>());
+        hipLaunchKernelGGL(k_ruffini_apply, grid, 256, 0, s, (const fr_t *)p_dev, (const fr_t *)carry.p, x_size, y_size, xm, L,
+                           (fr_t *)q_x_dev, rx.as<fr_t>());
+    }
     hipLaunchKernelGGL(k_ruffini_y, 1, 64, 0, s, (const fr_t *)rx.p, y_size, Fr::to_mont(fr_in(y)), (fr_t *)q_y_dev, rem.as<fr_t>());
     TK_HIP(hipGetLastError());
     TK_HIP(hipMemcpyAsync(r_host, rem.p, sizeof(fr_t), hipMemcpyDeviceToHost, s));
