@@ -175,3 +175,52 @@ extern "C" int hc_ntt(const uint8_t *in, uint32_t logn, uint64_t batch, int colu
     for (uint64_t i = 0; i < total; i++) store<Fr>(out + 32 * i, (*src)[i]);
     return passes;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// unsaturated (radix 2^29) field / curve path of the MSM accumulate loop (csrc/ffu.h, ec_u.h), on the host with
+// every bound assertion enabled.
+// ---------------------------------------------------------------------------------------------------
+#include "ec_u.h"
+
+// plain Fq values in / out; op 0 mul, 1 sqr, 2 add, 3 sub<2> (a - b mod p), 4 pack(unpack) round trip
+extern "C" void hc_fqu_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) {
+    fq_t ksat;
+    for (int i = 0; i < 12; i++) ksat.l[i] = bls12_381_fq_params::KSAT[i];
+    for (size_t i = 0; i < n; i++) {
+        fq_t x, y;
+        load<Fq>(x, a + 48 * i);
+        load<Fq>(y, b + 48 * i);
+        // plain -> x 2^(29L) mod p (what k_convert_bases does) -> strict limbs
+        fqu_t ux = Fqu::from_packed(Fq::mul(x, ksat)), uy = Fqu::from_packed(Fq::mul(y, ksat));
+        fqu_t r;
+        switch (op) {
+            case 0: r = Fqu::mul(ux, uy); break;
+            case 1: r = Fqu::sqr(ux); break;
+            case 2: r = Fqu::add(ux, uy); break;
+            case 3: r = Fqu::sub<2>(ux, uy); break;
+            default: r = ux;
+        }
+        // back: x 2^(29L) (redundant) -> saturated Montgomery -> plain
+        store<Fq>(o + 48 * i, Fq::from_mont(Fqu::to_sat_mont(r)));
+    }
+}
+// chain: acc = P0; acc += P_i (signed) for every following point, through the unsaturated mixed add; result affine plain
+extern "C" void hc_g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, uint8_t *out) {
+    fq_t ksat;
+    for (int i = 0; i < 12; i++) ksat.l[i] = bls12_381_fq_params::KSAT[i];
+    G1U::X acc = G1U::inf();
+    for (size_t i = 0; i < n; i++) {
+        g1_affine_t rec;
+        load<Fq>(rec.x, pts + 96 * i);
+        load<Fq>(rec.y, pts + 96 * i + 48);
+        if (!(Fq::is_zero(rec.x) && Fq::is_zero(rec.y))) {
+            rec.x = Fq::mul(rec.x, ksat);
+            rec.y = Fq::mul(rec.y, ksat);
+        }
+        G1U::A q;
+        if (!G1U::load_affine(q, rec)) continue;
+        if (negate[i]) q = G1U::neg(q);
+        acc = G1U::add_mixed(acc, q);
+    }
+    store_aff(out, G1::to_affine(G1U::to_sat(acc)));
+}

@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "tokamak-zk-evm_amd", "csrc")
 def hc():
     src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
     so = os.path.join(HERE, "hostcheck", "libhostcheck.so")
-    deps = [src] + [os.path.join(CSRC, f) for f in ("ff.h", "ec.h", "field_params.h")]
+    deps = [src] + [os.path.join(CSRC, f) for f in ("ff.h", "ec.h", "field_params.h", "ntt_plan.h", "ffu.h", "ec_u.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         if shutil.which("hipcc") is None:
             pytest.skip("hipcc not available")
@@ -101,3 +101,46 @@ def test_ntt_pass_plan_emulation(hc, oracle, logn, batch, max_logR, log_tile):
                 got, passes = _hc_ntt(hc, x, logn, batch, columns, inverse, coset, max_logR, log_tile, logn + 2)
                 assert passes == max(1, -(-logn // max_logR))
                 assert (got == want).all(), (columns, inverse, coset is not None)
+
+
+def test_unsaturated_field_matches_oracle(hc, oracle):
+    """csrc/ffu.h (29-bit limbs, carry-free products) with all bound assertions on: mul / sqr / add / sub vs the oracle"""
+    rnd = random.Random(17)
+    mod = oracle.P_MOD
+    n = 400
+    a, b = _edge(mod, n, rnd), _edge(mod, n, rnd)
+    rnd.shuffle(b)
+    a += [mod - 1] * 4 + [(1 << 380) - 1, (1 << 377) - 1]
+    b += [mod - 1, 1, 0, mod - 2, (1 << 380) - 1, (1 << 29) - 1]
+    n = len(a)
+    A, B = oracle.to_bytes(a, 48), oracle.to_bytes(b, 48)
+    out = np.empty_like(A)
+    for op, want in ((0, oracle.fq_mul(A, B)), (1, oracle.fq_mul(A, A)), (2, oracle.fq_add(A, B)), (3, oracle.fq_sub(A, B)), (4, A)):
+        hc.hc_fqu_op(op, _p(A), _p(B), _p(out), ctypes.c_size_t(n))
+        assert (out == want).all(), "op %d" % op
+
+
+def test_unsaturated_mixed_add_chain_matches_oracle(hc, oracle):
+    """csrc/ec_u.h: a bucket-like accumulation chain incl. infinity records, a repeated point (doubling branch), P then -P
+    (cancels to infinity, then continues) — same result as the oracle's group law"""
+    pts = oracle.g1_random_bases(77, 40)
+    P = [pts[96 * i:96 * (i + 1)].copy() for i in range(40)]
+    seq = P[:10] + [np.zeros(96, np.uint8)] + [P[10], P[10]] + P[11:20] + [P[3]] + P[20:]
+    neg = [0] * len(seq)
+    neg[4] = 1
+    neg[15] = 1
+    # make the running sum hit infinity: append the negation of everything so far, then continue
+    acc = np.zeros(96, np.uint8)
+    for q, s in zip(seq, neg):
+        acc = oracle.g1_add(acc, oracle.g1_neg(q) if s else q)
+    seq2 = seq + [acc] + [P[0], P[0], P[1]]
+    neg2 = neg + [1] + [0, 1, 0]
+    want = np.zeros(96, np.uint8)
+    for q, s in zip(seq2, neg2):
+        want = oracle.g1_add(want, oracle.g1_neg(q) if s else q)
+    buf = np.concatenate(seq2)
+    flags = np.array(neg2, np.uint8)
+    out = np.empty(96, np.uint8)
+    hc.hc_g1u_accumulate(_p(buf), _p(flags), ctypes.c_size_t(len(seq2)), _p(out))
+    assert (out == want).all()
+    assert (want == P[1]).all()

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.h"
+#include "ec_u.h"
 
 // --- curve arithmetic flavour for the long-running kernels: keep the 12-limb Montgomery product out of
 // line so the accumulate loop body stays small (10 inlined products are ~50 KB of code) ---
@@ -46,14 +47,19 @@ struct msm_plan_t {
     uint32_t bits;
 };
 
+// bases -> the form the accumulate loop consumes: {x 2^406 mod p, y 2^406 mod p} (canonical, 32-bit limbs; the
+// Montgomery radix of the unsaturated representation, ffu.h); (0,0) stays (0,0) = infinity
 __global__ __launch_bounds__(256) void k_convert_bases(const g1_affine_t *__restrict__ in, g1_affine_t *__restrict__ out,
-                                                      uint64_t n) {
+                                                      uint64_t n, int in_montgomery) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     g1_affine_t p = tk_load(in + i);
     if (!G1::is_inf(p)) {
-        p.x = Fq::to_mont(Fq::canon(p.x));
-        p.y = Fq::to_mont(Fq::canon(p.y));
+        fq_t k;
+#pragma unroll
+        for (int j = 0; j < 12; j++) k.l[j] = in_montgomery ? bls12_381_fq_params::KSATM[j] : bls12_381_fq_params::KSAT[j];
+        p.x = Fq::mul(Fq::canon(p.x), k);
+        p.y = Fq::mul(Fq::canon(p.y), k);
     }
     tk_store(out + i, p);
 }
@@ -221,12 +227,14 @@ __global__ __launch_bounds__(256) void k_accumulate_chunks(const g1_affine_t *__
     uint32_t bend = bs[b + 1];           // end of the current bucket (> lo by construction of bucket_of,
     while (bend <= lo) bend = bs[++b + 1];  //  except across empty buckets sharing the same offset)
     uint32_t seg_lo = lo;
-    g1_xyzz_t acc = G1::inf();
+    G1U::X acc = G1U::inf();
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t rec = s[k];
-        g1_affine_t p = tk_load(bases + (rec & 0x7fffffffu));
-        if (rec & 0x80000000u) p.y = Fq::neg(p.y);
-        acc = G1::add_mixed(acc, p);
+        G1U::A q;
+        if (G1U::load_affine(q, tk_load(bases + (rec & 0x7fffffffu)))) {
+            if (rec & 0x80000000u) q = G1U::neg(q);
+            acc = G1U::add_mixed(acc, q);
+        }
         if (k + 1 == bend || k + 1 == hi) {  // the segment [seg_lo, k+1) of bucket b ends here
             uint32_t bbeg = bs[b];
             bool whole = seg_lo == bbeg && k + 1 == bend;
@@ -234,8 +242,8 @@ __global__ __launch_bounds__(256) void k_accumulate_chunks(const g1_affine_t *__
             if (whole) dst = buckets + (uint64_t)w * pl.B + b;
             else if (seg_lo == lo) dst = frag_head + (uint64_t)w * chunks_per_window + t;
             else dst = frag_tail + (uint64_t)w * chunks_per_window + t;
-            tk_store(dst, acc);
-            acc = G1::inf();
+            tk_store(dst, G1U::to_sat(acc));
+            acc = G1U::inf();
             seg_lo = k + 1;
             if (k + 1 < hi) {
                 do { b++; bend = bs[b + 1]; } while (bend <= k + 1);
@@ -442,6 +450,16 @@ static tkmk_error msm_debug_check(const msm_plan_t &pl, const fr_t *scalars, con
     std::vector<g1_xyzz_t> buckets((size_t)pl.W * pl.B);
     TK_HIP(hipMemcpy(sc.data(), scalars, sc.size() * sizeof(fr_t), hipMemcpyDeviceToHost));
     TK_HIP(hipMemcpy(bs.data(), bases, bs.size() * sizeof(g1_affine_t), hipMemcpyDeviceToHost));
+    {   // device bases are {x 2^406, y 2^406} (packed); the host re-derivation works in saturated Montgomery form
+        fq_t rp;
+        for (int j = 0; j < 12; j++) rp.l[j] = bls12_381_fq_params::KSATM[j];  // 2^406 mod p (plain)
+        fq_t rinv = Fq::inv(Fq::to_mont(rp));
+        for (auto &b : bs)
+            if (!G1::is_inf(b)) {
+                b.x = Fq::mul(Fq::to_mont(b.x), rinv);
+                b.y = Fq::mul(Fq::to_mont(b.y), rinv);
+            }
+    }
     TK_HIP(hipMemcpy(dig.data(), d_dig, dig.size() * 4, hipMemcpyDeviceToHost));
     TK_HIP(hipMemcpy(sorted.data(), d_sorted, sorted.size() * 4, hipMemcpyDeviceToHost));
     TK_HIP(hipMemcpy(bstart.data(), d_bstart, bstart.size() * 4, hipMemcpyDeviceToHost));
@@ -630,18 +648,17 @@ TK_API tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *ba
             TK_HIP(hipStreamSynchronize(s));
             for (uint32_t b = 0; b < batch; b++) store_canonical(&host_res[b], r[b]);
         } else {
-            const g1_affine_t *bm = (const g1_affine_t *)P.dev;
             tk_scratch d_bm;
-            if (!cfg->are_points_montgomery_form) {
-                TK_TRY(d_bm.alloc(n_bases * 96, s));
+            TK_TRY(d_bm.alloc(n_bases * 96, s));
+            {
                 tk_prof prof(s);
                 hipLaunchKernelGGL(k_convert_bases, tk_div_up(n_bases, 256), 256, 0, s, (const g1_affine_t *)P.dev,
-                                   d_bm.as<g1_affine_t>(), (uint64_t)n_bases);
+                                   d_bm.as<g1_affine_t>(), (uint64_t)n_bases, cfg->are_points_montgomery_form ? 1 : 0);
                 prof.mark("msm.convert_bases");
                 prof.finish();
                 TK_HIP(hipGetLastError());
-                bm = d_bm.as<g1_affine_t>();
             }
+            const g1_affine_t *bm = d_bm.as<g1_affine_t>();
             for (uint32_t b = 0; b < batch; b++) {
                 g1_xyzz_t r;
                 TK_TRY(msm_one((const fr_t *)S.dev + (size_t)b * n, bm + (cfg->are_points_shared_in_batch ? 0 : (size_t)b * n), n,

@@ -114,6 +114,55 @@ def gen_linear(n, p):
     return L
 
 
+WU = 29  # limb width of the unsaturated (carry-free product) representation
+
+
+def limbs_u(v, n):
+    """29-bit digits; the top limb takes whatever is left"""
+    out = []
+    for i in range(n):
+        out.append(v & ((1 << WU) - 1) if i < n - 1 else v)
+        v >>= WU
+    assert out[-1] < (1 << 31)
+    return ", ".join("0x%08xu" % x for x in out)
+
+
+def sub_const(k, p, n):
+    """K*p written with limbs that dominate any strict operand: c_0 = d_0 + 2^29, c_i = d_i + 2^29 - 1, c_top = d_top - 1"""
+    v = k * p
+    d = []
+    for i in range(n):
+        d.append(v & ((1 << WU) - 1) if i < n - 1 else v)
+        v >>= WU
+    c = [d[0] + (1 << WU)] + [d[i] + (1 << WU) - 1 for i in range(1, n - 1)] + [d[n - 1] - 1]
+    assert sum(ci << (WU * i) for i, ci in enumerate(c)) == k * p and c[-1] > 0
+    return c
+
+
+def gen_unsat(name, p):
+    """constants of the radix-2^29 representation (csrc/ffu.h)"""
+    nsat = (p.bit_length() + 31) // 32
+    L = -(-(p.bit_length() + 4) // WU)          # >= 4 spare bits so that values up to 16p keep a small top limb
+    Ru = 1 << (WU * L)
+    Rs = 1 << (32 * nsat)
+    o = []
+    o.append("    // ---- unsaturated representation: %d limbs of %d bits, Montgomery radix 2^%d (csrc/ffu.h) ----" % (L, WU, WU * L))
+    o.append("    static constexpr int LU = %d;" % L)
+    o.append("    static constexpr uint32_t INVU = 0x%08xu;   // -p^-1 mod 2^29" % ((-pow(p, -1, 1 << WU)) % (1 << WU)))
+    o.append("    static constexpr uint32_t PINVU = 0x%08xu;  // p^-1 mod 2^29" % pow(p, -1, 1 << WU))
+    o.append("    static constexpr uint32_t MODU[%d] = {%s};" % (L, limbs_u(p, L)))
+    o.append("    static constexpr uint32_t ONEU[%d] = {%s};   // 2^%d mod p" % (L, limbs_u(Ru % p, L), WU * L))
+    o.append("    static constexpr uint32_t RSATU[%d] = {%s};  // 2^%d mod p: mulU(v, RSATU) turns x*2^%d into x*2^%d" % (L, limbs_u(Rs % p, L), 32 * nsat, WU * L, 32 * nsat))
+    o.append("    // saturated-side constants: mont_mul(x_plain, KSAT) = x*2^%d mod p;  mont_mul(x*2^%d, KSATM) = x*2^%d mod p" % (WU * L, 32 * nsat, WU * L))
+    o.append("    static constexpr uint32_t KSAT[%d] = {%s};" % (nsat, limbs((Ru * Rs) % p, nsat)))
+    o.append("    static constexpr uint32_t KSATM[%d] = {%s};" % (nsat, limbs(Ru % p, nsat)))
+    for k in (2, 4, 8, 16):
+        c = sub_const(k, p, L)
+        o.append("    static constexpr uint32_t SUB%d[%d] = {%s};  // %d*p, dominating limbs; top limb %d" % (k, L, ", ".join("0x%08xu" % x for x in c), k, c[-1]))
+    o.append("    static constexpr uint64_t TOP_PER_P_X1024 = %dull;  // floor(1024 * p / 2^%d): top-limb growth per multiple of p" % ((1024 * p) >> (WU * (L - 1)), WU * (L - 1)))
+    return o
+
+
 def main():
     out = ["// GENERATED by tools/gen_field_params.py — do not edit.", "#pragma once", "#include <stdint.h>", ""]
     for name, f in FIELDS.items():
@@ -136,6 +185,7 @@ def main():
             out.append("    static constexpr int TWO_ADICITY = %d;" % s)
             out.append("    // w_{2^%d} = %d^((p-1)/2^%d), plain form" % (s, f["qnr"], s))
             out.append("    static constexpr uint32_t ROOT[%d] = {%s};" % (n, limbs(w, n)))
+        out.extend(gen_unsat(name, p))
         out.append("#if defined(__HIP_DEVICE_COMPILE__)")
         out.append("    // r = a*b/2^(32N) in [0, 2p): product-scanning Montgomery product, 1 v_mad_u64_u32 + 1 v_addc_co_u32")
         out.append("    // per limb product, modulus limbs in SGPRs (see tools/gen_field_params.py:gen_mul)")
