@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--logn", type=int, default=24, help="log2 of points per GPU (default: BASELINE configs[1])")
     ap.add_argument("--cpu-sample-logn", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true", help="skip the secondary NTT measurements (BASELINE.json configs[2], _biNTT)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --dist-backend gloo)")
     args = ap.parse_args()
@@ -144,6 +145,10 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(tkmk, args.cpu_sample_logn)
+        if not args.no_ntt:
+            scalars.free()
+            bases.free()
+            out["ntt"] = _ntt_secondary(tkmk)
         out["result_x_lo"] = int.from_bytes(bytes(result[:8]), "little")
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -168,6 +173,34 @@ def _traffic_from_profiles(logn):
         return t.get(key, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def _ntt_secondary(tkmk):
+    """Secondary, outside the timed region: BASELINE.json configs[2] (256 independent 2^20-point NTTs, resident) and the
+    reference's largest production _biNTT (16384 x 512).  Algorithmic bytes = 64 B per element."""
+    res = {}
+    try:
+        tkmk.init_ntt_domain_for_size(1 << 23)
+        for name, n, batch, bi in (("rows_256x2^20", 1 << 20, 256, None), ("bintt_16384x512", None, None, (16384, 512))):
+            elems = n * batch if bi is None else bi[0] * bi[1]
+            a = tkmk.fr_random_device(SEED + 5, elems)
+            o = tkmk.DeviceBuffer(32 * elems)
+            fn = (lambda: tkmk.ntt(a, n, batch=batch, out=o)) if bi is None else (lambda: tkmk.bintt(a, bi[0], bi[1], out=o))
+            fn()
+            tkmk.synchronize()
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            tkmk.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            res[name] = {"ms": dt * 1e3, "elements_per_s": elems / dt, "algorithmic_GBps": 64 * elems / dt / 1e9,
+                         "hbm_frac": 64 * elems / dt / 1e9 / HBM_PEAK_GBS}
+            a.free()
+            o.free()
+    except Exception as e:  # secondary figure: never fail the headline line
+        res["error"] = str(e)
+    return res
 
 
 def _cpu_baseline(tkmk, sample_logn):

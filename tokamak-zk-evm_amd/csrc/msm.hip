@@ -25,15 +25,11 @@
 #include "common.h"
 #include "ec_u.h"
 
-// --- curve arithmetic flavour for the long-running kernels: keep the 12-limb Montgomery product out of
-// line so the accumulate loop body stays small (10 inlined products are ~50 KB of code) ---
-struct FqK : Fq {
-    static __device__ __noinline__ fq_t mul(fq_t a, fq_t b) { return Fq::mul(a, b); }
-    static __device__ __forceinline__ fq_t sqr(const fq_t &a) { return mul(a, a); }
-};
-using G1K = ec<FqK>;
-using g1k_xyzz = G1K::X;
-using g1k_aff = G1K::A;
+// curve arithmetic of the small latency-bound kernels (combine / reduce / size-1): saturated ec.h, fully inlined
+using G1K = G1;
+using FqK = Fq;
+using g1k_xyzz = g1_xyzz_t;
+using g1k_aff = g1_affine_t;
 
 static_assert(sizeof(g1_affine_t) == 96 && sizeof(g1_xyzz_t) == 192, "layout");
 
@@ -533,6 +529,7 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
     pl.W = bits / pl.c + 1;
     pl.B = 1u << (pl.c - 1);
     uint32_t want = (512 + pl.W - 1) / pl.W;
+    if (getenv("TKMK_MSM_CHUNKS")) want = (uint32_t)atoi(getenv("TKMK_MSM_CHUNKS"));
     uint32_t maxc = (n + 8191) / 8192;
     pl.chunks = want < maxc ? want : maxc;
     if (pl.chunks < 1) pl.chunks = 1;
