@@ -149,3 +149,12 @@ def test_msm_skewed_witness_like_scalars(gpu, oracle):
     s2 = oracle.to_bytes(vals, 32)
     assert (_msm_affine(gpu, s2, gpu.DeviceBuffer.from_host(ph[:96 * len(vals)].copy()), c=4)
             == oracle.g1_msm(s2, ph[:96 * len(vals)].copy())).all()
+
+
+def test_msm_2_20_vs_oracle(gpu, oracle):
+    # a production-size commit (4096 x 256 coefficients) against the oracle's Pippenger on the host cores
+    n = 1 << 20
+    s = gpu.fr_random_device(0x746F6B616D616B03, n)
+    h = gpu.fr_random_device(0x746F6B616D616B04, n)
+    p = gpu.g1_batch_scalar_mul_device(h, oracle.g1_generator(), n)
+    assert (_msm_affine(gpu, s, p) == oracle.g1_msm(s.to_host(), p.to_host())).all()

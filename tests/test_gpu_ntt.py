@@ -99,3 +99,26 @@ def test_ntt_errors(dom, oracle):
         dom.ntt(x[:32 * 3], 3)               # not a power of two
     with pytest.raises(dom.TkmkError):
         dom.ntt(np.zeros(32 << 24, np.uint8), 1 << 24)   # larger than the domain (reference panics: mod.rs:1437-1445)
+
+
+def test_full_domain_sizes(dom, oracle):
+    """largest shapes the production domain allows (2^23 elements): the p_comb domain 16384 x 512 and one 2^23-point
+    vector — round trips, and linearity NTT(a + b) == NTT(a) + NTT(b)"""
+    xs, ys = 16384, 512
+    a, b = dom.fr_random_device(71, xs * ys), dom.fr_random_device(72, xs * ys)
+    ea, eb = dom.bintt(a, xs, ys), dom.bintt(b, xs, ys)
+    eab = dom.bintt(dom.vec_add(a, b), xs, ys)
+    assert (dom.vec_add(ea, eb).to_host() == eab.to_host()).all()
+    assert (dom.bintt(ea, xs, ys, inverse=True).to_host() == a.to_host()).all()
+    n = 1 << 23
+    ev = dom.ntt(a, n)
+    assert (dom.ntt(ev, n, inverse=True).to_host() == a.to_host()).all()
+    # spot-check 2^23-point outputs against the definition: X[k] = sum_j x[j] w^{jk} for a sparse x
+    x = np.zeros(32 * n, np.uint8)
+    x[32 * 1] = 1          # x = delta_1  ->  X[k] = w^k
+    x[32 * 5 + 0] = 2      # + 2 delta_5 ->  X[k] = w^k + 2 w^{5k}
+    X = dom.ntt(x, n)
+    w = oracle.to_ints(oracle.root_of_unity(n), 32)[0]
+    for k in (0, 1, 12345, n - 1):
+        want = (pow(w, k, oracle.R_MOD) + 2 * pow(w, 5 * k, oracle.R_MOD)) % oracle.R_MOD
+        assert oracle.to_ints(X[32 * k:32 * k + 32].copy(), 32)[0] == want

@@ -97,17 +97,22 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(ntt_pass_t p, const fr
     }
     __syncthreads();
 
-    // radix-2 DIT stages on bit-reversed rows; l is the fastest thread index so a 16-lane LDS group
-    // touches consecutive 16-byte slots
+    // radix-2 DIT stages on bit-reversed rows; l is the fastest thread index so a 16-lane LDS group touches
+    // consecutive 16-byte slots.  In the early stages (many groups, few twiddles) the group index runs faster than the
+    // twiddle index, so a whole wave shares one twiddle and the w = 1 butterflies (pos == 0: 1/2 of stage 1, 1/4 of
+    // stage 2, ...) skip their product through a wave-uniform branch: ~0.5 of the ~3.5 products per element per pass.
     for (uint32_t s = 0; s < logR; s++) {
         const uint32_t h = 1u << s;
+        const uint32_t lg = logR - 1 - s;              // log2(number of butterfly groups)
+        const bool grp_fast = logT + lg >= 6;          // 64 consecutive lanes then share pos
         for (uint32_t q = tid; q < (NTT_TILE >> 1); q += NTT_THREADS) {
             uint32_t l = q & (T - 1), qq = q >> logT;
-            uint32_t pos = qq & (h - 1), grp = qq >> s;
+            uint32_t pos = grp_fast ? qq >> lg : qq & (h - 1);
+            uint32_t grp = grp_fast ? qq & ((1u << lg) - 1) : qq >> s;
             uint32_t r0 = (grp << (s + 1)) + pos, r1 = r0 + h;
             uint32_t s0 = ntt_slot(logT, l, r0), s1 = ntt_slot(logT, l, r1);
             fr_t a = lds_elem::get(lo, hi, s0), b = lds_elem::get(lo, hi, s1);
-            if (s) b = Fr::mul(b, twl[pos << (logR - 1 - s)]);
+            if (grp_fast ? pos != 0 : s != 0) b = Fr::mul(b, twl[pos << lg]);
             lds_elem::put(lo, hi, s0, Fr::add(a, b));
             lds_elem::put(lo, hi, s1, Fr::sub(a, b));
         }
