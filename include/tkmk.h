@@ -204,6 +204,10 @@ tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, uint32_t
  * --------------------------------------------------------------------------------------------- */
 /* out[i] = splitmix64(seed) stream element (first + i), reduced mod r; device pointer */
 tkmk_error tkmk_fr_random_device(uint64_t seed, uint64_t first, uint64_t n, tkmk_fr *out_dev, tkmk_stream s);
+/* dst[i] = src[idx[i]] for rows of row_bytes (multiple of 16; 96 = one G1 affine point): device-side gather of the
+ * bases of the binding commitments (libs/src/group_structures/mod.rs:127-300 builds these lists on the host) */
+tkmk_error tkmk_gather_rows_device(const void *src_dev, uint32_t row_bytes, const uint32_t *idx_dev, uint64_t n, void *dst_dev,
+                                   tkmk_stream s);
 /* out[i] = [scalars[i]] base  (affine results); all pointers device except `base` (host) */
 tkmk_error tkmk_g1_batch_scalar_mul_device(const tkmk_fr *scalars_dev, const tkmk_g1_affine *base_host,
                                            uint64_t n, tkmk_g1_affine *out_dev, tkmk_stream s);

@@ -572,14 +572,53 @@ static void g1j_add(g1j_t *o, const g1j_t *p, const g1j_t *q) {
     fq_mul(&r.z, &t, &h);
     *o = r;
 }
+/* mixed addition p + (+-q), q affine: madd-2007-bl (7M + 4S); degenerate cases through the general adder */
 static void g1j_add_affine(g1j_t *o, const g1j_t *p, const g1a_t *q, int negate) {
     if (q->inf) { *o = *p; return; }
-    g1j_t qq;
-    qq.x = q->x;
-    qq.y = q->y;
-    if (negate) fq_neg(&qq.y, &qq.y);
-    qq.z = fq_R1;
-    g1j_add(o, p, &qq);
+    fq_t qy = q->y;
+    if (negate) fq_neg(&qy, &qy);
+    if (fq_is_zero(&p->z)) {
+        o->x = q->x;
+        o->y = qy;
+        o->z = fq_R1;
+        return;
+    }
+    fq_t z1z1, u2, s2, h, hh, i, j, rr, v, t;
+    fq_sqr(&z1z1, &p->z);
+    fq_mul(&u2, &q->x, &z1z1);
+    fq_mul(&s2, &qy, &p->z);
+    fq_mul(&s2, &s2, &z1z1);
+    if (fq_eq(&u2, &p->x)) {
+        g1j_t qq;
+        qq.x = q->x;
+        qq.y = qy;
+        qq.z = fq_R1;
+        g1j_add(o, p, &qq); /* doubling or infinity */
+        return;
+    }
+    fq_sub(&h, &u2, &p->x);
+    fq_sqr(&hh, &h);
+    fq_add(&i, &hh, &hh);
+    fq_add(&i, &i, &i);
+    fq_mul(&j, &h, &i);
+    fq_sub(&rr, &s2, &p->y);
+    fq_add(&rr, &rr, &rr);
+    fq_mul(&v, &p->x, &i);
+    g1j_t r;
+    fq_sqr(&r.x, &rr);
+    fq_sub(&r.x, &r.x, &j);
+    fq_sub(&r.x, &r.x, &v);
+    fq_sub(&r.x, &r.x, &v);
+    fq_sub(&t, &v, &r.x);
+    fq_mul(&t, &t, &rr);
+    fq_mul(&v, &p->y, &j);
+    fq_add(&v, &v, &v);
+    fq_sub(&r.y, &t, &v);
+    fq_add(&t, &p->z, &h);
+    fq_sqr(&t, &t);
+    fq_sub(&t, &t, &z1z1);
+    fq_sub(&r.z, &t, &hh);
+    *o = r;
 }
 /* [s]P, s plain 4 limbs, MSB-first double-and-add */
 static void g1j_scalar_mul(g1j_t *o, const u64 *s, const g1j_t *p) {
@@ -685,7 +724,9 @@ void tko_g1_msm_naive(const uint8_t *s, const uint8_t *p, size_t n, uint8_t *out
 }
 
 /* Pippenger bucket method (the published algorithm ICICLE's CPU/CUDA msm backends implement):
- * unsigned c-bit windows, per-window buckets, running-sum reduction, Horner over windows. */
+ * unsigned c-bit windows, per-window buckets, running-sum reduction, Horner over windows.
+ * Parallel over (window, slice of the points): every task owns a private bucket array; slice results of a window
+ * are added before the Horner step. */
 void tko_g1_msm(const uint8_t *s, const uint8_t *p, size_t n, int threads, uint8_t *out96) {
     tko_init();
     if (n == 0) { memset(out96, 0, 96); return; }
@@ -704,14 +745,21 @@ void tko_g1_msm(const uint8_t *s, const uint8_t *p, size_t n, int threads, uint8
         g1a_load(&pts[i], p + 96 * i);
         load_scalar_plain(sc + 4 * i, s + 32 * i);
     }
-    g1j_t *wsum = (g1j_t *)malloc(sizeof(g1j_t) * nwin);
+    /* slices: enough tasks for all threads, but at least ~2^c points per task so bucket set-up stays minor */
+    int slices = (threads + nwin - 1) / nwin;
+    while (slices > 1 && n / (size_t)slices < ((size_t)1 << c)) slices--;
+    if (slices < 1) slices = 1;
+    int ntask = nwin * slices;
+    g1j_t *tsum = (g1j_t *)malloc(sizeof(g1j_t) * ntask);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (int w = 0; w < nwin; w++) {
+    for (int task = 0; task < ntask; task++) {
+        int w = task / slices, sl = task % slices;
+        size_t i0 = n * (size_t)sl / slices, i1 = n * (size_t)(sl + 1) / slices;
         size_t nb = ((size_t)1 << c) - 1;
         g1j_t *bk = (g1j_t *)malloc(sizeof(g1j_t) * nb);
         for (size_t b = 0; b < nb; b++) g1j_set_inf(&bk[b]);
         int lo = w * c;
-        for (size_t i = 0; i < n; i++) {
+        for (size_t i = i0; i < i1; i++) {
             const u64 *k = sc + 4 * i;
             int li = lo >> 6, sh = lo & 63;
             u64 d = k[li] >> sh;
@@ -726,19 +774,19 @@ void tko_g1_msm(const uint8_t *s, const uint8_t *p, size_t n, int threads, uint8
             g1j_add(&run, &run, &bk[b]);
             g1j_add(&tot, &tot, &run);
         }
-        wsum[w] = tot;
+        tsum[task] = tot;
         free(bk);
     }
     g1j_t acc;
     g1j_set_inf(&acc);
     for (int w = nwin - 1; w >= 0; w--) {
         for (int k = 0; k < c; k++) g1j_double(&acc, &acc);
-        g1j_add(&acc, &acc, &wsum[w]);
+        for (int sl = 0; sl < slices; sl++) g1j_add(&acc, &acc, &tsum[w * slices + sl]);
     }
     g1a_t r;
     g1j_to_affine(&r, &acc);
     g1a_store(out96, &r);
-    free(wsum);
+    free(tsum);
     free(sc);
     free(pts);
 }

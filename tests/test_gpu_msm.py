@@ -158,3 +158,21 @@ def test_msm_2_20_vs_oracle(gpu, oracle):
     h = gpu.fr_random_device(0x746F6B616D616B04, n)
     p = gpu.g1_batch_scalar_mul_device(h, oracle.g1_generator(), n)
     assert (_msm_affine(gpu, s, p) == oracle.g1_msm(s.to_host(), p.to_host())).all()
+
+
+def test_gathered_bases_msm(gpu, oracle):
+    """binding commitments (encode_O_* -> msm_g1_bases, libs/src/group_structures/mod.rs:127-300): bases picked out of a
+    resident CRS table by an index list, gathered on the device, then one MSM"""
+    import random
+    rnd = random.Random(3)
+    table_n, n = 5000, 1500
+    h = gpu.fr_random_device(81, table_n)
+    table = gpu.g1_batch_scalar_mul_device(h, oracle.g1_generator(), table_n)
+    idx = np.array([rnd.randrange(table_n) for _ in range(n)], np.uint32)
+    idx[10] = idx[11]                                   # the same wire can appear twice
+    bases = gpu.gather_rows_device(table, 96, idx)
+    th = table.to_host().reshape(table_n, 96)
+    want_bases = th[idx].reshape(-1).copy()
+    assert (bases.to_host() == want_bases).all()
+    s = oracle.to_bytes([rnd.choice([0, 1, 1, 1, rnd.randrange(1 << 128), rnd.randrange(oracle.R_MOD)]) for _ in range(n)], 32)
+    assert (_msm_affine(gpu, s, bases) == oracle.g1_msm(s, want_bases)).all()

@@ -82,3 +82,26 @@ TK_API tkmk_error tkmk_g1_batch_scalar_mul_device(const tkmk_fr *scalars_dev, co
     TK_HIP(hipStreamSynchronize(tk_stream(s)));
     return TKMK_SUCCESS;
 }
+
+// dst[i] = src[idx[i]] for rows of row_bytes (multiple of 16): the device-side gather behind the binding
+// commitments, which the reference builds on the host by walking nested CRS tables
+// (packages/backend/libs/src/group_structures/mod.rs:145-300 encode_*_common -> msm_g1_bases :127-143)
+__global__ __launch_bounds__(256) void k_gather_rows(const uint4 *__restrict__ src, const uint32_t *__restrict__ idx, uint64_t n,
+                                                    uint32_t vec_per_row, uint4 *__restrict__ dst) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * vec_per_row) return;
+    uint64_t i = e / vec_per_row;
+    uint32_t k = (uint32_t)(e - i * vec_per_row);
+    dst[e] = src[(uint64_t)idx[i] * vec_per_row + k];
+}
+TK_API tkmk_error tkmk_gather_rows_device(const void *src_dev, uint32_t row_bytes, const uint32_t *idx_dev, uint64_t n, void *dst_dev,
+                                          tkmk_stream s) {
+    if ((!src_dev || !idx_dev || !dst_dev) && n) return TKMK_ERR_INVALID_POINTER;
+    if (row_bytes == 0 || row_bytes % 16) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    if (n == 0) return TKMK_SUCCESS;
+    hipLaunchKernelGGL(k_gather_rows, tk_div_up(n * (row_bytes / 16), 256), 256, 0, tk_stream(s), (const uint4 *)src_dev, idx_dev, n,
+                       row_bytes / 16, (uint4 *)dst_dev);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
