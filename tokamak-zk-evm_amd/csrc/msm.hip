@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void k_digits(const fr_t *__restrict__ scalars
 }
 
 // grid (chunks, W); dynamic LDS = B * 4 bytes
-__global__ __launch_bounds__(1024) void k_hist(const uint32_t *__restrict__ dig, uint32_t *__restrict__ counts, msm_plan_t pl) {
+__global__ __launch_bounds__(1024) void k_hist(const uint32_t *__restrict__ dig, uint32_t *__restrict__ counts, msm_plan_t pl,
+                                              uint32_t shift) {
     extern __shared__ uint32_t hist[];
     const uint32_t w = blockIdx.y, ch = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < pl.B; b += blockDim.x) hist[b] = 0;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(1024) void k_hist(const uint32_t *__restrict__ dig,
     const uint32_t *d = dig + (uint64_t)w * pl.n;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         uint32_t r = d[i] & 0x7fffffffu;
-        if (r) atomicAdd(&hist[r - 1], 1u);
+        if (r) atomicAdd(&hist[(r - 1) >> shift], 1u);
     }
     __syncthreads();
     // counts[w][b][chunk]
@@ -180,6 +181,144 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint32_t *__restrict__ d
             s[pos] = i | (rec & 0x80000000u);
         }
     }
+}
+
+// ---- two-pass (MSD) bucket sort with LDS-staged, coalesced scatters -----------------------------------------
+// The single-pass k_scatter issues one 4-byte store per item into 2^15 x chunks different 64-byte granules: 2^28
+// partial-line writes that the L2 / fabric retire at ~40 G/s chip-wide (6.6 ms at 2^24 points, 8x write
+// amplification).  Splitting the bucket index into a coarse part (<= 256 bins) and a fine part (128 bins) lets
+// each pass sort a 4096-item tile by bin inside LDS first, so that a wave writes runs of consecutive addresses.
+//   pass A: per (chunk, window): bins = bucket >> 7;  out: A_idx = point | sign, A_key = bucket (u16), grouped by coarse bin
+//   pass B: per (part, (window, coarse bin)): bins = bucket & 127;  out: the final bucket-sorted index list
+#define SC_TILE 4096
+#define SC_FINE_BITS 7
+#define SC_PARTS 4
+
+template <bool PASS_B>
+__global__ __launch_bounds__(1024) void k_scatter_staged(const uint32_t *__restrict__ in0, const uint16_t *__restrict__ in1,
+                                                        const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ cursors,
+                                                        uint32_t *__restrict__ out0, uint16_t *__restrict__ out1, uint32_t n,
+                                                        uint32_t bins, uint32_t coarse_bins, uint32_t chunk_len) {
+    __shared__ uint32_t hist[256], start[256], cur[256];
+    __shared__ uint32_t sv0[SC_TILE], sv1[SC_TILE];
+    const uint32_t tid = threadIdx.x, part = blockIdx.x, parts = gridDim.x, sgm = blockIdx.y;
+    const uint32_t w = PASS_B ? sgm / coarse_bins : sgm;
+    uint32_t lo, hi, base = 0;
+    if (PASS_B) {
+        const uint32_t cb = sgm - w * coarse_bins;
+        const uint32_t *cs = seg_start + (uint64_t)w * (coarse_bins + 1);
+        uint32_t s0 = cs[cb], s1 = cs[cb + 1];
+        uint32_t per = (s1 - s0 + parts - 1) / parts;
+        lo = s0 + part * per;
+        hi = lo + per < s1 ? lo + per : s1;
+        if (lo > s1) lo = s1;
+        base = s0;
+    } else {
+        lo = part * chunk_len;
+        hi = lo + chunk_len < n ? lo + chunk_len : n;
+        if (lo > n) lo = n;
+    }
+    in0 += (uint64_t)w * n;
+    if (PASS_B) in1 += (uint64_t)w * n;
+    out0 += (uint64_t)w * n;
+    if (!PASS_B) out1 += (uint64_t)w * n;
+    if (tid < bins) cur[tid] = cursors[((uint64_t)sgm * bins + tid) * parts + part] + base;
+    __syncthreads();
+    for (uint32_t tlo = lo; tlo < hi; tlo += SC_TILE) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        uint32_t v0[4], v1[4], rk[4];
+        bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t k = tlo + tid + 1024u * j;
+            ok[j] = k < hi;
+            v0[j] = v1[j] = rk[j] = 0;
+            if (ok[j]) {
+                if (PASS_B) {
+                    v0[j] = in0[k];
+                    v1[j] = in1[k];
+                } else {
+                    uint32_t rec = in0[k], r = rec & 0x7fffffffu;
+                    ok[j] = r != 0;
+                    v0[j] = k | (rec & 0x80000000u);
+                    v1[j] = r - 1;
+                }
+            }
+            if (ok[j]) rk[j] = atomicAdd(&hist[PASS_B ? (v1[j] & ((1u << SC_FINE_BITS) - 1)) : (v1[j] >> SC_FINE_BITS)], 1u);
+        }
+        __syncthreads();
+        // exclusive prefix of hist[] -> start[] (256 lanes, Hillis-Steele)
+        uint32_t mine = tid < 256 ? hist[tid] : 0;
+        if (tid < 256) start[tid] = mine;
+        __syncthreads();
+        for (uint32_t off = 1; off < 256; off <<= 1) {
+            uint32_t t = (tid < 256 && tid >= off) ? start[tid - off] : 0;
+            __syncthreads();
+            if (tid < 256) start[tid] += t;
+            __syncthreads();
+        }
+        const uint32_t total = start[255];
+        __syncthreads();
+        if (tid < 256) start[tid] -= mine;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (ok[j]) {
+                uint32_t b = PASS_B ? (v1[j] & ((1u << SC_FINE_BITS) - 1)) : (v1[j] >> SC_FINE_BITS);
+                uint32_t pos = start[b] + rk[j];
+                sv0[pos] = v0[j];
+                sv1[pos] = v1[j];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t k2 = tid + 1024u * j;
+            if (k2 < total) {
+                uint32_t a0 = sv0[k2], a1 = sv1[k2];
+                uint32_t b = PASS_B ? (a1 & ((1u << SC_FINE_BITS) - 1)) : (a1 >> SC_FINE_BITS);
+                uint32_t g = cur[b] + (k2 - start[b]);
+                out0[g] = a0;
+                if (!PASS_B) out1[g] = (uint16_t)a1;
+            }
+        }
+        __syncthreads();
+        if (tid < 256) cur[tid] += hist[tid];
+        __syncthreads();
+    }
+}
+
+// pass-B histogram: counts[(w * coarse_bins + cb)][fine][part]
+__global__ __launch_bounds__(1024) void k_hist_fine(const uint16_t *__restrict__ key, const uint32_t *__restrict__ seg_start,
+                                                   uint32_t *__restrict__ counts, uint32_t n, uint32_t coarse_bins) {
+    __shared__ uint32_t hist[1u << SC_FINE_BITS];
+    const uint32_t tid = threadIdx.x, part = blockIdx.x, parts = gridDim.x, sgm = blockIdx.y;
+    const uint32_t w = sgm / coarse_bins, cb = sgm - w * coarse_bins;
+    const uint32_t *cs = seg_start + (uint64_t)w * (coarse_bins + 1);
+    uint32_t s0 = cs[cb], s1 = cs[cb + 1];
+    uint32_t per = (s1 - s0 + parts - 1) / parts;
+    uint32_t lo = s0 + part * per, hi = lo + per < s1 ? lo + per : s1;
+    if (tid < (1u << SC_FINE_BITS)) hist[tid] = 0;
+    __syncthreads();
+    const uint16_t *k = key + (uint64_t)w * n;
+    for (uint32_t i = lo + tid; i < hi; i += 1024) atomicAdd(&hist[k[i] & ((1u << SC_FINE_BITS) - 1)], 1u);
+    __syncthreads();
+    if (tid < (1u << SC_FINE_BITS)) counts[((uint64_t)sgm * (1u << SC_FINE_BITS) + tid) * parts + part] = hist[tid];
+}
+
+// bstart[w][cb * 128 + fb] = coarse_start[w][cb] + fine_start[w * CB + cb][fb];  bstart[w][B] = total
+__global__ __launch_bounds__(256) void k_bstart_assemble(const uint32_t *__restrict__ coarse_start, const uint32_t *__restrict__ fine_start,
+                                                        uint32_t *__restrict__ bstart, uint32_t W, uint32_t B, uint32_t coarse_bins) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)W * (B + 1)) return;
+    uint32_t w = (uint32_t)(e / (B + 1)), b = (uint32_t)(e - (uint64_t)w * (B + 1));
+    const uint32_t *cs = coarse_start + (uint64_t)w * (coarse_bins + 1);
+    if (b == B) {
+        bstart[e] = cs[coarse_bins];
+        return;
+    }
+    uint32_t cb = b >> SC_FINE_BITS, fb = b & ((1u << SC_FINE_BITS) - 1);
+    bstart[e] = cs[cb] + fine_start[((uint64_t)w * coarse_bins + cb) * ((1u << SC_FINE_BITS) + 1) + fb];
 }
 
 // ---- bucket accumulation, balanced by construction -------------------------------------------------
@@ -555,20 +694,67 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
         TK_HIP(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_hist, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, d_counts.as<uint32_t>(), pl);
-    prof.mark("msm.hist");
-    const uint32_t groups = (pl.B + 1023) / 1024;
-    tk_scratch d_local, d_gtot;
-    TK_TRY(d_local.alloc((size_t)pl.W * pl.B * 4, s));
-    TK_TRY(d_gtot.alloc((size_t)pl.W * groups * 4, s));
-    hipLaunchKernelGGL(k_scan_local, dim3(groups, pl.W), 1024, 0, s, (const uint32_t *)d_counts.p, d_local.as<uint32_t>(),
-                       d_gtot.as<uint32_t>(), pl);
-    hipLaunchKernelGGL(k_scan_apply, dim3(groups, pl.W), 1024, 0, s, d_counts.as<uint32_t>(), (const uint32_t *)d_local.p,
-                       (const uint32_t *)d_gtot.p, d_bstart.as<uint32_t>(), pl);
-    prof.mark("msm.scan");
-    hipLaunchKernelGGL(k_scatter, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, (const uint32_t *)d_counts.p,
-                       d_sorted.as<uint32_t>(), pl);
-    prof.mark("msm.scatter");
+    static const bool force_one_pass = getenv("TKMK_MSM_ONE_PASS") != nullptr;
+    const bool two_pass = !force_one_pass && pl.c >= 13 && n >= (1u << 18);
+    if (!two_pass) {
+        hipLaunchKernelGGL(k_hist, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, d_counts.as<uint32_t>(), pl, 0u);
+        prof.mark("msm.hist");
+        const uint32_t groups = (pl.B + 1023) / 1024;
+        tk_scratch d_local, d_gtot;
+        TK_TRY(d_local.alloc((size_t)pl.W * pl.B * 4, s));
+        TK_TRY(d_gtot.alloc((size_t)pl.W * groups * 4, s));
+        hipLaunchKernelGGL(k_scan_local, dim3(groups, pl.W), 1024, 0, s, (const uint32_t *)d_counts.p, d_local.as<uint32_t>(),
+                           d_gtot.as<uint32_t>(), pl);
+        hipLaunchKernelGGL(k_scan_apply, dim3(groups, pl.W), 1024, 0, s, d_counts.as<uint32_t>(), (const uint32_t *)d_local.p,
+                           (const uint32_t *)d_gtot.p, d_bstart.as<uint32_t>(), pl);
+        prof.mark("msm.scan");
+        hipLaunchKernelGGL(k_scatter, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, (const uint32_t *)d_counts.p,
+                           d_sorted.as<uint32_t>(), pl);
+        prof.mark("msm.scatter");
+    } else {
+        const uint32_t FB = 1u << SC_FINE_BITS, CB = pl.B >> SC_FINE_BITS;
+        tk_scratch d_aidx, d_akey, d_cs, d_localA, d_gtotA, d_cntB, d_fs, d_localB, d_gtotB;
+        TK_TRY(d_aidx.alloc((size_t)pl.W * n * 4, s));
+        TK_TRY(d_akey.alloc((size_t)pl.W * n * 2, s));
+        TK_TRY(d_cs.alloc((size_t)pl.W * (CB + 1) * 4, s));
+        // ---- pass A: coarse bins ----
+        msm_plan_t pa = pl;
+        pa.B = CB;
+        hipLaunchKernelGGL(k_hist, dim3(pl.chunks, pl.W), 1024, (size_t)CB * 4, s, (const uint32_t *)d_dig.p, d_counts.as<uint32_t>(), pa,
+                           (uint32_t)SC_FINE_BITS);
+        prof.mark("msm.hist");
+        TK_TRY(d_localA.alloc((size_t)pl.W * CB * 4, s));
+        TK_TRY(d_gtotA.alloc((size_t)pl.W * 4, s));
+        hipLaunchKernelGGL(k_scan_local, dim3(1, pl.W), 1024, 0, s, (const uint32_t *)d_counts.p, d_localA.as<uint32_t>(),
+                           d_gtotA.as<uint32_t>(), pa);
+        hipLaunchKernelGGL(k_scan_apply, dim3(1, pl.W), 1024, 0, s, d_counts.as<uint32_t>(), (const uint32_t *)d_localA.p,
+                           (const uint32_t *)d_gtotA.p, d_cs.as<uint32_t>(), pa);
+        prof.mark("msm.scan");
+        hipLaunchKernelGGL(k_scatter_staged<false>, dim3(pl.chunks, pl.W), 1024, 0, s, (const uint32_t *)d_dig.p, (const uint16_t *)nullptr,
+                           (const uint32_t *)nullptr, (const uint32_t *)d_counts.p, d_aidx.as<uint32_t>(), d_akey.as<uint16_t>(), n, CB, CB,
+                           pl.chunk_len);
+        // ---- pass B: fine bins inside every (window, coarse bin) segment ----
+        const uint32_t segs_b = pl.W * CB;
+        TK_TRY(d_cntB.alloc((size_t)segs_b * FB * SC_PARTS * 4, s));
+        TK_TRY(d_fs.alloc((size_t)segs_b * (FB + 1) * 4, s));
+        TK_TRY(d_localB.alloc((size_t)segs_b * FB * 4, s));
+        TK_TRY(d_gtotB.alloc((size_t)segs_b * 4, s));
+        hipLaunchKernelGGL(k_hist_fine, dim3(SC_PARTS, segs_b), 1024, 0, s, (const uint16_t *)d_akey.p, (const uint32_t *)d_cs.p,
+                           d_cntB.as<uint32_t>(), n, CB);
+        msm_plan_t pb = pl;
+        pb.B = FB;
+        pb.chunks = SC_PARTS;
+        hipLaunchKernelGGL(k_scan_local, dim3(1, segs_b), 1024, 0, s, (const uint32_t *)d_cntB.p, d_localB.as<uint32_t>(),
+                           d_gtotB.as<uint32_t>(), pb);
+        hipLaunchKernelGGL(k_scan_apply, dim3(1, segs_b), 1024, 0, s, d_cntB.as<uint32_t>(), (const uint32_t *)d_localB.p,
+                           (const uint32_t *)d_gtotB.p, d_fs.as<uint32_t>(), pb);
+        hipLaunchKernelGGL(k_bstart_assemble, tk_div_up((size_t)pl.W * (pl.B + 1), 256), 256, 0, s, (const uint32_t *)d_cs.p,
+                           (const uint32_t *)d_fs.p, d_bstart.as<uint32_t>(), pl.W, pl.B, CB);
+        hipLaunchKernelGGL(k_scatter_staged<true>, dim3(SC_PARTS, segs_b), 1024, 0, s, (const uint32_t *)d_aidx.p, (const uint16_t *)d_akey.p,
+                           (const uint32_t *)d_cs.p, (const uint32_t *)d_cntB.p, d_sorted.as<uint32_t>(), (uint16_t *)nullptr, n, FB, CB,
+                           0u);
+        prof.mark("msm.scatter");
+    }
     const uint32_t cpw = (n + MSM_CHUNK - 1) / MSM_CHUNK;  // chunks per window (upper bound: all digits non-zero)
     const uint32_t big_cap = 1u << 16;
     tk_scratch d_fh, d_ft, d_big;
