@@ -97,7 +97,7 @@ int tkmk_is_hip_build(void);
 typedef struct {
     tkmk_stream stream_handle;          /* NULL = default stream */
     int precompute_factor;              /* 1; >1 is rejected with API_NOT_IMPLEMENTED */
-    int c;                              /* window bits; 0 = choose from size */
+    int c;                              /* window bits (2..18); 0 = choose from size */
     int bitsize;                        /* scalar bits to process; 0 = 255 */
     int batch_size;                     /* number of MSMs; results = batch_size points */
     bool are_points_shared_in_batch;    /* true: one bases array of msm_size; false: batch_size * msm_size */

@@ -18,7 +18,7 @@ def test_msm_vs_oracle_sizes(gpu, oracle, n):
     assert (_msm_affine(gpu, s, p) == oracle.g1_msm(s, p)).all()
 
 
-@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 15, 16])
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 15, 16, 18])
 def test_msm_every_window_width(gpu, oracle, c):
     n = 300
     s = oracle.fr_random(77, n)
@@ -176,3 +176,14 @@ def test_gathered_bases_msm(gpu, oracle):
     assert (bases.to_host() == want_bases).all()
     s = oracle.to_bytes([rnd.choice([0, 1, 1, 1, rnd.randrange(1 << 128), rnd.randrange(oracle.R_MOD)]) for _ in range(n)], 32)
     assert (_msm_affine(gpu, s, bases) == oracle.g1_msm(s, want_bases)).all()
+
+
+@pytest.mark.parametrize("c", [13, 16, 17, 18])
+def test_msm_two_pass_sort_wide_windows(gpu, oracle, c):
+    """n >= 2^18 takes the two-pass (coarse / fine) LDS-staged bucket sort; c = 17, 18 exist only there"""
+    n = 1 << 18
+    s = gpu.fr_random_device(0x1234 + c, n)
+    h = gpu.fr_random_device(0x5678, n)
+    p = gpu.g1_batch_scalar_mul_device(h, oracle.g1_generator(), n)
+    want = oracle.g1_msm(s.to_host(), p.to_host())
+    assert (_msm_affine(gpu, s, p, c=c) == want).all()

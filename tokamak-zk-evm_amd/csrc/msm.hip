@@ -188,18 +188,19 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint32_t *__restrict__ d
 // partial-line writes that the L2 / fabric retire at ~40 G/s chip-wide (6.6 ms at 2^24 points, 8x write
 // amplification).  Splitting the bucket index into a coarse part (<= 256 bins) and a fine part (128 bins) lets
 // each pass sort a 4096-item tile by bin inside LDS first, so that a wave writes runs of consecutive addresses.
-//   pass A: per (chunk, window): bins = bucket >> 7;  out: A_idx = point | sign, A_key = bucket (u16), grouped by coarse bin
-//   pass B: per (part, (window, coarse bin)): bins = bucket & 127;  out: the final bucket-sorted index list
+//   pass A: per (chunk, window): bins = bucket >> f;  out: A_idx = point | sign, A_key = bucket & (2^f - 1), grouped by coarse bin
+//   pass B: per (part, (window, coarse bin)): bins = A_key;  out: the final bucket-sorted index list       (f = 7 or 8)
 #define SC_TILE 4096
-#define SC_FINE_BITS 7
+#define SC_MAXBINS 512   // bins per pass: coarse <= 512 (c <= 18 with 8 fine bits), fine <= 256
 #define SC_PARTS 4
 
 template <bool PASS_B>
 __global__ __launch_bounds__(1024) void k_scatter_staged(const uint32_t *__restrict__ in0, const uint16_t *__restrict__ in1,
                                                         const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ cursors,
                                                         uint32_t *__restrict__ out0, uint16_t *__restrict__ out1, uint32_t n,
-                                                        uint32_t bins, uint32_t coarse_bins, uint32_t chunk_len) {
-    __shared__ uint32_t hist[256], start[256], cur[256];
+                                                        uint32_t bins, uint32_t coarse_bins, uint32_t chunk_len, uint32_t fbits) {
+    __shared__ uint32_t hist[SC_MAXBINS], start[SC_MAXBINS], cur[SC_MAXBINS];
+    const uint32_t fmask = (1u << fbits) - 1;
     __shared__ uint32_t sv0[SC_TILE], sv1[SC_TILE];
     const uint32_t tid = threadIdx.x, part = blockIdx.x, parts = gridDim.x, sgm = blockIdx.y;
     const uint32_t w = PASS_B ? sgm / coarse_bins : sgm;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(1024) void k_scatter_staged(const uint32_t *__restr
     if (tid < bins) cur[tid] = cursors[((uint64_t)sgm * bins + tid) * parts + part] + base;
     __syncthreads();
     for (uint32_t tlo = lo; tlo < hi; tlo += SC_TILE) {
-        if (tid < 256) hist[tid] = 0;
+        if (tid < SC_MAXBINS) hist[tid] = 0;
         __syncthreads();
         uint32_t v0[4], v1[4], rk[4];
         bool ok[4];
@@ -245,27 +246,27 @@ __global__ __launch_bounds__(1024) void k_scatter_staged(const uint32_t *__restr
                     v1[j] = r - 1;
                 }
             }
-            if (ok[j]) rk[j] = atomicAdd(&hist[PASS_B ? (v1[j] & ((1u << SC_FINE_BITS) - 1)) : (v1[j] >> SC_FINE_BITS)], 1u);
+            if (ok[j]) rk[j] = atomicAdd(&hist[PASS_B ? (v1[j] & fmask) : (v1[j] >> fbits)], 1u);
         }
         __syncthreads();
-        // exclusive prefix of hist[] -> start[] (256 lanes, Hillis-Steele)
-        uint32_t mine = tid < 256 ? hist[tid] : 0;
-        if (tid < 256) start[tid] = mine;
+        // exclusive prefix of hist[] -> start[] (Hillis-Steele over SC_MAXBINS lanes)
+        uint32_t mine = tid < SC_MAXBINS ? hist[tid] : 0;
+        if (tid < SC_MAXBINS) start[tid] = mine;
         __syncthreads();
-        for (uint32_t off = 1; off < 256; off <<= 1) {
-            uint32_t t = (tid < 256 && tid >= off) ? start[tid - off] : 0;
+        for (uint32_t off = 1; off < SC_MAXBINS; off <<= 1) {
+            uint32_t t = (tid < SC_MAXBINS && tid >= off) ? start[tid - off] : 0;
             __syncthreads();
-            if (tid < 256) start[tid] += t;
+            if (tid < SC_MAXBINS) start[tid] += t;
             __syncthreads();
         }
-        const uint32_t total = start[255];
+        const uint32_t total = start[SC_MAXBINS - 1];
         __syncthreads();
-        if (tid < 256) start[tid] -= mine;
+        if (tid < SC_MAXBINS) start[tid] -= mine;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (ok[j]) {
-                uint32_t b = PASS_B ? (v1[j] & ((1u << SC_FINE_BITS) - 1)) : (v1[j] >> SC_FINE_BITS);
+                uint32_t b = PASS_B ? (v1[j] & fmask) : (v1[j] >> fbits);
                 uint32_t pos = start[b] + rk[j];
                 sv0[pos] = v0[j];
                 sv1[pos] = v1[j];
@@ -276,39 +277,41 @@ __global__ __launch_bounds__(1024) void k_scatter_staged(const uint32_t *__restr
             uint32_t k2 = tid + 1024u * j;
             if (k2 < total) {
                 uint32_t a0 = sv0[k2], a1 = sv1[k2];
-                uint32_t b = PASS_B ? (a1 & ((1u << SC_FINE_BITS) - 1)) : (a1 >> SC_FINE_BITS);
+                uint32_t b = PASS_B ? (a1 & fmask) : (a1 >> fbits);
                 uint32_t g = cur[b] + (k2 - start[b]);
                 out0[g] = a0;
-                if (!PASS_B) out1[g] = (uint16_t)a1;
+                if (!PASS_B) out1[g] = (uint16_t)(a1 & fmask);   // pass B only needs the fine part
             }
         }
         __syncthreads();
-        if (tid < 256) cur[tid] += hist[tid];
+        if (tid < SC_MAXBINS) cur[tid] += hist[tid];
         __syncthreads();
     }
 }
 
 // pass-B histogram: counts[(w * coarse_bins + cb)][fine][part]
 __global__ __launch_bounds__(1024) void k_hist_fine(const uint16_t *__restrict__ key, const uint32_t *__restrict__ seg_start,
-                                                   uint32_t *__restrict__ counts, uint32_t n, uint32_t coarse_bins) {
-    __shared__ uint32_t hist[1u << SC_FINE_BITS];
+                                                   uint32_t *__restrict__ counts, uint32_t n, uint32_t coarse_bins, uint32_t fbits) {
+    __shared__ uint32_t hist[256];
+    const uint32_t fb_n = 1u << fbits;
     const uint32_t tid = threadIdx.x, part = blockIdx.x, parts = gridDim.x, sgm = blockIdx.y;
     const uint32_t w = sgm / coarse_bins, cb = sgm - w * coarse_bins;
     const uint32_t *cs = seg_start + (uint64_t)w * (coarse_bins + 1);
     uint32_t s0 = cs[cb], s1 = cs[cb + 1];
     uint32_t per = (s1 - s0 + parts - 1) / parts;
     uint32_t lo = s0 + part * per, hi = lo + per < s1 ? lo + per : s1;
-    if (tid < (1u << SC_FINE_BITS)) hist[tid] = 0;
+    if (tid < fb_n) hist[tid] = 0;
     __syncthreads();
     const uint16_t *k = key + (uint64_t)w * n;
-    for (uint32_t i = lo + tid; i < hi; i += 1024) atomicAdd(&hist[k[i] & ((1u << SC_FINE_BITS) - 1)], 1u);
+    for (uint32_t i = lo + tid; i < hi; i += 1024) atomicAdd(&hist[k[i] & (fb_n - 1)], 1u);
     __syncthreads();
-    if (tid < (1u << SC_FINE_BITS)) counts[((uint64_t)sgm * (1u << SC_FINE_BITS) + tid) * parts + part] = hist[tid];
+    if (tid < fb_n) counts[((uint64_t)sgm * fb_n + tid) * parts + part] = hist[tid];
 }
 
 // bstart[w][cb * 128 + fb] = coarse_start[w][cb] + fine_start[w * CB + cb][fb];  bstart[w][B] = total
 __global__ __launch_bounds__(256) void k_bstart_assemble(const uint32_t *__restrict__ coarse_start, const uint32_t *__restrict__ fine_start,
-                                                        uint32_t *__restrict__ bstart, uint32_t W, uint32_t B, uint32_t coarse_bins) {
+                                                        uint32_t *__restrict__ bstart, uint32_t W, uint32_t B, uint32_t coarse_bins,
+                                                        uint32_t fbits) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (uint64_t)W * (B + 1)) return;
     uint32_t w = (uint32_t)(e / (B + 1)), b = (uint32_t)(e - (uint64_t)w * (B + 1));
@@ -317,8 +320,8 @@ __global__ __launch_bounds__(256) void k_bstart_assemble(const uint32_t *__restr
         bstart[e] = cs[coarse_bins];
         return;
     }
-    uint32_t cb = b >> SC_FINE_BITS, fb = b & ((1u << SC_FINE_BITS) - 1);
-    bstart[e] = cs[cb] + fine_start[((uint64_t)w * coarse_bins + cb) * ((1u << SC_FINE_BITS) + 1) + fb];
+    uint32_t cb = b >> fbits, fb = b & ((1u << fbits) - 1);
+    bstart[e] = cs[cb] + fine_start[((uint64_t)w * coarse_bins + cb) * ((1u << fbits) + 1) + fb];
 }
 
 // ---- bucket accumulation, balanced by construction -------------------------------------------------
@@ -518,7 +521,8 @@ __global__ __launch_bounds__(128) void k_msm_size1(const fr_t *__restrict__ scal
 // host side
 // ---------------------------------------------------------------------------------------------------
 static uint32_t choose_c(uint32_t n) {
-    // minimise W * (n + ~4*B) over c; capped at 16 by the 128 KiB LDS histogram (2^15 buckets * 4 B)
+    // minimise W * (n + ~4*B) over c <= 16.  (c = 17, 18 are accepted on request — the two-pass sort handles 512 x 256 bins —
+    // but measured slower at 2^24 points: 63.4 vs 51.3 ms; 128-entry buckets mean more chunk fragments to flush and combine.)
     uint32_t best = 2;
     double best_cost = 1e300;
     for (uint32_t c = 2; c <= 16; c++) {
@@ -664,7 +668,9 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
     pl.bits = bits;
     pl.c = c_req ? c_req : choose_c(n);
     if (pl.c < 2) pl.c = 2;
-    if (pl.c > 16) pl.c = 16;
+    if (pl.c > 18) pl.c = 18;
+    static const bool force_one_pass = getenv("TKMK_MSM_ONE_PASS") != nullptr;
+    if (pl.c > 16 && (force_one_pass || n < (1u << 18))) pl.c = 16;   // wide windows need the two-pass sort
     pl.W = bits / pl.c + 1;
     pl.B = 1u << (pl.c - 1);
     uint32_t want = (512 + pl.W - 1) / pl.W;
@@ -694,7 +700,6 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
         TK_HIP(hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    static const bool force_one_pass = getenv("TKMK_MSM_ONE_PASS") != nullptr;
     const bool two_pass = !force_one_pass && pl.c >= 13 && n >= (1u << 18);
     if (!two_pass) {
         hipLaunchKernelGGL(k_hist, dim3(pl.chunks, pl.W), 1024, lds, s, (const uint32_t *)d_dig.p, d_counts.as<uint32_t>(), pl, 0u);
@@ -712,7 +717,7 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
                            d_sorted.as<uint32_t>(), pl);
         prof.mark("msm.scatter");
     } else {
-        const uint32_t FB = 1u << SC_FINE_BITS, CB = pl.B >> SC_FINE_BITS;
+        const uint32_t fbits = pl.c >= 17 ? 8u : 7u, FB = 1u << fbits, CB = pl.B >> fbits;
         tk_scratch d_aidx, d_akey, d_cs, d_localA, d_gtotA, d_cntB, d_fs, d_localB, d_gtotB;
         TK_TRY(d_aidx.alloc((size_t)pl.W * n * 4, s));
         TK_TRY(d_akey.alloc((size_t)pl.W * n * 2, s));
@@ -721,7 +726,7 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
         msm_plan_t pa = pl;
         pa.B = CB;
         hipLaunchKernelGGL(k_hist, dim3(pl.chunks, pl.W), 1024, (size_t)CB * 4, s, (const uint32_t *)d_dig.p, d_counts.as<uint32_t>(), pa,
-                           (uint32_t)SC_FINE_BITS);
+                           fbits);
         prof.mark("msm.hist");
         TK_TRY(d_localA.alloc((size_t)pl.W * CB * 4, s));
         TK_TRY(d_gtotA.alloc((size_t)pl.W * 4, s));
@@ -732,7 +737,7 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
         prof.mark("msm.scan");
         hipLaunchKernelGGL(k_scatter_staged<false>, dim3(pl.chunks, pl.W), 1024, 0, s, (const uint32_t *)d_dig.p, (const uint16_t *)nullptr,
                            (const uint32_t *)nullptr, (const uint32_t *)d_counts.p, d_aidx.as<uint32_t>(), d_akey.as<uint16_t>(), n, CB, CB,
-                           pl.chunk_len);
+                           pl.chunk_len, fbits);
         // ---- pass B: fine bins inside every (window, coarse bin) segment ----
         const uint32_t segs_b = pl.W * CB;
         TK_TRY(d_cntB.alloc((size_t)segs_b * FB * SC_PARTS * 4, s));
@@ -740,7 +745,7 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
         TK_TRY(d_localB.alloc((size_t)segs_b * FB * 4, s));
         TK_TRY(d_gtotB.alloc((size_t)segs_b * 4, s));
         hipLaunchKernelGGL(k_hist_fine, dim3(SC_PARTS, segs_b), 1024, 0, s, (const uint16_t *)d_akey.p, (const uint32_t *)d_cs.p,
-                           d_cntB.as<uint32_t>(), n, CB);
+                           d_cntB.as<uint32_t>(), n, CB, fbits);
         msm_plan_t pb = pl;
         pb.B = FB;
         pb.chunks = SC_PARTS;
@@ -749,10 +754,10 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
         hipLaunchKernelGGL(k_scan_apply, dim3(1, segs_b), 1024, 0, s, d_cntB.as<uint32_t>(), (const uint32_t *)d_localB.p,
                            (const uint32_t *)d_gtotB.p, d_fs.as<uint32_t>(), pb);
         hipLaunchKernelGGL(k_bstart_assemble, tk_div_up((size_t)pl.W * (pl.B + 1), 256), 256, 0, s, (const uint32_t *)d_cs.p,
-                           (const uint32_t *)d_fs.p, d_bstart.as<uint32_t>(), pl.W, pl.B, CB);
+                           (const uint32_t *)d_fs.p, d_bstart.as<uint32_t>(), pl.W, pl.B, CB, fbits);
         hipLaunchKernelGGL(k_scatter_staged<true>, dim3(SC_PARTS, segs_b), 1024, 0, s, (const uint32_t *)d_aidx.p, (const uint16_t *)d_akey.p,
                            (const uint32_t *)d_cs.p, (const uint32_t *)d_cntB.p, d_sorted.as<uint32_t>(), (uint16_t *)nullptr, n, FB, CB,
-                           0u);
+                           0u, fbits);
         prof.mark("msm.scatter");
     }
     const uint32_t cpw = (n + MSM_CHUNK - 1) / MSM_CHUNK;  // chunks per window (upper bound: all digits non-zero)
@@ -801,7 +806,7 @@ TK_API tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *ba
                                 tkmk_g1_projective *results) {
     if (!cfg || cfg->ext) return TKMK_ERR_INVALID_ARGUMENT;
     if (cfg->precompute_factor > 1) return TKMK_ERR_API_NOT_IMPLEMENTED;
-    if (msm_size < 0 || cfg->batch_size < 1 || cfg->bitsize < 0 || cfg->bitsize > 255 || cfg->c < 0 || cfg->c > 16)
+    if (msm_size < 0 || cfg->batch_size < 1 || cfg->bitsize < 0 || cfg->bitsize > 255 || cfg->c < 0 || cfg->c > 18)
         return TKMK_ERR_INVALID_ARGUMENT;
     if (!results) return TKMK_ERR_INVALID_POINTER;
     TK_TRY(tk_require_device());
