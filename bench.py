@@ -27,6 +27,8 @@ sys.path.insert(0, os.path.join(ROOT, "tokamak-zk-evm_amd"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MAD_PEAK_PER_S = 3.2e13          # measured v_mad_u64_u32 issue rate, lane-ops/s (profiles/r01_arith_microbench_v3.json)
+MADS_PER_BUCKET_ADD = 8 * 392 + 2 * 301   # madd-2008-s on 14 x 29-bit limbs: 8 products + 2 squares (csrc/ffu.h)
 ADDS_PER_POINT = 16              # SURVEY.md §8d cfg 2: N * ceil(b/c) at c = 16, b = 255
 ALG_BYTES_PER_POINT = 32 + 96    # each scalar and base read once
 SEED = 0x746F6B616D616B00
@@ -142,6 +144,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer-VALU bound by construction (SURVEY.md §8d): ~375 int mul-adds per algorithmic byte"},
             "kernel_ms": sections,
+            # the bound that actually applies: 32x32->64 integer multiply-add issue in k_accumulate_chunks
+            "valu_roofline": {"kernel": "k_accumulate_chunks", "unit": "v_mad_u64_u32 lane-ops/s",
+                              "achieved": n * ADDS_PER_POINT * MADS_PER_BUCKET_ADD / (kernel_ms * 1e-3),
+                              "peak": MAD_PEAK_PER_S,
+                              "frac": n * ADDS_PER_POINT * MADS_PER_BUCKET_ADD / (kernel_ms * 1e-3) / MAD_PEAK_PER_S},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(tkmk, args.cpu_sample_logn)

@@ -73,3 +73,59 @@ def test_point_sharded_msm_world2_gloo():
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(world))
     assert res == {0: True, 1: True}
+
+
+class _OracleNttOps:
+    """test-only stand-in for the per-rank GPU transforms"""
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def ntt_rows(self, buf, n, batch, coset, inverse):
+        return self.o.ntt(buf, n, batch=batch, inverse=inverse, coset_gen=coset)
+
+    def ntt_cols(self, buf, n, batch, coset, inverse):
+        return self.o.ntt(buf, n, batch=batch, columns_batch=True, inverse=inverse, coset_gen=coset)
+
+
+def _ntt_worker(rank, world, port, xs, ys, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tokamak-zk-evm_amd"))
+    import torch.distributed as dist
+    import oracle
+    from tkmk import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = oracle.fr_random(9, xs * ys)
+        cx, cy = oracle.fr_random(10, 1), oracle.fr_random(11, 1)
+        rows, cols = xs // world, ys // world
+        ok = True
+        for inverse in (False, True):
+            want = oracle.bintt(m, xs, ys, inverse=inverse, coset_x=cx, coset_y=cy).reshape(xs, ys, 32)
+            slab = m.reshape(xs, ys * 32)[rank * rows:(rank + 1) * rows].reshape(-1).copy()
+            got = sharding.bintt_sharded(_OracleNttOps(oracle), dist, slab, xs, ys, inverse=inverse, coset_x=cx, coset_y=cy)
+            ok &= bool((got.reshape(xs, cols, 32) == want[:, rank * cols:(rank + 1) * cols, :]).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_bintt_all_to_all_world2_gloo():
+    """the single exchange step of the path: x-slabs -> row NTTs -> all_to_all -> column NTTs on y-slabs"""
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_ntt_worker, args=(r, world, port, 16, 8, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=10) for _ in range(world)) == {0: True, 1: True}

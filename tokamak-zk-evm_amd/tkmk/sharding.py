@@ -41,3 +41,49 @@ def msm_sharded(tkmk, dist, scalars_shard, bases_shard, device="cuda"):
     if dist is None or dist.get_world_size() == 1:
         return part
     return combine_partials(tkmk, gather_partials(dist, part, device))
+
+
+# ---------------------------------------------------------------------------------------------------
+# One large bivariate NTT sharded over the ranks: the only sub-path with a real exchange.
+#   rank r holds the x-slab: rows [r*xs/G, (r+1)*xs/G) of the xs x ys matrix (element (ix,iy) at ix*ys + iy)
+#   1. row transforms (length ys, coset_y) on the slab                                — local
+#   2. ONE all_to_all: block (rows of r) x (columns of q) goes to rank q              — RCCL over xGMI (nccl backend)
+#   3. column transforms (length xs, coset_x) on the assembled xs x (ys/G) y-slab     — local
+# Output = this rank's y-slab (all ix, columns [r*ys/G, (r+1)*ys/G)), row-major xs x (ys/G).
+# Independent NTT batches (u/v/w, the leaves of p_comb) shard by batch index with no communication at all.
+# ---------------------------------------------------------------------------------------------------
+class TkmkNttOps:
+    """per-rank compute through the HIP library; buffers are host numpy arrays here (the exchange is the point)"""
+
+    def __init__(self, tkmk):
+        self.t = tkmk
+
+    def ntt_rows(self, buf, n, batch, coset, inverse):
+        return self.t.ntt(buf, n, batch=batch, inverse=inverse, coset_gen=coset)
+
+    def ntt_cols(self, buf, n, batch, coset, inverse):
+        return self.t.ntt(buf, n, batch=batch, columns_batch=True, inverse=inverse, coset_gen=coset)
+
+
+def bintt_sharded(ops, dist, slab, x_size, y_size, inverse=False, coset_x=None, coset_y=None, device="cpu"):
+    import torch
+    G, r = dist.get_world_size(), dist.get_rank()
+    if x_size % G or y_size % G:
+        raise ValueError("x_size and y_size must be multiples of the world size")
+    rows, cols = x_size // G, y_size // G
+    assert slab.size == 32 * rows * y_size
+    # 1. rows of this slab
+    a = ops.ntt_rows(np.ascontiguousarray(slab), y_size, rows, coset_y, inverse)
+    # 2. all_to_all: send[q] = block (rows x cols_q); recv[q] = block from rank q (its rows, my columns)
+    m = a.reshape(rows, G, cols * 32)
+    send = torch.from_numpy(np.ascontiguousarray(m.transpose(1, 0, 2))).to(device)      # [q][row][col bytes]
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    yslab = recv.cpu().numpy().reshape(G * rows, cols * 32).reshape(-1)                  # rows of rank 0, then rank 1, ... = all ix
+    # 3. columns of the y-slab: xs x cols, element (ix, j) at ix*cols + j
+    return ops.ntt_cols(np.ascontiguousarray(yslab), x_size, cols, coset_x, inverse)
+
+
+def shard_batch(n_batch, rank, world):
+    """independent NTTs: contiguous batch range of this rank (no communication)"""
+    return shard_range(n_batch, rank, world)
