@@ -194,6 +194,9 @@ tkmk_error bls12_381_scalar_mul_vec(const tkmk_fr *a, const tkmk_fr *b, uint64_t
 /* out[b] = sum / product of vector b (batch_size vectors of n) */
 tkmk_error bls12_381_vector_sum(const tkmk_fr *a, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
 tkmk_error bls12_381_vector_product(const tkmk_fr *a, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+/* out[i] = prod_{j > i} a[j], out[n-1] = 1 (device pointers, out != a): the running product of prove1, a serial host loop over
+ * 2^20 elements in the reference (packages/backend/prove/src/lib.rs:1858-1862) */
+tkmk_error tkmk_vec_suffix_product(const tkmk_fr *a_dev, uint64_t n, tkmk_fr *out_dev, tkmk_stream stream);
 /* row-major rows x cols -> cols x rows */
 tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, uint32_t cols, const tkmk_vecops_config *cfg, tkmk_fr *out);
 

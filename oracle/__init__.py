@@ -110,6 +110,12 @@ def fr_transpose(a, rows, cols):
     return out
 
 
+def fr_suffix_product(a):
+    out = np.empty_like(a)
+    lib().tko_fr_suffix_product(_p(a), _sz(a.size // 32), _p(out))
+    return out
+
+
 def fr_random(seed, n, first=0):
     out = np.empty(32 * n, np.uint8)
     lib().tko_fr_random(_u64(seed), _sz(first), _sz(n), _p(out))

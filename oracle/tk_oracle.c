@@ -997,3 +997,17 @@ void tko_poly_div_by_ruffini(const uint8_t *p, size_t xs, size_t ys, const uint8
     free(q);
     free(rx);
 }
+
+/* prove1 running product, packages/backend/prove/src/lib.rs:1858-1862:
+ * r[n-1] = 1; for idx in (0..n-1).rev(): r[idx] = r[idx+1] * s[idx+1] */
+void tko_fr_suffix_product(const uint8_t *s, size_t n, uint8_t *out) {
+    tko_init();
+    if (n == 0) return;
+    fr_t r = fr_R1, t;
+    fr_store(out + 32 * (n - 1), &r);
+    for (size_t idx = n - 1; idx-- > 0;) {
+        fr_load(&t, s + 32 * (idx + 1));
+        fr_mul(&r, &r, &t);
+        fr_store(out + 32 * idx, &r);
+    }
+}

@@ -49,6 +49,7 @@ void tko_fr_scalar_add(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t 
 void tko_fr_scalar_sub(const uint8_t *s, const uint8_t *a, uint8_t *out, size_t n); /* s - a[i] (ICICLE v3 scalar_sub_vec) */
 void tko_fr_pow_u64(const uint8_t *a, uint64_t e, uint8_t *out);
 void tko_fr_transpose(const uint8_t *in, size_t rows, size_t cols, uint8_t *out);
+void tko_fr_suffix_product(const uint8_t *s, size_t n, uint8_t *out); /* prove/src/lib.rs:1858-1862 */
 void tko_fq_mul(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
 void tko_fq_add(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
 void tko_fq_sub(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);

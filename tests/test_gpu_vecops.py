@@ -84,3 +84,13 @@ def test_device_montgomery_product_edges(gpu, oracle, field):
     b = [y for _ in edge for y in edge] + [rnd.randrange(mod) for _ in range(5000)]
     A, B = oracle.to_bytes(a, width), oracle.to_bytes(b, width)
     assert (gpu.diag_field_mul(field, A, B) == omul(A, B)).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 4096, 4097, 70001, 1 << 20])
+def test_suffix_product(gpu, oracle, n):
+    """prove1's running product (prove/src/lib.rs:1858-1862) as a device scan vs the oracle's serial loop"""
+    a = oracle.fr_random(900 + n % 1000, n)
+    if n > 17:
+        a[32 * 5:32 * 6] = 0            # a zero factor kills every product to its left
+    got = gpu.vec_suffix_product(a).to_host()
+    assert (got == oracle.fr_suffix_product(a)).all()

@@ -236,3 +236,9 @@ def test_convolution_theorem(oracle):
             if x and y:
                 want[i + j] = (want[i + j] + x * y) % pyref.R
     assert oracle.to_ints(prod, 32) == want
+
+
+def test_suffix_product_definition(oracle):
+    vals = [3, 5, 7, 11, 13]
+    out = oracle.to_ints(oracle.fr_suffix_product(oracle.to_bytes(vals, 32)), 32)
+    assert out == [5 * 7 * 11 * 13, 7 * 11 * 13, 11 * 13, 13, 1]

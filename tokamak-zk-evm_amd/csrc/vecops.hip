@@ -265,3 +265,93 @@ TK_API tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, u
     if (!cfg->is_async || !cfg->is_result_on_device) TK_HIP(hipStreamSynchronize(s));
     return TKMK_SUCCESS;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Exclusive suffix product: out[i] = prod_{j > i} a[j], out[n-1] = 1 — the copy-constraint running product of
+// prove1, which the reference computes with a serial host loop over 2^20 elements
+// (packages/backend/prove/src/lib.rs:1858-1862: r[idx] = r[idx+1] * scalers[idx+1]).  Three launches: per-workgroup
+// products (16 consecutive elements per lane, LDS suffix scan over the 256 lanes), a scan of the workgroup products,
+// and the apply pass.  Accumulators are kept in Montgomery form.
+// ---------------------------------------------------------------------------------------------------
+#define SP_RUN 16
+#define SP_BLOCK (256 * SP_RUN)
+// lane-level exclusive suffix scan of Montgomery values over 256 lanes: sh[t] <- prod_{u > t} v[u]; returns the
+// inclusive block product in *total
+__device__ __forceinline__ fr_t sp_suffix_scan(fr_t v, fr_t *sh, fr_t *total) {
+    const uint32_t t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    fr_t incl = v;  // inclusive suffix product
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        fr_t other = t + off < 256 ? sh[t + off] : Fr::one();
+        __syncthreads();
+        incl = Fr::mul(incl, other);
+        sh[t] = incl;
+        __syncthreads();
+    }
+    fr_t excl = t + 1 < 256 ? sh[t + 1] : Fr::one();
+    *total = sh[0];
+    __syncthreads();
+    return excl;
+}
+__global__ __launch_bounds__(256) void k_sp_block_products(const fr_t *__restrict__ a, uint64_t n, fr_t *__restrict__ bprod) {
+    __shared__ fr_t sh[256];
+    uint64_t base = (uint64_t)blockIdx.x * SP_BLOCK + (uint64_t)threadIdx.x * SP_RUN;
+    fr_t p = Fr::one();
+    for (int k = 0; k < SP_RUN; k++)
+        if (base + k < n) p = Fr::mul(p, Fr::to_mont(Fr::canon(tk_load(a + base + k))));
+    fr_t total;
+    (void)sp_suffix_scan(p, sh, &total);
+    if (threadIdx.x == 0) tk_store(bprod + blockIdx.x, total);
+}
+// single workgroup: carry[b] = prod_{c > b} bprod[c]  (nb <= 2^24 / 4096; serial chunks of 256)
+__global__ __launch_bounds__(256) void k_sp_block_scan(const fr_t *__restrict__ bprod, uint32_t nb, fr_t *__restrict__ carry) {
+    __shared__ fr_t sh[256];
+    fr_t tail = Fr::one();  // product of all blocks beyond the current chunk
+    for (int64_t hi = nb; hi > 0; hi -= 256) {
+        int64_t lo = hi - 256 < 0 ? 0 : hi - 256;
+        int64_t idx = lo + threadIdx.x;
+        fr_t v = idx < hi ? tk_load(bprod + idx) : Fr::one();
+        fr_t total;
+        fr_t excl = sp_suffix_scan(v, sh, &total);
+        if (idx < hi) tk_store(carry + idx, Fr::mul(excl, tail));
+        tail = Fr::mul(tail, total);
+    }
+}
+__global__ __launch_bounds__(256) void k_sp_apply(const fr_t *__restrict__ a, uint64_t n, const fr_t *__restrict__ carry,
+                                                 fr_t *__restrict__ out) {
+    __shared__ fr_t sh[256];
+    uint64_t base = (uint64_t)blockIdx.x * SP_BLOCK + (uint64_t)threadIdx.x * SP_RUN;
+    fr_t x[SP_RUN];
+    fr_t p = Fr::one();
+#pragma unroll
+    for (int k = 0; k < SP_RUN; k++) {
+        x[k] = base + k < n ? Fr::to_mont(Fr::canon(tk_load(a + base + k))) : Fr::one();
+        p = Fr::mul(p, x[k]);
+    }
+    fr_t total;
+    fr_t run = Fr::mul(sp_suffix_scan(p, sh, &total), tk_load(carry + blockIdx.x));  // product of everything beyond this lane's run
+#pragma unroll
+    for (int k = SP_RUN - 1; k >= 0; k--) {
+        if (base + k < n) tk_store(out + base + k, Fr::from_mont(run));
+        run = Fr::mul(run, x[k]);
+    }
+}
+
+TK_API tkmk_error tkmk_vec_suffix_product(const tkmk_fr *a_dev, uint64_t n, tkmk_fr *out_dev, tkmk_stream stream) {
+    if ((!a_dev || !out_dev) && n) return TKMK_ERR_INVALID_POINTER;
+    TK_TRY(tk_require_device());
+    if (n == 0) return TKMK_SUCCESS;
+    if ((const void *)a_dev == (void *)out_dev) return TKMK_ERR_INVALID_ARGUMENT;
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    uint32_t nb = (uint32_t)((n + SP_BLOCK - 1) / SP_BLOCK);
+    tk_scratch bprod, carry;
+    TK_TRY(bprod.alloc((size_t)nb * sizeof(fr_t), s));
+    TK_TRY(carry.alloc((size_t)nb * sizeof(fr_t), s));
+    hipLaunchKernelGGL(k_sp_block_products, nb, 256, 0, s, (const fr_t *)a_dev, n, bprod.as<fr_t>());
+    hipLaunchKernelGGL(k_sp_block_scan, 1, 256, 0, s, (const fr_t *)bprod.p, nb, carry.as<fr_t>());
+    hipLaunchKernelGGL(k_sp_apply, nb, 256, 0, s, (const fr_t *)a_dev, n, (const fr_t *)carry.p, (fr_t *)out_dev);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}

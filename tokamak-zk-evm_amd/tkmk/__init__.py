@@ -87,7 +87,7 @@ SYMBOLS = [
     "bls12_381_ntt", "tkmk_bintt", "tkmk_vecops_default_config", "bls12_381_vector_add", "bls12_381_vector_sub",
     "bls12_381_vector_mul", "bls12_381_vector_div", "bls12_381_vector_inv", "bls12_381_scalar_add_vec",
     "bls12_381_scalar_sub_vec", "bls12_381_scalar_mul_vec", "bls12_381_vector_sum", "bls12_381_vector_product",
-    "bls12_381_matrix_transpose", "tkmk_fr_random_device", "tkmk_gather_rows_device", "tkmk_g1_batch_scalar_mul_device", "tkmk_profile_enable",
+    "bls12_381_matrix_transpose", "tkmk_vec_suffix_product", "tkmk_fr_random_device", "tkmk_gather_rows_device", "tkmk_g1_batch_scalar_mul_device", "tkmk_profile_enable",
     "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench", "tkmk_diag_field_mul", "tkmk_poly_find_degree",
     "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
     "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini",
@@ -401,4 +401,12 @@ def gather_rows_device(src, row_bytes, idx, out=None):
     out = DeviceBuffer(row_bytes * n) if out is None else out
     _check(lib().tkmk_gather_rows_device(_p(src), ctypes.c_uint32(row_bytes), _p(idx), ctypes.c_uint64(n), _p(out), None),
            "tkmk_gather_rows_device")
+    return out
+
+
+def vec_suffix_product(a, out=None):
+    """out[i] = prod_{j > i} a[j], out[n-1] = 1 (prove1's running product: prove/src/lib.rs:1858-1862)"""
+    a = a if isinstance(a, DeviceBuffer) else DeviceBuffer.from_host(a)
+    out = DeviceBuffer(a.nbytes) if out is None else out
+    _check(lib().tkmk_vec_suffix_product(_p(a), ctypes.c_uint64(a.nbytes // 32), _p(out), None), "tkmk_vec_suffix_product")
     return out
