@@ -252,6 +252,16 @@ tkmk_error tkmk_poly_div_by_ruffini(const tkmk_fr *p_dev, uint32_t x_size, uint3
                                     tkmk_fr *q_x_dev, tkmk_fr *q_y_dev, tkmk_fr *r_host, tkmk_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Witness side of the path: sparse R1CS rows x placement variables -> rows of the u / v / w evaluation
+ * matrices.  Replaces eval_uvwxy_sparse_rows / eval_sparse_rows (libs/src/iotools/mod.rs:1426-1523,1590-1608), a host loop.
+ * CSR of one matrix of one subcircuit; variables = n_placements x n_wires (plain Fr); out = s_max x n matrix, row
+ * out_slot[p] receives placement p (rows >= n_rows stay as the caller zeroed them).  Device pointers throughout.
+ * --------------------------------------------------------------------------------------------- */
+tkmk_error tkmk_r1cs_eval_rows(const uint32_t *row_ptr_dev, const uint32_t *wire_dev, const tkmk_fr *coeff_dev, uint32_t n_rows,
+                               uint32_t nnz, const tkmk_fr *variables_dev, uint32_t n_wires, uint32_t n_placements,
+                               const uint32_t *out_slot_dev, uint32_t n, tkmk_fr *out_dev, tkmk_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart; the reference's `timing` feature wraps host spans:
  * libs/src/lib.rs:11-141).  When enabled, launchers bracket each kernel with HIP events recorded on the
  * launch stream; names: "msm.digits|hist|scan|scatter|accumulate|reduce_segments|reduce_windows|

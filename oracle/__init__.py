@@ -279,6 +279,15 @@ def poly_div_by_ruffini(p, xs, ys, x, y):
     return qx, qy, r
 
 
+def r1cs_eval_rows(row_ptr, wire, coeff, variables, out_len):
+    out = np.empty(32 * out_len, np.uint8)
+    rp = np.ascontiguousarray(row_ptr, np.uint32)
+    wi = np.ascontiguousarray(wire, np.uint32)
+    lib().tko_r1cs_eval_rows(rp.ctypes.data_as(ctypes.c_void_p), wi.ctypes.data_as(ctypes.c_void_p), _p(coeff), _sz(len(rp) - 1),
+                             _p(variables), _p(out), _sz(out_len))
+    return out
+
+
 def num_threads():
     return lib().tko_num_threads()
 

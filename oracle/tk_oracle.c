@@ -1011,3 +1011,23 @@ void tko_fr_suffix_product(const uint8_t *s, size_t n, uint8_t *out) {
         fr_store(out + 32 * idx, &r);
     }
 }
+
+/* eval_sparse_rows, packages/backend/libs/src/iotools/mod.rs:1590-1608, on CSR input: for one placement,
+ * out[row] = sum over the row's entries of coeff * variables[wire]  (rows >= out_len dropped; empty rows stay 0) */
+void tko_r1cs_eval_rows(const uint32_t *row_ptr, const uint32_t *wire, const uint8_t *coeff, size_t n_rows,
+                        const uint8_t *variables, uint8_t *out, size_t out_len) {
+    tko_init();
+    memset(out, 0, 32 * out_len);
+    for (size_t r = 0; r < n_rows; r++) {
+        if (row_ptr[r] == row_ptr[r + 1]) continue;
+        fr_t acc, c, v, t;
+        memset(&acc, 0, sizeof acc);
+        for (uint32_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+            fr_load(&c, coeff + 32 * (size_t)k);
+            fr_load(&v, variables + 32 * (size_t)wire[k]);
+            fr_mul(&t, &c, &v);
+            fr_add(&acc, &acc, &t);
+        }
+        if (r < out_len) fr_store(out + 32 * r, &acc);
+    }
+}

@@ -103,6 +103,10 @@ int tko_poly_div_by_vanishing_opt(const uint8_t *p, size_t xs, size_t ys, size_t
 void tko_poly_div_by_ruffini(const uint8_t *p, size_t xs, size_t ys, const uint8_t *x, const uint8_t *y, uint8_t *q_x,
                              uint8_t *q_y, uint8_t *r);
 
+/* eval_sparse_rows (libs/src/iotools/mod.rs:1590-1608) on CSR input, one placement */
+void tko_r1cs_eval_rows(const uint32_t *row_ptr, const uint32_t *wire, const uint8_t *coeff, size_t n_rows,
+                        const uint8_t *variables, uint8_t *out, size_t out_len);
+
 int tko_num_threads(void);
 
 #ifdef __cplusplus

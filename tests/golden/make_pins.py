@@ -56,3 +56,15 @@ out["setup_params"] = json.load(open(REF + "/frontend/qap-compiler/subcircuits/l
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pins.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
+
+# Data fixtures for the R1CS reader / uvw evaluation tests: three small compiled subcircuits (binary iden3 .r1cs) and
+# their subcircuitInfo entries, copied as DATA from the reference's committed library.
+import shutil
+lib = REF + "/frontend/qap-compiler/subcircuits/library/"
+dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "qap")
+os.makedirs(dst + "/r1cs", exist_ok=True)
+for i in (1, 2, 12):
+    shutil.copy(lib + "r1cs/subcircuit%d.r1cs" % i, dst + "/r1cs/")
+info = [e for e in json.load(open(lib + "subcircuitInfo.json")) if e["id"] in (1, 2, 12)]
+json.dump(info, open(dst + "/subcircuitInfo.json", "w"))
+json.dump(json.load(open(lib + "setupParams.json")), open(dst + "/setupParams.json", "w"))

@@ -195,3 +195,35 @@ def test_polyexpr_fused_equals_coefficient_route(P, gpu, oracle):
     assert (big.x_size, big.y_size) == (64, 32) and (ev(big) == want).all()
     with pytest.raises(ValueError):
         expr.evaluate_fused_with_domain(8, 16)
+
+
+def test_read_R1CS_gen_uvwXY(P, gpu, oracle):
+    """read_R1CS_gen_uvwXY (libs/src/iotools/mod.rs:1287-1420) on the device: committed subcircuits (data fixtures), synthetic
+    placement variables; vs the oracle's eval_sparse_rows + transpose + inverse bivariate NTT"""
+    import random
+    from tkmk import r1cs
+    qap = os.path.join(os.path.dirname(__file__), "golden", "qap")
+    infos = json.load(open(os.path.join(qap, "subcircuitInfo.json")))
+    params = dict(json.load(open(os.path.join(qap, "setupParams.json"))), n=64, s_max=8)   # small grid for the oracle
+    by_id = {e["id"]: e for e in infos}
+    rnd = random.Random(8)
+    placements = []
+    for sid in (1, 12, 2, 1, 12):                               # 5 placements <= s_max, ids repeat
+        nw = by_id[sid]["Nwires"]
+        placements.append({"subcircuitId": sid, "variables": ["0x%x" % rnd.randrange(oracle.R_MOD) for _ in range(nw)]})
+    placements[1]["variables"][0] = "0x01"
+    u, v, w = r1cs.read_R1CS_gen_uvwXY(qap, placements, infos, params)
+    n, s_max = params["n"], params["s_max"]
+    for m, poly in enumerate((u, v, w)):
+        ev = np.zeros(32 * s_max * n, np.uint8)
+        for slot, pl in enumerate(placements):
+            e = by_id[pl["subcircuitId"]]
+            s = r1cs.SubcircuitR1CS.from_r1cs_sparse_only(os.path.join(qap, "r1cs", "subcircuit%d.r1cs" % e["id"]), params, e)
+            ptr, wires, coeffs = s.csr[m]
+            var = oracle.to_bytes([r1cs.hex_to_fr(h) for h in pl["variables"]], 32)
+            ev[32 * n * slot:32 * n * (slot + 1)] = oracle.r1cs_eval_rows(ptr, wires, coeffs if coeffs.size else np.zeros(32, np.uint8), var, n)
+        want = oracle.bintt(oracle.fr_transpose(ev, s_max, n), n, s_max, inverse=True)
+        assert (poly.x_size, poly.y_size) == (n, s_max)
+        assert (poly.copy_coeffs() == want).all(), "matrix %d" % m
+    with pytest.raises(ValueError):
+        r1cs.read_R1CS_gen_uvwXY(qap, placements * 2, infos, params)     # more placements than s_max

@@ -90,7 +90,7 @@ SYMBOLS = [
     "bls12_381_matrix_transpose", "tkmk_vec_suffix_product", "tkmk_fr_random_device", "tkmk_gather_rows_device", "tkmk_g1_batch_scalar_mul_device", "tkmk_profile_enable",
     "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench", "tkmk_diag_field_mul", "tkmk_poly_find_degree",
     "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
-    "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini",
+    "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini", "tkmk_r1cs_eval_rows",
 ]
 
 
