@@ -227,3 +227,41 @@ def test_read_R1CS_gen_uvwXY(P, gpu, oracle):
         assert (poly.copy_coeffs() == want).all(), "matrix %d" % m
     with pytest.raises(ValueError):
         r1cs.read_R1CS_gen_uvwXY(qap, placements * 2, infos, params)     # more placements than s_max
+
+
+def test_witness_and_permutation_polynomials(P, gpu, oracle):
+    """gen_bXY / gen_a_free_X (libs/src/polynomial_structures/mod.rs:104-162) and Permutation::to_poly
+    (libs/src/iotools/mod.rs:419-455): evaluations of the resulting polynomials on the grid give back the inputs"""
+    import random
+    from tkmk import witness
+    rnd = random.Random(12)
+    R = oracle.R_MOD
+    params = {"l": 4, "l_D": 20, "s_max": 8, "l_free": 8, "l_user": 5}
+    m_i, s_max = params["l_D"] - params["l"], params["s_max"]
+    infos = [{"id": 0, "flattenMap": [0, 4, 5, 19, 20, 7]}, {"id": 1, "flattenMap": [3, 6, 18]}]
+    placements = [{"subcircuitId": 0, "variables": ["0x1", "0x0", "0xabc", "0x%x" % (R - 1), "0x5", "0x7"]},
+                  {"subcircuitId": 1, "variables": ["0x9", "0x%x" % rnd.randrange(R), "0x0"]},
+                  {"subcircuitId": 0, "variables": ["0x2", "0x3", "0x0", "0x4", "0x5", "0x6"]}]
+    b = witness.gen_bXY(placements, infos, params)
+    ev = oracle.to_ints(b.to_rou_evals().to_host(), 32)
+    want = [0] * (m_i * s_max)
+    for i, pl in enumerate(placements):
+        for g, v in zip(infos[pl["subcircuitId"]]["flattenMap"], pl["variables"]):
+            if params["l"] <= g < params["l_D"] and v != "0x0":
+                want[(g - params["l"]) * s_max + i] = int(v, 16) % R
+    assert ev == want
+    with pytest.raises(ValueError):
+        witness.gen_bXY([{"subcircuitId": 1, "variables": ["0x1"]}], infos, params)
+    inst = {"a_pub_user": ["0x%x" % rnd.randrange(R) for _ in range(5)], "a_pub_block": ["0x%x" % rnd.randrange(R) for _ in range(3)]}
+    a = witness.gen_a_free_X(inst, params)
+    assert oracle.to_ints(a.to_rou_evals().to_host(), 32) == [int(h, 16) % R for h in inst["a_pub_user"] + inst["a_pub_block"]]
+    perm = [{"row": 1, "col": 2, "X": 5, "Y": 7}, {"row": 5, "col": 7, "X": 1, "Y": 2}, {"row": 15, "col": 0, "X": 15, "Y": 0}]
+    s0, s1 = witness.permutation_to_poly(perm, m_i, s_max)
+    wx = oracle.to_ints(oracle.root_of_unity(m_i), 32)[0]
+    wy = oracle.to_ints(oracle.root_of_unity(s_max), 32)[0]
+    e0, e1 = oracle.to_ints(s0.to_rou_evals().to_host(), 32), oracle.to_ints(s1.to_rou_evals().to_host(), 32)
+    tgt = {(p["row"], p["col"]): (p["X"], p["Y"]) for p in perm}
+    for r in range(m_i):
+        for c in range(s_max):
+            X, Y = tgt.get((r, c), (r, c))
+            assert e0[r * s_max + c] == pow(wx, X, R) and e1[r * s_max + c] == pow(wy, Y, R)
