@@ -82,6 +82,8 @@ tkmk_error tkmk_stream_create(tkmk_stream *s);            /* IcicleStream::creat
 tkmk_error tkmk_stream_synchronize(tkmk_stream s);        /* IcicleStream::synchronize */
 tkmk_error tkmk_stream_destroy(tkmk_stream s);            /* IcicleStream::destroy */
 tkmk_error tkmk_device_synchronize(void);
+/* scratch used by MSM / NTT calls lives in per-stream grow-only arenas; this returns all of it to the driver */
+tkmk_error tkmk_release_scratch(void);
 const char *tkmk_error_string(tkmk_error e);
 /* 1 if libtkmk_hip.so was built with gfx950 code objects (always, for this library) */
 int tkmk_is_hip_build(void);

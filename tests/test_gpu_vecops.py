@@ -94,3 +94,16 @@ def test_suffix_product(gpu, oracle, n):
         a[32 * 5:32 * 6] = 0            # a zero factor kills every product to its left
     got = gpu.vec_suffix_product(a).to_host()
     assert (got == oracle.fr_suffix_product(a)).all()
+
+
+def test_release_scratch_returns_memory(gpu, oracle):
+    n = 1 << 18
+    s = gpu.fr_random_device(1, n)
+    h = gpu.fr_random_device(2, n)
+    p = gpu.g1_batch_scalar_mul_device(h, oracle.g1_generator(), n)
+    r1 = gpu.msm(s, p)
+    _, free_before = gpu.available_memory()
+    gpu.release_scratch()
+    _, free_after = gpu.available_memory()
+    assert free_after > free_before
+    assert (gpu.msm(s, p) == r1).all()          # arenas regrow transparently

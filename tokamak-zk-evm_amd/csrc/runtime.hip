@@ -161,6 +161,21 @@ tkmk_error tk_staged::copy_back(void *dst, size_t bytes, bool on_device, hipStre
     return TKMK_SUCCESS;
 }
 
+// frees every per-stream scratch arena (they are grow-only otherwise: a 2^24-point MSM leaves ~7 GiB parked)
+TK_API tkmk_error tkmk_release_scratch(void) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : g_arenas) {
+        tk_arena *a = kv.second;
+        if (a->depth > 0) return TKMK_ERR_INVALID_ARGUMENT;  // a call is in progress on that stream
+        for (auto &c : a->chunks) (void)hipFree(c.base);
+        a->chunks.clear();
+        a->cur = a->off = 0;
+        a->used_peak = a->used_now = 0;
+    }
+    return TKMK_SUCCESS;
+}
+
 TK_API tkmk_error tkmk_device_count(int *count) {
     if (!count) return TKMK_ERR_INVALID_POINTER;
     int n = 0;

@@ -82,7 +82,7 @@ SYMBOLS = [
     "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
     "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
     "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
-    "tkmk_device_synchronize", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm",
+    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm",
     "tkmk_ntt_default_config", "bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain",
     "bls12_381_ntt", "tkmk_bintt", "tkmk_vecops_default_config", "bls12_381_vector_add", "bls12_381_vector_sub",
     "bls12_381_vector_mul", "bls12_381_vector_div", "bls12_381_vector_inv", "bls12_381_scalar_add_vec",
@@ -410,3 +410,7 @@ def vec_suffix_product(a, out=None):
     out = DeviceBuffer(a.nbytes) if out is None else out
     _check(lib().tkmk_vec_suffix_product(_p(a), ctypes.c_uint64(a.nbytes // 32), _p(out), None), "tkmk_vec_suffix_product")
     return out
+
+
+def release_scratch():
+    _check(lib().tkmk_release_scratch(), "tkmk_release_scratch")

@@ -1,0 +1,10 @@
+import sys, time, numpy as np
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tokamak-zk-evm_amd')
+import tkmk, oracle
+tkmk.set_device(0)
+p = oracle.g1_random_bases(3, 8)
+ones = np.zeros(32*8, np.uint8); ones[0::32]=1
+tkmk.msm(ones, p)
+t=time.perf_counter()
+for _ in range(20): tkmk.msm(ones, p)
+print("8-point msm ms", (time.perf_counter()-t)/20*1e3)
