@@ -1,0 +1,492 @@
+// tkmk_host.hpp — C++17 host-side mirror of the reference's Rust `libs` types over the C ABI (include/tkmk.h).
+//
+// The reference's host language (Rust) is not available in this build environment, so the interface a maintainer
+// programs against is restated here in C++ with the reference's names, argument meaning and error behaviour
+// (Rust panics become tkmk::Error exceptions):
+//   DeviceVec<T>            icicle_runtime::memory::DeviceVec            (RAII device buffer)
+//   init_ntt_domain_for_size  libs/src/bivariate_polynomial/mod.rs:33-55 (global, grow-only)
+//   DensePolynomialExt      libs/src/bivariate_polynomial/mod.rs:112-118 + trait BivariatePolynomial :1283-1416
+//   PolyExpr                libs/src/bivariate_polynomial/mod.rs:141-436  (fused evaluation-domain evaluator)
+//   Sigma1::encode_poly     libs/src/iotools/mod.rs:2033-2113, libs/src/group_structures/mod.rs:59-119
+// Every method is a few calls into libtkmk_hip.so; the coefficient matrix stays in HBM (the reference copies it to the
+// host for find_degree / resize / mul_monomial / scaling / divisions).  Header-only; link with -ltkmk_hip.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../../include/tkmk.h"
+
+namespace tkmk {
+
+struct Error : std::runtime_error {
+    tkmk_error code;
+    Error(tkmk_error c, const std::string &where) : std::runtime_error(where + ": " + tkmk_error_string(c)), code(c) {}
+    explicit Error(const std::string &msg) : std::runtime_error(msg), code(TKMK_ERR_INVALID_ARGUMENT) {}
+};
+inline void check(tkmk_error e, const char *where) {
+    if (e != TKMK_SUCCESS) throw Error(e, where);
+}
+
+using ScalarField = tkmk_fr;
+using G1Affine = tkmk_g1_affine;
+
+inline ScalarField fr_from_u32(uint32_t v) {
+    ScalarField f{};
+    f.limbs[0] = v;
+    return f;
+}
+inline bool fr_is_zero(const ScalarField &a) {
+    uint32_t x = 0;
+    for (uint32_t l : a.limbs) x |= l;
+    return x == 0;
+}
+inline bool fr_eq(const ScalarField &a, const ScalarField &b) { return std::memcmp(&a, &b, sizeof a) == 0; }
+
+template <class T>
+class DeviceVec {
+    T *p_ = nullptr;
+    size_t n_ = 0;
+
+  public:
+    DeviceVec() = default;
+    explicit DeviceVec(size_t n) : n_(n) { check(tkmk_malloc((void **)&p_, n * sizeof(T)), "DeviceVec::device_malloc"); }
+    DeviceVec(const DeviceVec &) = delete;
+    DeviceVec &operator=(const DeviceVec &) = delete;
+    DeviceVec(DeviceVec &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr, o.n_ = 0; }
+    DeviceVec &operator=(DeviceVec &&o) noexcept {
+        if (this != &o) {
+            if (p_) tkmk_free(p_);
+            p_ = o.p_, n_ = o.n_, o.p_ = nullptr, o.n_ = 0;
+        }
+        return *this;
+    }
+    ~DeviceVec() {
+        if (p_) tkmk_free(p_);
+    }
+    static DeviceVec from_host(const T *src, size_t n) {
+        DeviceVec d(n);
+        d.copy_from_host(src, n);
+        return d;
+    }
+    static DeviceVec from_host(const std::vector<T> &v) { return from_host(v.data(), v.size()); }
+    void copy_from_host(const T *src, size_t n) { check(tkmk_memcpy_h2d(p_, src, n * sizeof(T)), "DeviceVec::copy_from_host"); }
+    void copy_to_host(T *dst, size_t n, size_t first = 0) const { check(tkmk_memcpy_d2h(dst, p_ + first, n * sizeof(T)), "DeviceVec::copy_to_host"); }
+    std::vector<T> to_host() const {
+        std::vector<T> v(n_);
+        if (n_) copy_to_host(v.data(), n_);
+        return v;
+    }
+    DeviceVec clone() const {
+        DeviceVec d(n_);
+        check(tkmk_memcpy_d2d(d.p_, p_, n_ * sizeof(T)), "DeviceVec::copy");
+        return d;
+    }
+    T *ptr() { return p_; }
+    const T *ptr() const { return p_; }
+    size_t len() const { return n_; }
+};
+
+// ---- NTT domain: global and grow-only, like init_ntt_domain_for_size (mod.rs:33-55) ----
+inline size_t &ntt_domain_size_cell() {
+    static size_t size = 0;
+    return size;
+}
+inline void init_ntt_domain_for_size(size_t size) {
+    if (size == 0) throw Error("NTT domain size must be non-zero.");
+    if (size & (size - 1)) throw Error("NTT domain size must be a power of two.");
+    size_t &cur = ntt_domain_size_cell();
+    if (cur >= size) return;
+    if (cur) check(bls12_381_ntt_release_domain(), "ntt::release_domain");
+    ScalarField root;
+    check(bls12_381_get_root_of_unity(size, &root), "ntt::get_root_of_unity");
+    tkmk_ntt_init_domain_config cfg{nullptr, false, nullptr};
+    check(bls12_381_ntt_init_domain(&root, &cfg), "ntt::initialize_domain");
+    cur = size;
+}
+
+inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+inline size_t next_pow2(size_t n) {
+    size_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+// _find_size_as_twopower (mod.rs:72-86)
+inline std::pair<size_t, size_t> find_size_as_twopower(size_t tx, size_t ty) {
+    if (tx == 0 || ty == 0) throw Error("Invalid target sizes for resize");
+    return {next_pow2(tx), next_pow2(ty)};
+}
+
+inline tkmk_vecops_config dev_cfg() {
+    tkmk_vecops_config c = tkmk_vecops_default_config();
+    c.is_a_on_device = c.is_b_on_device = c.is_result_on_device = true;
+    return c;
+}
+
+class DensePolynomialExt {
+  public:
+    DeviceVec<ScalarField> poly;  // x_size * y_size coefficients, element (ix, iy) at ix*y_size + iy
+    int64_t x_degree = -1, y_degree = -1;
+    size_t x_size = 1, y_size = 1;
+
+    DensePolynomialExt() = default;
+    DensePolynomialExt(DeviceVec<ScalarField> &&c, size_t xs, size_t ys, int64_t xd, int64_t yd)
+        : poly(std::move(c)), x_degree(xd), y_degree(yd), x_size(xs), y_size(ys) {}
+
+    static DensePolynomialExt zero() {
+        ScalarField z{};
+        return DensePolynomialExt(DeviceVec<ScalarField>::from_host(&z, 1), 1, 1, -1, -1);
+    }
+    // from_coeffs (mod.rs:1527-1551): takes ownership of a device vector
+    static DensePolynomialExt from_coeffs(DeviceVec<ScalarField> &&coeffs, size_t x_size, size_t y_size) {
+        if (x_size * y_size != coeffs.len()) throw Error("Mismatch between the coefficient vector and the polynomial size");
+        if (!is_pow2(x_size) || !is_pow2(y_size)) throw Error("The input sizes for from_coeffs must be powers of two.");
+        return DensePolynomialExt(std::move(coeffs), x_size, y_size, (int64_t)x_size - 1, (int64_t)y_size - 1);
+    }
+    static DensePolynomialExt from_coeffs(const std::vector<ScalarField> &coeffs, size_t x_size, size_t y_size) {
+        return from_coeffs(DeviceVec<ScalarField>::from_host(coeffs), x_size, y_size);
+    }
+    // from_rou_evals (mod.rs:1615-1644): inverse _biNTT of device-resident evaluations
+    static DensePolynomialExt from_rou_evals(const DeviceVec<ScalarField> &evals, size_t x_size, size_t y_size,
+                                             const ScalarField *coset_x = nullptr, const ScalarField *coset_y = nullptr) {
+        if (!is_pow2(x_size) || !is_pow2(y_size)) throw Error("The input sizes for from_rou_evals must be powers of two.");
+        if (evals.len() < x_size * y_size) throw Error("Insufficient buffer length for from_rou_evals");
+        DeviceVec<ScalarField> coeffs(x_size * y_size);
+        check(tkmk_bintt(evals.ptr(), x_size, y_size, TKMK_NTT_INVERSE, coset_x, coset_y, true, nullptr, coeffs.ptr()), "_biNTT");
+        return from_coeffs(std::move(coeffs), x_size, y_size);
+    }
+    // to_rou_evals (mod.rs:1646-1674) without the reference's D->H->D round trip
+    void to_rou_evals(const ScalarField *coset_x, const ScalarField *coset_y, DeviceVec<ScalarField> &evals) const {
+        if (evals.len() < x_size * y_size) throw Error("Insufficient buffer length for to_rou_evals");
+        check(tkmk_bintt(poly.ptr(), x_size, y_size, TKMK_NTT_FORWARD, coset_x, coset_y, true, nullptr, evals.ptr()), "_biNTT");
+    }
+    DensePolynomialExt clone() const { return DensePolynomialExt(poly.clone(), x_size, y_size, x_degree, y_degree); }
+    std::vector<ScalarField> copy_coeffs() const { return poly.to_host(); }
+    ScalarField get_coeff(uint64_t ix, uint64_t iy) const {
+        if (!(ix <= x_size && iy <= y_size)) throw Error("The index at which to get a coefficient exceeds the coefficient size.");
+        ScalarField v;
+        poly.copy_to_host(&v, 1, ix * y_size + iy);
+        return v;
+    }
+    std::pair<int64_t, int64_t> degree() const { return {x_degree, y_degree}; }
+
+    // find_degree (mod.rs:1480-1515)
+    std::pair<int64_t, int64_t> find_degree() const {
+        int64_t xd, yd;
+        check(tkmk_poly_find_degree(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &xd, &yd, nullptr), "find_degree");
+        return {xd, yd};
+    }
+    // resize (mod.rs:1784-1806)
+    void resize(size_t target_x_size, size_t target_y_size) {
+        auto [nx, ny] = find_size_as_twopower(target_x_size, target_y_size);
+        if (x_size == nx && y_size == ny) return;
+        DeviceVec<ScalarField> dst(nx * ny);
+        check(tkmk_poly_place(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, dst.ptr(), (uint32_t)nx, (uint32_t)ny, 0, 0, nullptr), "resize");
+        poly = std::move(dst);
+        x_size = nx, y_size = ny;
+    }
+    // optimize_size (mod.rs:1808-1818)
+    void optimize_size() {
+        auto [xd, yd] = find_degree();
+        x_degree = xd, y_degree = yd;
+        if (xd + 1 == 0 || yd + 1 == 0) return;
+        resize((size_t)(xd + 1), (size_t)(yd + 1));
+    }
+    // mul_monomial (mod.rs:1820-1844)
+    DensePolynomialExt mul_monomial(size_t x_exponent, size_t y_exponent) const {
+        if (x_exponent == 0 && y_exponent == 0) return clone();
+        auto [nx, ny] = find_size_as_twopower((size_t)(x_degree + 1) + x_exponent, (size_t)(y_degree + 1) + y_exponent);
+        if (x_size + x_exponent > nx || y_size + y_exponent > ny) throw Error("mul_monomial: coefficient block does not fit the target");
+        DeviceVec<ScalarField> dst(nx * ny);
+        check(tkmk_poly_place(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, dst.ptr(), (uint32_t)nx, (uint32_t)ny, (uint32_t)x_exponent,
+                              (uint32_t)y_exponent, nullptr),
+              "mul_monomial");
+        return from_coeffs(std::move(dst), nx, ny);
+    }
+    // scale_coeffs_x / scale_coeffs_y (mod.rs:1553-1613)
+    DensePolynomialExt scale_coeffs(const ScalarField *fx, const ScalarField *fy) const {
+        DeviceVec<ScalarField> dst(x_size * y_size);
+        check(tkmk_poly_scale_coeffs(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, fx, fy, dst.ptr(), nullptr), "_scale_coeffs");
+        return from_coeffs(std::move(dst), x_size, y_size);
+    }
+    DensePolynomialExt scale_coeffs_x(const ScalarField &f) const { return scale_coeffs(&f, nullptr); }
+    DensePolynomialExt scale_coeffs_y(const ScalarField &f) const { return scale_coeffs(nullptr, &f); }
+    // eval_x / eval_y / eval (mod.rs:1719-1750)
+    DensePolynomialExt eval_x(const ScalarField &x) const {
+        DeviceVec<ScalarField> out(y_size);
+        check(tkmk_poly_eval_x(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &x, out.ptr(), nullptr), "eval_x");
+        return from_coeffs(std::move(out), 1, y_size);
+    }
+    DensePolynomialExt eval_y(const ScalarField &y) const {
+        DeviceVec<ScalarField> out(x_size);
+        check(tkmk_poly_eval_y(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &y, out.ptr(), nullptr), "eval_y");
+        return from_coeffs(std::move(out), x_size, 1);
+    }
+    ScalarField eval(const ScalarField &x, const ScalarField &y) const {
+        ScalarField r;
+        check(tkmk_poly_eval(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &x, &y, &r, nullptr), "eval");
+        return r;
+    }
+
+    // ---- arithmetic (mod.rs:532-1281): operands are brought to the common (max) shape first ----
+    static std::tuple<DensePolynomialExt, DensePolynomialExt> same_shape(const DensePolynomialExt &a, const DensePolynomialExt &b) {
+        size_t nx = std::max(a.x_size, b.x_size), ny = std::max(a.y_size, b.y_size);
+        DensePolynomialExt l = a.clone(), r = b.clone();
+        l.resize(nx, ny);
+        r.resize(nx, ny);
+        return {std::move(l), std::move(r)};
+    }
+    friend DensePolynomialExt operator+(const DensePolynomialExt &a, const DensePolynomialExt &b) {
+        auto [l, r] = same_shape(a, b);
+        tkmk_vecops_config c = dev_cfg();
+        check(bls12_381_vector_add(l.poly.ptr(), r.poly.ptr(), l.poly.len(), &c, l.poly.ptr()), "add");
+        return from_coeffs(std::move(l.poly), l.x_size, l.y_size);
+    }
+    friend DensePolynomialExt operator-(const DensePolynomialExt &a, const DensePolynomialExt &b) {
+        auto [l, r] = same_shape(a, b);
+        tkmk_vecops_config c = dev_cfg();
+        check(bls12_381_vector_sub(l.poly.ptr(), r.poly.ptr(), l.poly.len(), &c, l.poly.ptr()), "sub");
+        return from_coeffs(std::move(l.poly), l.x_size, l.y_size);
+    }
+    friend DensePolynomialExt operator*(const DensePolynomialExt &a, const ScalarField &s) {
+        DensePolynomialExt out = a.clone();
+        tkmk_vecops_config c = dev_cfg();
+        c.is_a_on_device = false;
+        check(bls12_381_scalar_mul_vec(&s, out.poly.ptr(), out.poly.len(), &c, out.poly.ptr()), "scalar_mul");
+        return from_coeffs(std::move(out.poly), out.x_size, out.y_size);
+    }
+    // _mul (mod.rs:1846-1996)
+    friend DensePolynomialExt operator*(const DensePolynomialExt &a, const DensePolynomialExt &b) {
+        auto [lx, ly] = a.find_degree();
+        auto [rx, ry] = b.find_degree();
+        if (lx + ly == 0 && rx + ry > 0) return b * a.get_coeff(0, 0);
+        if (rx + ry == 0 && lx + ly > 0) return a * b.get_coeff(0, 0);
+        if (rx + ry == 0 && lx + ly == 0) {
+            DensePolynomialExt one = a.clone();
+            one.resize(1, 1);
+            return one * b.get_coeff(0, 0);
+        }
+        size_t tx = (size_t)(lx + rx + 1), ty = (size_t)(ly + ry + 1);
+        DensePolynomialExt l = a.clone(), r = b.clone();
+        l.resize(tx, ty);
+        r.resize(tx, ty);
+        size_t xs = l.x_size, ys = l.y_size;
+        check(tkmk_bintt(l.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, l.poly.ptr()), "_biNTT");
+        check(tkmk_bintt(r.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, r.poly.ptr()), "_biNTT");
+        tkmk_vecops_config c = dev_cfg();
+        check(bls12_381_vector_mul(l.poly.ptr(), r.poly.ptr(), l.poly.len(), &c, l.poly.ptr()), "mul");
+        return from_rou_evals(l.poly, xs, ys);
+    }
+
+    // div_by_vanishing_opt (mod.rs:2284-2410)
+    std::pair<DensePolynomialExt, DensePolynomialExt> div_by_vanishing_opt(int64_t denom_x_degree, int64_t denom_y_degree) {
+        if (denom_x_degree <= 0 || denom_y_degree <= 0 || !is_pow2((size_t)denom_x_degree) || !is_pow2((size_t)denom_y_degree))
+            throw Error("The denominators must have degress as powers of two.");
+        optimize_size();
+        if (x_degree < denom_x_degree || y_degree < denom_y_degree) throw Error("The numerator must have grater degrees than denominators.");
+        size_t c = (size_t)denom_x_degree, d = (size_t)denom_y_degree;
+        size_t xs = (x_size / c) * c, ys = (y_size / d) * d;
+        DeviceVec<ScalarField> qx(xs * ys), qy(c * ys);
+        check(tkmk_poly_div_by_vanishing_opt(poly.ptr(), (uint32_t)xs, (uint32_t)ys, (uint32_t)c, (uint32_t)d, qx.ptr(), qy.ptr(), nullptr),
+              "div_by_vanishing_opt");
+        DensePolynomialExt quo_x = from_coeffs(std::move(qx), xs, ys), quo_y = from_coeffs(std::move(qy), c, ys);
+        if (xs > c) quo_x.x_degree = (int64_t)(xs - c) - 1, quo_x.y_degree = (int64_t)ys - 1;
+        else quo_x.x_degree = quo_x.y_degree = -1;
+        if (ys > d) quo_y.x_degree = (int64_t)c - 1, quo_y.y_degree = (int64_t)(ys - d) - 1;
+        else quo_y.x_degree = quo_y.y_degree = -1;
+        return {std::move(quo_x), std::move(quo_y)};
+    }
+    // div_by_ruffini (mod.rs:2412-2458)
+    std::tuple<DensePolynomialExt, DensePolynomialExt, ScalarField> div_by_ruffini(const ScalarField &x, const ScalarField &y) const {
+        DeviceVec<ScalarField> qx(x_size * y_size), qy(y_size);
+        ScalarField r;
+        check(tkmk_poly_div_by_ruffini(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &x, &y, qx.ptr(), qy.ptr(), &r, nullptr), "div_by_ruffini");
+        return {from_coeffs(std::move(qx), x_size, y_size), from_coeffs(std::move(qy), 1, y_size), r};
+    }
+};
+
+// ---- PolyExpr (mod.rs:141-436) ----
+class PolyExpr {
+  public:
+    enum Kind { Poly, Scalar, Add, Sub, Mul, Scale, MulXMinusOne, Sum };
+    Kind kind;
+    const DensePolynomialExt *leaf = nullptr;
+    ScalarField scalar_{};
+    std::vector<PolyExpr> kids;
+
+    static PolyExpr poly(const DensePolynomialExt &p) {
+        PolyExpr e{Poly};
+        e.leaf = &p;
+        return e;
+    }
+    static PolyExpr scalar(const ScalarField &s) {
+        PolyExpr e{Scalar};
+        e.scalar_ = s;
+        return e;
+    }
+    static PolyExpr add(PolyExpr l, PolyExpr r) { return binary(Add, std::move(l), std::move(r)); }
+    static PolyExpr sub(PolyExpr l, PolyExpr r) { return binary(Sub, std::move(l), std::move(r)); }
+    static PolyExpr mul(PolyExpr l, PolyExpr r) { return binary(Mul, std::move(l), std::move(r)); }
+    static PolyExpr scale(const ScalarField &s, PolyExpr e) {
+        PolyExpr out{Scale};
+        out.scalar_ = s;
+        out.kids.push_back(std::move(e));
+        return out;
+    }
+    static PolyExpr mul_x_minus_one(PolyExpr e) {
+        PolyExpr out{MulXMinusOne};
+        out.kids.push_back(std::move(e));
+        return out;
+    }
+    static PolyExpr weighted_sum(std::vector<std::pair<ScalarField, PolyExpr>> terms) {
+        PolyExpr out{Sum};
+        for (auto &t : terms) out.kids.push_back(scale(t.first, std::move(t.second)));
+        return out;
+    }
+
+    std::pair<int64_t, int64_t> degree_bound() const {
+        switch (kind) {
+            case Poly: return leaf->find_degree();
+            case Scalar: return fr_is_zero(scalar_) ? std::make_pair<int64_t, int64_t>(-1, -1) : std::make_pair<int64_t, int64_t>(0, 0);
+            case Add:
+            case Sub: {
+                auto l = kids[0].degree_bound(), r = kids[1].degree_bound();
+                return {std::max(l.first, r.first), std::max(l.second, r.second)};
+            }
+            case Mul: {
+                auto l = kids[0].degree_bound(), r = kids[1].degree_bound();
+                if (l.first < 0 || l.second < 0 || r.first < 0 || r.second < 0) return {-1, -1};
+                return {l.first + r.first, l.second + r.second};
+            }
+            case Scale: return fr_is_zero(scalar_) ? std::make_pair<int64_t, int64_t>(-1, -1) : kids[0].degree_bound();
+            case MulXMinusOne: {
+                auto d = kids[0].degree_bound();
+                if (d.first < 0 || d.second < 0) return {-1, -1};
+                return {d.first + 1, d.second};
+            }
+            default: {
+                std::pair<int64_t, int64_t> acc{-1, -1};
+                for (auto &k : kids) {
+                    auto d = k.degree_bound();
+                    acc = {std::max(acc.first, d.first), std::max(acc.second, d.second)};
+                }
+                return acc;
+            }
+        }
+    }
+    static size_t domain_size_for_degree(int64_t degree) { return degree < 0 ? 1 : next_pow2((size_t)degree + 1); }
+
+    DensePolynomialExt evaluate_fused() const {
+        auto d = degree_bound();
+        return evaluate_fused_with_domain(domain_size_for_degree(d.first), domain_size_for_degree(d.second));
+    }
+    DensePolynomialExt evaluate_fused_with_domain(size_t target_x_size, size_t target_y_size) const {
+        if (!is_pow2(target_x_size) || !is_pow2(target_y_size)) throw Error("Fused polynomial expression domains must be powers of two.");
+        auto d = degree_bound();
+        if (domain_size_for_degree(d.first) > target_x_size || domain_size_for_degree(d.second) > target_y_size)
+            throw Error("Fused polynomial expression domain is too small for the expression degree.");
+        std::map<const DensePolynomialExt *, std::shared_ptr<DeviceVec<ScalarField>>> cache;
+        DeviceVec<ScalarField> evals = on_domain(target_x_size, target_y_size, cache);
+        return DensePolynomialExt::from_rou_evals(evals, target_x_size, target_y_size);
+    }
+
+  private:
+    explicit PolyExpr(Kind k) : kind(k) {}
+    static PolyExpr binary(Kind k, PolyExpr l, PolyExpr r) {
+        PolyExpr e{k};
+        e.kids.push_back(std::move(l));
+        e.kids.push_back(std::move(r));
+        return e;
+    }
+    // every node returns a buffer it owns (leaf evaluations are copied out of the cache like the reference does)
+    DeviceVec<ScalarField> on_domain(size_t xs, size_t ys, std::map<const DensePolynomialExt *, std::shared_ptr<DeviceVec<ScalarField>>> &cache) const {
+        size_t n = xs * ys;
+        tkmk_vecops_config c = dev_cfg();
+        switch (kind) {
+            case Poly: {
+                auto it = cache.find(leaf);
+                if (it == cache.end()) {
+                    DensePolynomialExt r = leaf->clone();
+                    r.resize(xs, ys);
+                    check(tkmk_bintt(r.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, r.poly.ptr()), "_biNTT");
+                    it = cache.emplace(leaf, std::make_shared<DeviceVec<ScalarField>>(std::move(r.poly))).first;
+                }
+                return it->second->clone();
+            }
+            case Scalar: {
+                std::vector<ScalarField> v(n, scalar_);
+                return DeviceVec<ScalarField>::from_host(v);
+            }
+            case Add:
+            case Sub:
+            case Mul: {
+                DeviceVec<ScalarField> l = kids[0].on_domain(xs, ys, cache), r = kids[1].on_domain(xs, ys, cache);
+                auto fn = kind == Add ? bls12_381_vector_add : kind == Sub ? bls12_381_vector_sub : bls12_381_vector_mul;
+                check(fn(l.ptr(), r.ptr(), n, &c, l.ptr()), "fused pointwise");
+                return l;
+            }
+            case Scale: {
+                DeviceVec<ScalarField> e = kids[0].on_domain(xs, ys, cache);
+                if (fr_eq(scalar_, fr_from_u32(1))) return e;
+                c.is_a_on_device = false;
+                check(bls12_381_scalar_mul_vec(&scalar_, e.ptr(), n, &c, e.ptr()), "fused scale");
+                return e;
+            }
+            case MulXMinusOne: {
+                DeviceVec<ScalarField> e = kids[0].on_domain(xs, ys, cache);
+                check(tkmk_poly_mul_x_minus_one_evals(e.ptr(), (uint32_t)xs, (uint32_t)ys, e.ptr(), nullptr), "fused x-1");
+                return e;
+            }
+            default: {
+                std::vector<ScalarField> z(n);
+                DeviceVec<ScalarField> acc = DeviceVec<ScalarField>::from_host(z);
+                for (auto &k : kids) {
+                    DeviceVec<ScalarField> t = k.on_domain(xs, ys, cache);
+                    check(bls12_381_vector_add(acc.ptr(), t.ptr(), n, &c, acc.ptr()), "fused sum");
+                }
+                return acc;
+            }
+        }
+    }
+};
+
+// ---- Sigma1 with a device-resident xy_powers table: encode_poly (iotools/mod.rs:2033-2113) ----
+class Sigma1 {
+    DeviceVec<G1Affine> xy_powers_;
+    size_t rs_x_, rs_y_;
+
+  public:
+    // xy_powers[i*rs_y + j] = [tau_x^i tau_y^j]G;  rs_x = max(2n, 2(l_D - l)), rs_y = 2 s_max
+    Sigma1(DeviceVec<G1Affine> &&xy_powers, size_t rs_x_size, size_t rs_y_size) : xy_powers_(std::move(xy_powers)), rs_x_(rs_x_size), rs_y_(rs_y_size) {
+        if (xy_powers_.len() != rs_x_ * rs_y_) throw Error("xy_powers has the wrong length");
+    }
+    // -> affine commitment; (0,0) = G1serde::zero()
+    G1Affine encode_poly(DensePolynomialExt &poly) const {
+        poly.optimize_size();
+        size_t tx = (size_t)(poly.x_degree + 1), ty = (size_t)(poly.y_degree + 1);
+        if (tx > rs_x_ || ty > rs_y_) throw Error("Insufficient length of sigma.sigma_1.xy_powers");
+        G1Affine out{};
+        if (tx * ty == 0) return out;
+        DeviceVec<ScalarField> scalars(tx * ty);
+        DeviceVec<G1Affine> bases(tx * ty);
+        check(tkmk_memcpy_2d_d2d(scalars.ptr(), 32 * ty, poly.poly.ptr(), 32 * poly.y_size, 32 * ty, tx), "encode_poly gather");
+        check(tkmk_memcpy_2d_d2d(bases.ptr(), 96 * ty, xy_powers_.ptr(), 96 * rs_y_, 96 * ty, tx), "encode_poly gather");
+        tkmk_msm_config cfg = tkmk_msm_default_config();
+        cfg.are_scalars_on_device = cfg.are_points_on_device = true;
+        tkmk_g1_projective res;
+        check(bls12_381_msm(scalars.ptr(), bases.ptr(), (int)(tx * ty), &cfg, &res), "msm::msm");
+        bool inf = true;
+        for (uint32_t l : res.z.limbs) inf &= l == 0;
+        if (!inf) out.x = res.x, out.y = res.y;  // canonical (x, y, 1): dropping z is G1Affine::from(projective)
+        return out;
+    }
+};
+
+}  // namespace tkmk
