@@ -121,6 +121,19 @@ tkmk_msm_config tkmk_msm_default_config(void);            /* MSMConfig::default(
 tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *bases, int msm_size,
                          const tkmk_msm_config *cfg, tkmk_g1_projective *results);
 
+/* Several independent MSMs (own scalars, own bases, own size) in one call, e.g. the commits the prover issues
+ * between two transcript challenges (prove/src/lib.rs prove0..prove4 call encode_poly back to back on
+ * polynomials that do not depend on each other).  The jobs are pipelined over internal HIP streams so that one
+ * job's latency-bound bucket reduction overlaps the next job's sort and accumulation; results[j] is exactly what
+ * bls12_381_msm would return for job j.  cfg->batch_size must be 1; the *_on_device / *_montgomery_form flags
+ * apply to every job.  A bls12_381_msm call with batch_size > 1 uses the same pipeline. */
+typedef struct {
+    const tkmk_fr *scalars;
+    const tkmk_g1_affine *bases;
+    int msm_size;
+} tkmk_msm_job;
+tkmk_error tkmk_msm_multi(const tkmk_msm_job *jobs, int n_jobs, const tkmk_msm_config *cfg, tkmk_g1_projective *results);
+
 /* ---------------------------------------------------------------------------------------------
  * NTT — replaces icicle_core::ntt::{ntt, initialize_domain, release_domain, get_root_of_unity}
  * (extern "C" bls12_381_ntt, _ntt_init_domain, _ntt_release_domain, _get_root_of_unity) as called at

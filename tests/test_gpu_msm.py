@@ -187,3 +187,42 @@ def test_msm_two_pass_sort_wide_windows(gpu, oracle, c):
     p = gpu.g1_batch_scalar_mul_device(h, oracle.g1_generator(), n)
     want = oracle.g1_msm(s.to_host(), p.to_host())
     assert (_msm_affine(gpu, s, p, c=c) == want).all()
+
+
+def test_msm_multi_matches_single_calls(gpu, oracle):
+    # tkmk_msm_multi: independent jobs of ragged sizes (incl. 0 and 1) pipelined over internal streams; every
+    # result must equal the oracle's and the single-call result; more jobs than streams exercises slot reuse
+    sizes = [700, 0, 1, 33, 5000, 2, 1200, 64, 3000]
+    jobs, want = [], []
+    for k, n in enumerate(sizes):
+        s = oracle.fr_random(300 + k, n) if n else np.zeros(0, np.uint8)
+        p = oracle.g1_random_bases(400 + k, n) if n else np.zeros(0, np.uint8)
+        jobs.append((s, p, n))
+        want.append(oracle.g1_msm(s, p) if n else np.zeros(96, np.uint8))
+    got = gpu.projective_to_affine_bytes(gpu.msm_multi(jobs))
+    for k in range(len(sizes)):
+        assert (got[96 * k:96 * (k + 1)] == want[k]).all(), f"job {k} (n={sizes[k]})"
+    # device-resident inputs, twice in a row (arena reuse on the internal streams)
+    dev_jobs = [(gpu.DeviceBuffer.from_host(s), gpu.DeviceBuffer.from_host(p), n) for s, p, n in jobs if n >= 2]
+    ref = [w for w, n in zip(want, sizes) if n >= 2]
+    for _ in range(2):
+        got = gpu.projective_to_affine_bytes(gpu.msm_multi(dev_jobs))
+        for k in range(len(dev_jobs)):
+            assert (got[96 * k:96 * (k + 1)] == ref[k]).all()
+
+
+def test_msm_batch_pipeline_large(gpu, oracle):
+    # batch_size > 1 goes through the same pipeline; 2^18 points takes the two-pass sort on every stream
+    n, batch = 1 << 18, 4
+    sd = gpu.fr_random_device(91, n * batch)
+    base = oracle.g1_generator()
+    k = gpu.fr_random_device(92, n)
+    pd = gpu.g1_batch_scalar_mul_device(k, base, n)
+    got = gpu.projective_to_affine_bytes(gpu.msm(sd, pd, msm_size=n, batch=batch, shared_points=True))
+    # Σ s_i·(k_i·G) = (Σ s_i·k_i)·G: check against the device dot product
+    kk = oracle.to_ints(k.to_host(), 32)
+    sh = sd.to_host()
+    for b in range(batch):
+        sv = oracle.to_ints(sh[32 * n * b:32 * n * (b + 1)], 32)
+        dot = sum(x * y for x, y in zip(sv, kk)) % oracle.R_MOD
+        assert (got[96 * b:96 * (b + 1)] == oracle.g1_scalar_mul(oracle.to_bytes([dot], 32), base.copy())).all()

@@ -20,6 +20,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -659,10 +661,12 @@ static tkmk_error msm_debug_check(const msm_plan_t &pl, const fr_t *scalars, con
     return TKMK_SUCCESS;
 }
 
-// One MSM of n points with device-resident scalars / Montgomery bases -> host XYZZ window sums -> result.
-static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, uint32_t n, uint32_t c_req, uint32_t bits,
-                          bool scalars_mont, hipStream_t s, g1_xyzz_t *result_host) {
-    tk_frame frame(s);
+// Enqueues one MSM of n points (device-resident scalars / converted bases) on stream s, ending with the
+// async copy of the W window sums into wins_host (>= MSM_MAX_WINDOWS entries; pinned memory keeps the copy
+// asynchronous).  Scratch comes from the caller's tk_frame on s, which must stay open until s has drained.
+#define MSM_MAX_WINDOWS 128
+static tkmk_error msm_enqueue(const fr_t *scalars, const g1_affine_t *bases_mont, uint32_t n, uint32_t c_req, uint32_t bits,
+                              bool scalars_mont, hipStream_t s, g1_xyzz_t *wins_host, msm_plan_t *plan_out) {
     msm_plan_t pl;
     pl.n = n;
     pl.bits = bits;
@@ -788,18 +792,132 @@ static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, ui
                 (size_t)pl.W * segs * sizeof(g1_xyzz_t), d_wins.p);
     if (getenv("TKMK_MSM_DEBUG")) TK_TRY(msm_debug_check(pl, scalars, bases_mont, d_dig.as<uint32_t>(), d_sorted.as<uint32_t>(),
                                                           d_bstart.as<uint32_t>(), d_buckets.as<g1_xyzz_t>(), s));
-    std::vector<g1_xyzz_t> wins(pl.W);
-    TK_HIP(hipMemcpyAsync(wins.data(), d_wins.p, pl.W * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, s));
-    TK_HIP(hipStreamSynchronize(s));
+    TK_HIP(hipMemcpyAsync(wins_host, d_wins.p, pl.W * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, s));
     prof.finish();
-    // Horner over windows on the host: acc = 2^c * acc + W_w
+    *plan_out = pl;
+    return TKMK_SUCCESS;
+}
+
+// Horner over the window sums on the host: acc = 2^c * acc + W_w
+static g1_xyzz_t msm_horner(const msm_plan_t &pl, const g1_xyzz_t *wins) {
     g1_xyzz_t acc = G1::inf();
     for (int w = (int)pl.W - 1; w >= 0; w--) {
         for (uint32_t k = 0; k < pl.c; k++) acc = G1::dbl(acc);
         acc = G1::add(acc, wins[w]);
     }
-    *result_host = acc;
+    return acc;
+}
+
+// One MSM, synchronous on s.
+static tkmk_error msm_one(const fr_t *scalars, const g1_affine_t *bases_mont, uint32_t n, uint32_t c_req, uint32_t bits,
+                          bool scalars_mont, hipStream_t s, g1_xyzz_t *result_host) {
+    tk_frame frame(s);
+    g1_xyzz_t wins[MSM_MAX_WINDOWS];
+    msm_plan_t pl;
+    TK_TRY(msm_enqueue(scalars, bases_mont, n, c_req, bits, scalars_mont, s, wins, &pl));
+    TK_HIP(hipStreamSynchronize(s));
+    *result_host = msm_horner(pl, wins);
     return TKMK_SUCCESS;
+}
+
+// ---- pipelined independent MSMs -------------------------------------------------------------------
+// The tail of one MSM (combine, bucket reduction: a few thousand threads of serial EC adds) is latency-bound
+// and leaves most CUs idle; the prover's commits are 2^20..2^22 points, where that tail is 20-35 % of the call.
+// Independent MSMs therefore run round-robin on a few internal streams (each with its own scratch arena), so
+// one job's tail overlaps the next job's sort/accumulate; the host Horner of job i overlaps job i+1's kernels.
+struct msm_slot {
+    hipStream_t s = nullptr;
+    hipEvent_t done = nullptr;
+    g1_xyzz_t *wins = nullptr;  // pinned
+    tk_frame *frame = nullptr;
+    msm_plan_t pl;
+    int job = -1;
+};
+struct msm_pipe_job {
+    const fr_t *scalars;          // device
+    const g1_affine_t *bases;     // device; converted form if !convert
+    uint32_t n;
+    bool convert, bases_mont;
+};
+static std::mutex g_pipe_mu;
+static std::vector<msm_slot> g_slots;
+
+static tkmk_error msm_pipe_slots(uint32_t want) {
+    while (g_slots.size() < want) {
+        msm_slot sl;
+        TK_HIP(hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking));
+        TK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        TK_HIP(hipHostMalloc((void **)&sl.wins, MSM_MAX_WINDOWS * sizeof(g1_xyzz_t), hipHostMallocDefault));
+        g_slots.push_back(sl);
+    }
+    return TKMK_SUCCESS;
+}
+
+static tkmk_error msm_pipe_finish(msm_slot &sl, g1_xyzz_t *results) {
+    if (sl.job < 0) return TKMK_SUCCESS;
+    hipError_t e = hipEventSynchronize(sl.done);
+    delete sl.frame;
+    sl.frame = nullptr;
+    int j = sl.job;
+    sl.job = -1;
+    TK_HIP(e);
+    results[j] = msm_horner(sl.pl, sl.wins);
+    return TKMK_SUCCESS;
+}
+
+static tkmk_error msm_pipeline(const std::vector<msm_pipe_job> &jobs, uint32_t c_req, uint32_t bits, bool scalars_mont,
+                               hipStream_t caller, g1_xyzz_t *results) {
+    std::lock_guard<std::mutex> lk(g_pipe_mu);
+    static const uint32_t n_streams = [] {
+        const char *e = getenv("TKMK_MSM_STREAMS");
+        int v = e ? atoi(e) : 3;
+        return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v);
+    }();
+    const uint32_t K = jobs.size() < n_streams ? (uint32_t)jobs.size() : n_streams;
+    TK_TRY(msm_pipe_slots(K));
+    // work queued on the caller's stream (input uploads, shared-bases conversion) happens-before every job
+    hipEvent_t ready;
+    TK_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    TK_HIP(hipEventRecord(ready, caller));
+    tkmk_error err = TKMK_SUCCESS;
+    for (size_t j = 0; j < jobs.size() && err == TKMK_SUCCESS; j++) {
+        msm_slot &sl = g_slots[j % K];
+        err = msm_pipe_finish(sl, results);
+        if (err != TKMK_SUCCESS) break;
+        const msm_pipe_job &jb = jobs[j];
+        if (j < K) {
+            hipError_t e = hipStreamWaitEvent(sl.s, ready, 0);
+            if (e != hipSuccess) { err = TKMK_ERR_UNKNOWN; break; }
+        }
+        sl.frame = new tk_frame(sl.s);
+        sl.job = (int)j;
+        const g1_affine_t *bm = jb.bases;
+        if (jb.convert) {
+            tk_scratch d_bm;
+            err = d_bm.alloc((size_t)jb.n * 96, sl.s);
+            if (err != TKMK_SUCCESS) break;
+            hipLaunchKernelGGL(k_convert_bases, tk_div_up(jb.n, 256), 256, 0, sl.s, jb.bases, d_bm.as<g1_affine_t>(), (uint64_t)jb.n,
+                               jb.bases_mont ? 1 : 0);
+            bm = d_bm.as<g1_affine_t>();
+        }
+        err = msm_enqueue(jb.scalars, bm, jb.n, c_req, bits, scalars_mont, sl.s, sl.wins, &sl.pl);
+        if (err != TKMK_SUCCESS) break;
+        if (hipEventRecord(sl.done, sl.s) != hipSuccess) err = TKMK_ERR_UNKNOWN;
+    }
+    // drain in job order (also on error, so no frame outlives its kernels)
+    {
+        std::vector<msm_slot *> live;
+        for (auto &sl : g_slots)
+            if (sl.job >= 0) live.push_back(&sl);
+        std::sort(live.begin(), live.end(), [](msm_slot *a, msm_slot *b) { return a->job < b->job; });
+        for (msm_slot *sl : live) {
+            if (err != TKMK_SUCCESS) (void)hipStreamSynchronize(sl->s);
+            tkmk_error e2 = msm_pipe_finish(*sl, results);
+            if (err == TKMK_SUCCESS) err = e2;
+        }
+    }
+    (void)hipEventDestroy(ready);
+    return err;
 }
 
 TK_API tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *bases, int msm_size, const tkmk_msm_config *cfg,
@@ -847,11 +965,18 @@ TK_API tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *ba
                 TK_HIP(hipGetLastError());
             }
             const g1_affine_t *bm = d_bm.as<g1_affine_t>();
-            for (uint32_t b = 0; b < batch; b++) {
+            if (batch == 1) {
                 g1_xyzz_t r;
-                TK_TRY(msm_one((const fr_t *)S.dev + (size_t)b * n, bm + (cfg->are_points_shared_in_batch ? 0 : (size_t)b * n), n,
-                               (uint32_t)cfg->c, bits, cfg->are_scalars_montgomery_form, s, &r));
-                store_canonical(&host_res[b], r);
+                TK_TRY(msm_one((const fr_t *)S.dev, bm, n, (uint32_t)cfg->c, bits, cfg->are_scalars_montgomery_form, s, &r));
+                store_canonical(&host_res[0], r);
+            } else {
+                std::vector<msm_pipe_job> jobs(batch);
+                for (uint32_t b = 0; b < batch; b++)
+                    jobs[b] = {(const fr_t *)S.dev + (size_t)b * n, bm + (cfg->are_points_shared_in_batch ? 0 : (size_t)b * n), n, false,
+                               false};
+                std::vector<g1_xyzz_t> r(batch);
+                TK_TRY(msm_pipeline(jobs, (uint32_t)cfg->c, bits, cfg->are_scalars_montgomery_form, s, r.data()));
+                for (uint32_t b = 0; b < batch; b++) store_canonical(&host_res[b], r[b]);
             }
         }
     }
@@ -860,6 +985,55 @@ TK_API tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *ba
         TK_HIP(hipStreamSynchronize(s));
     } else {
         for (uint32_t b = 0; b < batch; b++) results[b] = host_res[b];
+    }
+    return TKMK_SUCCESS;
+}
+
+// Independent MSMs of different sizes / bases in one call (the prover's commits between two transcript
+// challenges), pipelined over internal streams.  cfg's *_on_device / *_montgomery_form flags apply to every job;
+// cfg->batch_size must be 1.
+TK_API tkmk_error tkmk_msm_multi(const tkmk_msm_job *jobs, int n_jobs, const tkmk_msm_config *cfg, tkmk_g1_projective *results) {
+    if (!cfg || cfg->ext || cfg->batch_size != 1 || n_jobs < 0) return TKMK_ERR_INVALID_ARGUMENT;
+    if (cfg->precompute_factor > 1) return TKMK_ERR_API_NOT_IMPLEMENTED;
+    if (cfg->bitsize < 0 || cfg->bitsize > 255 || cfg->c < 0 || cfg->c > 18) return TKMK_ERR_INVALID_ARGUMENT;
+    if (n_jobs == 0) return TKMK_SUCCESS;
+    if (!jobs || !results) return TKMK_ERR_INVALID_POINTER;
+    TK_TRY(tk_require_device());
+    const uint32_t bits = cfg->bitsize ? (uint32_t)cfg->bitsize : 255u;
+    hipStream_t s = tk_stream(cfg->stream_handle);
+    tk_frame frame(s);
+    std::vector<tkmk_g1_projective> host_res(n_jobs);
+    std::vector<msm_pipe_job> pj;
+    std::vector<int> pj_index;
+    std::vector<tk_staged> staged((size_t)n_jobs * 2);
+    for (int j = 0; j < n_jobs; j++) {
+        if (jobs[j].msm_size < 0) return TKMK_ERR_INVALID_ARGUMENT;
+        if (jobs[j].msm_size > 0 && (!jobs[j].scalars || !jobs[j].bases)) return TKMK_ERR_INVALID_POINTER;
+    }
+    for (int j = 0; j < n_jobs; j++) {
+        const uint32_t n = (uint32_t)jobs[j].msm_size;
+        if (n < 2) {  // empty sum / single scalar multiplication: the plain entry point handles both
+            tkmk_msm_config c1 = *cfg;
+            c1.are_results_on_device = false;
+            TK_TRY(bls12_381_msm(jobs[j].scalars, jobs[j].bases, (int)n, &c1, &host_res[j]));
+            continue;
+        }
+        tk_staged &S = staged[2 * j], &P = staged[2 * j + 1];
+        TK_TRY(S.in(jobs[j].scalars, (size_t)n * 32, cfg->are_scalars_on_device, s));
+        TK_TRY(P.in(jobs[j].bases, (size_t)n * 96, cfg->are_points_on_device, s));
+        pj.push_back({(const fr_t *)S.dev, (const g1_affine_t *)P.dev, n, true, cfg->are_points_montgomery_form});
+        pj_index.push_back(j);
+    }
+    if (!pj.empty()) {
+        std::vector<g1_xyzz_t> r(pj.size());
+        TK_TRY(msm_pipeline(pj, (uint32_t)cfg->c, bits, cfg->are_scalars_montgomery_form, s, r.data()));
+        for (size_t k = 0; k < pj.size(); k++) store_canonical(&host_res[pj_index[k]], r[k]);
+    }
+    if (cfg->are_results_on_device) {
+        TK_HIP(hipMemcpyAsync(results, host_res.data(), (size_t)n_jobs * sizeof(tkmk_g1_projective), hipMemcpyHostToDevice, s));
+        TK_HIP(hipStreamSynchronize(s));
+    } else {
+        for (int j = 0; j < n_jobs; j++) results[j] = host_res[j];
     }
     return TKMK_SUCCESS;
 }

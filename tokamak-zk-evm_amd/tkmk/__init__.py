@@ -82,7 +82,7 @@ SYMBOLS = [
     "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
     "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
     "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
-    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm",
+    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm", "tkmk_msm_multi",
     "tkmk_ntt_default_config", "bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain",
     "bls12_381_ntt", "tkmk_bintt", "tkmk_vecops_default_config", "bls12_381_vector_add", "bls12_381_vector_sub",
     "bls12_381_vector_mul", "bls12_381_vector_div", "bls12_381_vector_inv", "bls12_381_scalar_add_vec",
@@ -335,6 +335,34 @@ def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize
     cfg.stream_handle = stream
     out = np.empty(144 * batch, np.uint8)
     _check(lib().bls12_381_msm(_p(scalars), _p(bases), int(n), ctypes.byref(cfg), _p(out)), "bls12_381_msm")
+    return out
+
+
+class MsmJob(ctypes.Structure):
+    _fields_ = [("scalars", ctypes.c_void_p), ("bases", ctypes.c_void_p), ("msm_size", ctypes.c_int)]
+
+
+def msm_multi(jobs, c=0, bitsize=0, stream=None):
+    """jobs = [(scalars, bases[, msm_size])...], all host buffers or all DeviceBuffers; returns len(jobs) projective
+    results (144 B each) on the host.  Independent MSMs are pipelined over internal streams (tkmk_msm_multi)."""
+    cfg = lib().tkmk_msm_default_config()
+    if not jobs:
+        return np.empty(0, np.uint8)
+    on_dev_s = {_on_dev(j[0]) for j in jobs}
+    on_dev_p = {_on_dev(j[1]) for j in jobs}
+    if len(on_dev_s) != 1 or len(on_dev_p) != 1:
+        raise ValueError("msm_multi: every job's scalars (and every job's bases) must live on the same side")
+    cfg.are_scalars_on_device = on_dev_s.pop()
+    cfg.are_points_on_device = on_dev_p.pop()
+    cfg.c = c
+    cfg.bitsize = bitsize
+    cfg.stream_handle = stream
+    arr = (MsmJob * len(jobs))()
+    for k, j in enumerate(jobs):
+        n = j[2] if len(j) > 2 else _len(j[0])
+        arr[k] = MsmJob(_p(j[0]).value, _p(j[1]).value, int(n))
+    out = np.empty(144 * len(jobs), np.uint8)
+    _check(lib().tkmk_msm_multi(arr, len(jobs), ctypes.byref(cfg), _p(out)), "tkmk_msm_multi")
     return out
 
 
