@@ -92,6 +92,10 @@ int main(int argc, char **argv) {
         DensePolynomialExt Z = DensePolynomialExt::from_coeffs(std::vector<ScalarField>(4), 2, 2);
         G1Affine cz = sigma.encode_poly(Z);
         emit(92, &cz, sizeof cz);
+        // the same two commits plus B's through the pipelined multi-commit call
+        DensePolynomialExt A2 = A.clone(), Z2 = DensePolynomialExt::from_coeffs(std::vector<ScalarField>(4), 2, 2), B2 = B.clone();
+        std::vector<G1Affine> many = sigma.encode_polys({&A2, &Z2, &B2});
+        emit(94, many.data(), many.size() * sizeof(G1Affine));
         // error behaviour: the reference panics, the mirror throws
         uint32_t threw = 0;
         try {

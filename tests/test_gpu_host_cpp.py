@@ -96,4 +96,8 @@ def test_cpp_host_mirror_against_oracle(gpu, oracle, tmp_path):
     val = oracle.poly_eval(a, xs, ys, oracle.to_bytes([tx], 32), oracle.to_bytes([ty], 32))
     assert (np.frombuffer(rec[90], np.uint8) == oracle.g1_scalar_mul(val, g)).all()
     assert not np.frombuffer(rec[92], np.uint8).any()
+    many = np.frombuffer(rec[94], np.uint8)                # encode_polys({A, 0, B})
+    valb = oracle.poly_eval(b, bxs, bys, oracle.to_bytes([tx], 32), oracle.to_bytes([ty], 32))
+    assert (many[:96] == oracle.g1_scalar_mul(val, g)).all() and not many[96:192].any()
+    assert (many[192:] == oracle.g1_scalar_mul(valb, g)).all()
     assert struct.unpack("<I", rec[99])[0] == 7          # the three misuse cases raised tkmk::Error

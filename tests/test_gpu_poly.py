@@ -165,6 +165,14 @@ def test_encode_poly_commit_identity(P, gpu, oracle):
     assert (sigma.encode_poly(P.from_coeffs(np.zeros(32 * 16, np.uint8), 4, 4)) == 0).all()
     with pytest.raises(ValueError):
         sigma.encode_poly(P.from_coeffs(oracle.fr_random(3, 64 * 16), 64, 16))
+    # several independent commits in one pipelined call (incl. a zero polynomial) == the one-by-one results
+    shapes = ((32, 16, 31, 15), (32, 16, 20, 9), (4, 4, -1, -1), (64, 32, 17, 3), (32, 16, 5, 15))
+    ms = [np.zeros(32 * xs * ys, np.uint8) if xd < 0 else _sparse_box(oracle, 7 * xs + xd, xs, ys, xd, yd) for xs, ys, xd, yd in shapes]
+    many = sigma.encode_polys([P.from_coeffs(m, sh[0], sh[1]) for m, sh in zip(ms, shapes)])
+    for m, sh, cm in zip(ms, shapes, many):
+        assert (cm == sigma.encode_poly(P.from_coeffs(m, sh[0], sh[1]))).all()
+        assert (cm == oracle.g1_scalar_mul(oracle.poly_eval(m, sh[0], sh[1], TX, TY), g)).all() or sh[2] < 0
+    assert (many[2] == 0).all()
 
 
 def test_polyexpr_fused_equals_coefficient_route(P, gpu, oracle):

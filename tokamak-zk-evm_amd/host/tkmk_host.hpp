@@ -467,24 +467,57 @@ class Sigma1 {
     Sigma1(DeviceVec<G1Affine> &&xy_powers, size_t rs_x_size, size_t rs_y_size) : xy_powers_(std::move(xy_powers)), rs_x_(rs_x_size), rs_y_(rs_y_size) {
         if (xy_powers_.len() != rs_x_ * rs_y_) throw Error("xy_powers has the wrong length");
     }
-    // -> affine commitment; (0,0) = G1serde::zero()
-    G1Affine encode_poly(DensePolynomialExt &poly) const {
+  private:
+    struct Gathered {
+        DeviceVec<ScalarField> scalars;
+        DeviceVec<G1Affine> bases;
+        size_t n;
+    };
+    // compact coefficient box + matching CRS rows of one commit (empty for the zero polynomial)
+    std::unique_ptr<Gathered> gather(DensePolynomialExt &poly) const {
         poly.optimize_size();
         size_t tx = (size_t)(poly.x_degree + 1), ty = (size_t)(poly.y_degree + 1);
         if (tx > rs_x_ || ty > rs_y_) throw Error("Insufficient length of sigma.sigma_1.xy_powers");
+        if (tx * ty == 0) return nullptr;
+        std::unique_ptr<Gathered> g(new Gathered{DeviceVec<ScalarField>(tx * ty), DeviceVec<G1Affine>(tx * ty), tx * ty});
+        check(tkmk_memcpy_2d_d2d(g->scalars.ptr(), 32 * ty, poly.poly.ptr(), 32 * poly.y_size, 32 * ty, tx), "encode_poly gather");
+        check(tkmk_memcpy_2d_d2d(g->bases.ptr(), 96 * ty, xy_powers_.ptr(), 96 * rs_y_, 96 * ty, tx), "encode_poly gather");
+        return g;
+    }
+    static G1Affine to_affine(const tkmk_g1_projective &res) {
         G1Affine out{};
-        if (tx * ty == 0) return out;
-        DeviceVec<ScalarField> scalars(tx * ty);
-        DeviceVec<G1Affine> bases(tx * ty);
-        check(tkmk_memcpy_2d_d2d(scalars.ptr(), 32 * ty, poly.poly.ptr(), 32 * poly.y_size, 32 * ty, tx), "encode_poly gather");
-        check(tkmk_memcpy_2d_d2d(bases.ptr(), 96 * ty, xy_powers_.ptr(), 96 * rs_y_, 96 * ty, tx), "encode_poly gather");
-        tkmk_msm_config cfg = tkmk_msm_default_config();
-        cfg.are_scalars_on_device = cfg.are_points_on_device = true;
-        tkmk_g1_projective res;
-        check(bls12_381_msm(scalars.ptr(), bases.ptr(), (int)(tx * ty), &cfg, &res), "msm::msm");
         bool inf = true;
         for (uint32_t l : res.z.limbs) inf &= l == 0;
         if (!inf) out.x = res.x, out.y = res.y;  // canonical (x, y, 1): dropping z is G1Affine::from(projective)
+        return out;
+    }
+
+  public:
+    // -> affine commitment; (0,0) = G1serde::zero()
+    G1Affine encode_poly(DensePolynomialExt &poly) const {
+        auto g = gather(poly);
+        if (!g) return G1Affine{};
+        tkmk_msm_config cfg = tkmk_msm_default_config();
+        cfg.are_scalars_on_device = cfg.are_points_on_device = true;
+        tkmk_g1_projective res;
+        check(bls12_381_msm(g->scalars.ptr(), g->bases.ptr(), (int)g->n, &cfg, &res), "msm::msm");
+        return to_affine(res);
+    }
+    // commitments of independent polynomials in one pipelined call (tkmk_msm_multi)
+    std::vector<G1Affine> encode_polys(const std::vector<DensePolynomialExt *> &polys) const {
+        std::vector<std::unique_ptr<Gathered>> g;
+        std::vector<tkmk_msm_job> jobs;
+        for (DensePolynomialExt *p : polys) {
+            g.push_back(gather(*p));
+            if (g.back()) jobs.push_back({g.back()->scalars.ptr(), g.back()->bases.ptr(), (int)g.back()->n});
+        }
+        tkmk_msm_config cfg = tkmk_msm_default_config();
+        cfg.are_scalars_on_device = cfg.are_points_on_device = true;
+        std::vector<tkmk_g1_projective> res(jobs.size());
+        check(tkmk_msm_multi(jobs.data(), (int)jobs.size(), &cfg, res.data()), "tkmk_msm_multi");
+        std::vector<G1Affine> out;
+        size_t k = 0;
+        for (auto &gi : g) out.push_back(gi ? to_affine(res[k++]) : G1Affine{});
         return out;
     }
 };

@@ -22,14 +22,14 @@ class Sigma1:
         self.xy_powers = xy_powers if isinstance(xy_powers, tkmk.DeviceBuffer) else tkmk.DeviceBuffer.from_host(xy_powers)
         self.rs_x_size, self.rs_y_size = rs_x_size, rs_y_size
 
-    def encode_poly(self, poly: DensePolynomialExt):
-        """-> 96-byte affine commitment (G1serde); all-zero = G1serde::zero()"""
+    def _gather(self, poly: DensePolynomialExt):
+        """(scalars, bases, n) of the commit MSM for `poly`, or None for the zero polynomial"""
         poly.optimize_size()
         tx, ty = poly.x_degree + 1, poly.y_degree + 1
         if tx > self.rs_x_size or ty > self.rs_y_size:
             raise ValueError("Insufficient length of sigma.sigma_1.xy_powers")
         if tx * ty == 0:
-            return np.zeros(96, np.uint8)
+            return None
         # compact (tx x ty) scalar box and the matching CRS sub-grid, both gathered on the device
         scalars = tkmk.DeviceBuffer(32 * tx * ty)
         bases = tkmk.DeviceBuffer(96 * tx * ty)
@@ -38,4 +38,26 @@ class Sigma1:
                                            ctypes.c_size_t(32 * ty), ctypes.c_size_t(tx)), "tkmk_memcpy_2d_d2d")
         tkmk._check(lib.tkmk_memcpy_2d_d2d(tkmk._p(bases), ctypes.c_size_t(96 * ty), tkmk._p(self.xy_powers), ctypes.c_size_t(96 * self.rs_y_size),
                                            ctypes.c_size_t(96 * ty), ctypes.c_size_t(tx)), "tkmk_memcpy_2d_d2d")
-        return tkmk.projective_to_affine_bytes(tkmk.msm(scalars, bases))
+        return scalars, bases, tx * ty
+
+    def encode_poly(self, poly: DensePolynomialExt):
+        """-> 96-byte affine commitment (G1serde); all-zero = G1serde::zero()"""
+        job = self._gather(poly)
+        if job is None:
+            return np.zeros(96, np.uint8)
+        return tkmk.projective_to_affine_bytes(tkmk.msm(job[0], job[1]))
+
+    def encode_polys(self, polys):
+        """commitments of several independent polynomials (e.g. prove0's U, V, W, Q_AX, Q_AY, B:
+        prove/src/lib.rs prove0) in one pipelined tkmk_msm_multi call -> [96-byte affine, ...]"""
+        jobs = [self._gather(p) for p in polys]
+        live = [j for j in jobs if j is not None]
+        res = tkmk.projective_to_affine_bytes(tkmk.msm_multi(live)) if live else np.zeros(0, np.uint8)
+        out, k = [], 0
+        for j in jobs:
+            if j is None:
+                out.append(np.zeros(96, np.uint8))
+            else:
+                out.append(res[96 * k:96 * (k + 1)].copy())
+                k += 1
+        return out
