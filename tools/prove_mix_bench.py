@@ -34,6 +34,19 @@ crs = tkmk.g1_batch_scalar_mul_device(h, g, rs_x * rs_y)
 sigma = Sigma1(crs, rs_x, rs_y)
 
 
+MULTI = "--sequential-commits" not in sys.argv     # default: independent commits of one round go through tkmk_msm_multi
+
+
+def commits(shapes, seed):
+    """the encode_poly MSMs of one round: scalars of each shape against the resident CRS"""
+    scal = [tkmk.fr_random_device(seed, xs * ys) for xs, ys in shapes]
+    if MULTI:
+        tkmk.msm_multi([(sc, crs, xs * ys) for sc, (xs, ys) in zip(scal, shapes)])
+    else:
+        for sc, (xs, ys) in zip(scal, shapes):
+            tkmk.msm(sc, crs, msm_size=xs * ys)
+
+
 def run():
     t = {}
     def tick(name, t0):
@@ -48,8 +61,7 @@ def run():
     polys = [P.from_rou_evals(e, n, s_max) for e in ev]
     tick("init.intt", t0)
     t0 = time.perf_counter()
-    for size in (128, 728, 1 << 19, 1 << 19):                          # A_free, O_pub, O_mid, O_prv (order of magnitude)
-        tkmk.msm(tkmk.fr_random_device(20, size), crs, msm_size=size)
+    commits(((128, 1), (728, 1), (1 << 19, 1), (1 << 19, 1)), 20)     # A_free, O_pub, O_mid, O_prv (order of magnitude)
     tick("init.binding_msm", t0)
     u, v, w = polys[1], polys[2], polys[3]
     # ---- prove0: p0 = u*v - w (2 fwd + 1 inv NTT at 8192x512), div_by_vanishing_opt, 6 commits
@@ -60,8 +72,7 @@ def run():
     q_ax, q_ay = p0.div_by_vanishing_opt(n, s_max)
     tick("prove0.div_by_vanishing", t0)
     t0 = time.perf_counter()
-    for xs, ys in ((4097, 257), (4097, 257), (4097, 257), (4096, 256), (4096, 256), (4099, 259)):
-        tkmk.msm(tkmk.fr_random_device(30, xs * ys), crs, msm_size=xs * ys)       # sizes of U,V,W,Q_AX,Q_AY,B
+    commits(((4097, 257), (4097, 257), (4097, 257), (4096, 256), (4096, 256), (4099, 259)), 30)   # U,V,W,Q_AX,Q_AY,B
     tick("prove0.encode", t0)
     # ---- prove1: 2 fwd NTT 4096x256, batched division, 2 transposes, 1 iNTT, 1 commit
     t0 = time.perf_counter()
@@ -73,7 +84,7 @@ def run():
     r_poly = P.from_rou_evals(tr2, n, s_max)
     tick("prove1.poly", t0)
     t0 = time.perf_counter()
-    tkmk.msm(tkmk.fr_random_device(31, 4097 * 257), crs, msm_size=4097 * 257)
+    commits(((4097, 257),), 31)
     tick("prove1.encode", t0)
     # ---- prove2: 2 scale_coeffs, 3 Lagrange iNTTs, p_comb fused on 16384x512 (7 leaf NTTs + ~15 pointwise + 1 inverse),
     #              div_by_vanishing_opt, 2 commits
@@ -98,8 +109,7 @@ def run():
     q_cx, q_cy = p_comb.div_by_vanishing_opt(m_i, s_max)
     tick("prove2.div_by_vanishing", t0)
     t0 = time.perf_counter()
-    for xs, ys in ((8192, 511), (8191, 257)):
-        tkmk.msm(tkmk.fr_random_device(32, xs * ys), crs, msm_size=xs * ys)
+    commits(((8192, 511), (8191, 257)), 32)
     tick("prove2.encode", t0)
     # ---- prove3: 4 bivariate evaluations, 2 scale_coeffs
     t0 = time.perf_counter()
@@ -117,8 +127,7 @@ def run():
         _ = u * v
     tick("prove4.poly", t0)
     t0 = time.perf_counter()
-    for xs, ys in ((4825, 258), (4097, 511), (4098, 511), (8191, 511), (1, 256), (1, 256), (1, 510), (1, 510), (127, 1)):
-        tkmk.msm(tkmk.fr_random_device(33, xs * ys), crs, msm_size=xs * ys)
+    commits(((4825, 258), (4097, 511), (4098, 511), (8191, 511), (1, 256), (1, 256), (1, 510), (1, 510), (127, 1)), 33)
     tick("prove4.encode", t0)
     return t
 
@@ -128,7 +137,7 @@ t0 = time.perf_counter()
 sections = run()
 total = time.perf_counter() - t0
 slots = n * s_max
-print(json.dumps({"workload": "prove hot-path replay, production shape n=4096 s_max=256 m_I=4096 (2^20 constraint slots), synthetic data",
+print(json.dumps({"commits": "tkmk_msm_multi per round" if MULTI else "sequential bls12_381_msm", "workload": "prove hot-path replay, production shape n=4096 s_max=256 m_I=4096 (2^20 constraint slots), synthetic data",
                   "total_s": total, "constraint_slots_per_s": slots / total,
                   "msm_s": sum(v for k, v in sections.items() if "encode" in k or "msm" in k),
                   "poly_s": sum(v for k, v in sections.items() if "encode" not in k and "msm" not in k),
