@@ -31,6 +31,7 @@ def lib():
         _LIB.tko_dft_naive.restype = ctypes.c_int
         _LIB.tko_get_root_of_unity.restype = ctypes.c_int
         _LIB.tko_g1_on_curve.restype = ctypes.c_int
+        _LIB.tko_bn254_g1_on_curve.restype = ctypes.c_int
         _LIB.tko_num_threads.restype = ctypes.c_int
         _LIB.tko_poly_mul_monomial.restype = ctypes.c_int
         _LIB.tko_poly_div_by_vanishing_opt.restype = ctypes.c_int
@@ -210,6 +211,88 @@ def g1_proj_to_affine(p144):
     out = np.empty(96, np.uint8)
     lib().tko_g1_proj_to_affine(_p(p144), _p(out))
     return out
+
+
+class _Bn254:
+    """BN254 (alt_bn128) instantiation of the oracle's field / G1 code: Fr and Fq 32 B, affine 64 B, projective 96 B.
+    Same method names as the module-level BLS12-381 functions."""
+    R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    P_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    FQ_BYTES, AFF_BYTES = 32, 64
+
+    def __init__(self):
+        for f in ("fr", "fq"):
+            for op in ("add", "sub", "mul"):
+                setattr(self, "%s_%s" % (f, op), _binop("tko_bn254_%s_%s" % (f, op), 32))
+
+    @staticmethod
+    def _inv(name, a):
+        out = np.empty_like(a)
+        getattr(lib(), name)(_p(a), _p(out), _sz(a.size // 32))
+        return out
+
+    def fr_inv(self, a):
+        return self._inv("tko_bn254_fr_inv", a)
+
+    def fq_inv(self, a):
+        return self._inv("tko_bn254_fq_inv", a)
+
+    def fr_random(self, seed, n, first=0):
+        out = np.empty(32 * n, np.uint8)
+        lib().tko_bn254_fr_random(_u64(seed), _sz(first), _sz(n), _p(out))
+        return out
+
+    def g1_generator(self):
+        out = np.empty(64, np.uint8)
+        lib().tko_bn254_g1_generator(_p(out))
+        return out
+
+    def g1_on_curve(self, p):
+        return bool(lib().tko_bn254_g1_on_curve(_p(p)))
+
+    def g1_add(self, p, q):
+        out = np.empty(64, np.uint8)
+        lib().tko_bn254_g1_add(_p(p), _p(q), _p(out))
+        return out
+
+    def g1_neg(self, p):
+        out = np.empty(64, np.uint8)
+        lib().tko_bn254_g1_neg(_p(p), _p(out))
+        return out
+
+    def g1_scalar_mul(self, s, p):
+        out = np.empty(64, np.uint8)
+        lib().tko_bn254_g1_scalar_mul(_p(s), _p(p), _p(out))
+        return out
+
+    def g1_batch_scalar_mul(self, s, p):
+        n = s.size // 32
+        out = np.empty(64 * n, np.uint8)
+        lib().tko_bn254_g1_batch_scalar_mul(_p(s), _p(p), _sz(n), _p(out))
+        return out
+
+    def g1_random_bases(self, seed, n, first=0):
+        out = np.empty(64 * n, np.uint8)
+        lib().tko_bn254_g1_random_bases(_u64(seed), _sz(first), _sz(n), _p(out))
+        return out
+
+    def g1_msm_naive(self, s, p):
+        out = np.empty(64, np.uint8)
+        lib().tko_bn254_g1_msm_naive(_p(s), _p(p), _sz(s.size // 32), _p(out))
+        return out
+
+    def g1_msm(self, s, p, threads=0):
+        out = np.empty(64, np.uint8)
+        lib().tko_bn254_g1_msm(_p(s), _p(p), _sz(s.size // 32), int(threads), _p(out))
+        return out
+
+    def g1_proj_to_affine(self, p96):
+        out = np.empty(64, np.uint8)
+        lib().tko_bn254_g1_proj_to_affine(_p(p96), _p(out))
+        return out
+
+
+bn254 = _Bn254()
 
 
 def poly_find_degree(c, xs, ys):

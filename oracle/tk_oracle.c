@@ -170,6 +170,8 @@ typedef uint64_t u64;
 
 DEFINE_FIELD(fr, 4)
 DEFINE_FIELD(fq, 6)
+DEFINE_FIELD(bnr, 4)
+DEFINE_FIELD(bnq, 4)
 
 /* r: prime field of every committed .r1cs (qap-compiler/subcircuits/library/r1cs, header prime) */
 static const u64 FR_MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL,
@@ -178,7 +180,12 @@ static const u64 FR_MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x33
 static const u64 FQ_MOD[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
                               0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
 
-static fq_t FQ_B;        /* curve constant 4 (Montgomery) */
+/* BN254 scalar and base field (EIP-196 / alt_bn128) */
+static const u64 BNR_MOD[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static const u64 BNQ_MOD[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+
+static fq_t g1_CURVE_B;  /* curve constant 4 (Montgomery) */
+static bnq_t bn_CURVE_B; /* curve constant 3 (Montgomery) */
 static fr_t FR_ROOT32;   /* w_{2^32} = 5^((r-1)/2^32) (Montgomery) */
 
 static void tko_init(void) {
@@ -190,7 +197,13 @@ static void tko_init(void) {
             fq_t four;
             memset(&four, 0, sizeof four);
             four.l[0] = 4;
-            fq_to_mont(&FQ_B, &four);
+            fq_to_mont(&g1_CURVE_B, &four);
+            bnq_init(BNQ_MOD);
+            bnr_init(BNR_MOD);
+            bnq_t three;
+            memset(&three, 0, sizeof three);
+            three.l[0] = 3;
+            bnq_to_mont(&bn_CURVE_B, &three);
             /* root of unity before publishing fr_ready */
             memcpy(fr_P.l, FR_MOD, sizeof fr_P.l);
             fr_init(FR_MOD);
@@ -236,6 +249,24 @@ VEC_BINOP(tko_fr_mul, fr, 32, fr_mul)
 VEC_BINOP(tko_fq_add, fq, 48, fq_add)
 VEC_BINOP(tko_fq_sub, fq, 48, fq_sub)
 VEC_BINOP(tko_fq_mul, fq, 48, fq_mul)
+VEC_BINOP(tko_bn254_fr_add, bnr, 32, bnr_add)
+VEC_BINOP(tko_bn254_fr_sub, bnr, 32, bnr_sub)
+VEC_BINOP(tko_bn254_fr_mul, bnr, 32, bnr_mul)
+VEC_BINOP(tko_bn254_fq_add, bnq, 32, bnq_add)
+VEC_BINOP(tko_bn254_fq_sub, bnq, 32, bnq_sub)
+VEC_BINOP(tko_bn254_fq_mul, bnq, 32, bnq_mul)
+#define VEC_INV(NAME, F, SZ)                                                                   \
+    void NAME(const uint8_t *a, uint8_t *out, size_t n) {                                      \
+        tko_init();                                                                            \
+        _Pragma("omp parallel for schedule(static)") for (size_t i = 0; i < n; i++) {          \
+            F##_t x, y;                                                                        \
+            F##_load(&x, a + SZ * i);                                                          \
+            F##_inv(&y, &x);                                                                   \
+            F##_store(out + SZ * i, &y);                                                       \
+        }                                                                                      \
+    }
+VEC_INV(tko_bn254_fr_inv, bnr, 32)
+VEC_INV(tko_bn254_fq_inv, bnq, 32)
 
 void tko_fr_inv(const uint8_t *a, uint8_t *out, size_t n) {
     tko_init();
@@ -310,9 +341,21 @@ static inline u64 splitmix64_at(u64 seed, u64 idx) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-static inline void fr_random_plain(u64 seed, u64 i, fr_t *o) {
-    for (int k = 0; k < 4; k++) o->l[k] = splitmix64_at(seed, 4 * i + k);
-    while (fr_geq_p(o)) fr_sub_p(o);
+#define DEFINE_RANDOM(F)                                                                       \
+    static inline void F##_random_plain(u64 seed, u64 i, F##_t *o) {                           \
+        for (int k = 0; k < 4; k++) o->l[k] = splitmix64_at(seed, 4 * i + k);                  \
+        while (F##_geq_p(o)) F##_sub_p(o);                                                     \
+    }
+DEFINE_RANDOM(fr)
+DEFINE_RANDOM(bnr)
+void tko_bn254_fr_random(uint64_t seed, size_t first, size_t n, uint8_t *out) {
+    tko_init();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        bnr_t x;
+        bnr_random_plain(seed, first + i, &x);
+        memcpy(out + 32 * i, x.l, 32);
+    }
 }
 void tko_fr_random(uint64_t seed, size_t first, size_t n, uint8_t *out) {
     tko_init();
@@ -470,340 +513,40 @@ int tko_dft_naive(const uint8_t *in, size_t n, uint8_t *out) {
 }
 
 /* ------------------------------------------------------------------------------------------
- * G1: y^2 = x^3 + 4 over Fq, Jacobian coordinates (X/Z^2, Y/Z^3), Z = 0 <=> infinity.
- * Standard short-Weierstrass a=0 formulas (dbl-2009-l, add-2007-bl / madd-2007-bl).
+ * G1 groups: the curve-generic code lives in tk_g1.inc and is instantiated per curve.
  * ------------------------------------------------------------------------------------------ */
-typedef struct { fq_t x, y, z; } g1j_t;
-typedef struct { fq_t x, y; int inf; } g1a_t;
-
-static void g1a_load(g1a_t *o, const uint8_t *b) {
-    int z = 1;
-    for (int i = 0; i < 96; i++)
-        if (b[i]) { z = 0; break; }
-    o->inf = z;
-    fq_load(&o->x, b);
-    fq_load(&o->y, b + 48);
-}
-static void g1a_store(uint8_t *b, const g1a_t *p) {
-    if (p->inf) { memset(b, 0, 96); return; }
-    fq_store(b, &p->x);
-    fq_store(b + 48, &p->y);
-}
-static void g1j_set_inf(g1j_t *p) { memset(p, 0, sizeof *p); p->x = fq_R1; p->y = fq_R1; }
-static void g1j_from_affine(g1j_t *o, const g1a_t *p) {
-    if (p->inf) { g1j_set_inf(o); return; }
-    o->x = p->x; o->y = p->y; o->z = fq_R1;
-}
-static void g1j_to_affine(g1a_t *o, const g1j_t *p) {
-    if (fq_is_zero(&p->z)) { memset(o, 0, sizeof *o); o->inf = 1; return; }
-    fq_t zi, zi2, zi3;
-    fq_inv(&zi, &p->z);
-    fq_sqr(&zi2, &zi);
-    fq_mul(&zi3, &zi2, &zi);
-    fq_mul(&o->x, &p->x, &zi2);
-    fq_mul(&o->y, &p->y, &zi3);
-    o->inf = 0;
-}
-static void g1j_double(g1j_t *o, const g1j_t *p) {
-    if (fq_is_zero(&p->z)) { *o = *p; return; }
-    fq_t a, b, c, d, e, f, t;
-    fq_sqr(&a, &p->x);
-    fq_sqr(&b, &p->y);
-    fq_sqr(&c, &b);
-    fq_add(&t, &p->x, &b);
-    fq_sqr(&t, &t);
-    fq_sub(&t, &t, &a);
-    fq_sub(&t, &t, &c);
-    fq_add(&d, &t, &t);
-    fq_add(&e, &a, &a);
-    fq_add(&e, &e, &a);
-    fq_sqr(&f, &e);
-    g1j_t r;
-    fq_mul(&r.z, &p->y, &p->z);
-    fq_add(&r.z, &r.z, &r.z);
-    fq_sub(&r.x, &f, &d);
-    fq_sub(&r.x, &r.x, &d);
-    fq_sub(&t, &d, &r.x);
-    fq_mul(&t, &t, &e);
-    fq_add(&c, &c, &c);
-    fq_add(&c, &c, &c);
-    fq_add(&c, &c, &c);
-    fq_sub(&r.y, &t, &c);
-    *o = r;
-}
-static void g1j_add(g1j_t *o, const g1j_t *p, const g1j_t *q) {
-    if (fq_is_zero(&p->z)) { *o = *q; return; }
-    if (fq_is_zero(&q->z)) { *o = *p; return; }
-    fq_t z1z1, z2z2, u1, u2, s1, s2, h, i, j, rr, v, t;
-    fq_sqr(&z1z1, &p->z);
-    fq_sqr(&z2z2, &q->z);
-    fq_mul(&u1, &p->x, &z2z2);
-    fq_mul(&u2, &q->x, &z1z1);
-    fq_mul(&s1, &p->y, &q->z);
-    fq_mul(&s1, &s1, &z2z2);
-    fq_mul(&s2, &q->y, &p->z);
-    fq_mul(&s2, &s2, &z1z1);
-    if (fq_eq(&u1, &u2)) {
-        if (fq_eq(&s1, &s2)) { g1j_double(o, p); return; }
-        g1j_set_inf(o);
-        return;
-    }
-    fq_sub(&h, &u2, &u1);
-    fq_add(&i, &h, &h);
-    fq_sqr(&i, &i);
-    fq_mul(&j, &h, &i);
-    fq_sub(&rr, &s2, &s1);
-    fq_add(&rr, &rr, &rr);
-    fq_mul(&v, &u1, &i);
-    g1j_t r;
-    fq_sqr(&r.x, &rr);
-    fq_sub(&r.x, &r.x, &j);
-    fq_sub(&r.x, &r.x, &v);
-    fq_sub(&r.x, &r.x, &v);
-    fq_sub(&t, &v, &r.x);
-    fq_mul(&t, &t, &rr);
-    fq_mul(&s1, &s1, &j);
-    fq_add(&s1, &s1, &s1);
-    fq_sub(&r.y, &t, &s1);
-    fq_add(&t, &p->z, &q->z);
-    fq_sqr(&t, &t);
-    fq_sub(&t, &t, &z1z1);
-    fq_sub(&t, &t, &z2z2);
-    fq_mul(&r.z, &t, &h);
-    *o = r;
-}
-/* mixed addition p + (+-q), q affine: madd-2007-bl (7M + 4S); degenerate cases through the general adder */
-static void g1j_add_affine(g1j_t *o, const g1j_t *p, const g1a_t *q, int negate) {
-    if (q->inf) { *o = *p; return; }
-    fq_t qy = q->y;
-    if (negate) fq_neg(&qy, &qy);
-    if (fq_is_zero(&p->z)) {
-        o->x = q->x;
-        o->y = qy;
-        o->z = fq_R1;
-        return;
-    }
-    fq_t z1z1, u2, s2, h, hh, i, j, rr, v, t;
-    fq_sqr(&z1z1, &p->z);
-    fq_mul(&u2, &q->x, &z1z1);
-    fq_mul(&s2, &qy, &p->z);
-    fq_mul(&s2, &s2, &z1z1);
-    if (fq_eq(&u2, &p->x)) {
-        g1j_t qq;
-        qq.x = q->x;
-        qq.y = qy;
-        qq.z = fq_R1;
-        g1j_add(o, p, &qq); /* doubling or infinity */
-        return;
-    }
-    fq_sub(&h, &u2, &p->x);
-    fq_sqr(&hh, &h);
-    fq_add(&i, &hh, &hh);
-    fq_add(&i, &i, &i);
-    fq_mul(&j, &h, &i);
-    fq_sub(&rr, &s2, &p->y);
-    fq_add(&rr, &rr, &rr);
-    fq_mul(&v, &p->x, &i);
-    g1j_t r;
-    fq_sqr(&r.x, &rr);
-    fq_sub(&r.x, &r.x, &j);
-    fq_sub(&r.x, &r.x, &v);
-    fq_sub(&r.x, &r.x, &v);
-    fq_sub(&t, &v, &r.x);
-    fq_mul(&t, &t, &rr);
-    fq_mul(&v, &p->y, &j);
-    fq_add(&v, &v, &v);
-    fq_sub(&r.y, &t, &v);
-    fq_add(&t, &p->z, &h);
-    fq_sqr(&t, &t);
-    fq_sub(&t, &t, &z1z1);
-    fq_sub(&r.z, &t, &hh);
-    *o = r;
-}
-/* [s]P, s plain 4 limbs, MSB-first double-and-add */
-static void g1j_scalar_mul(g1j_t *o, const u64 *s, const g1j_t *p) {
-    g1j_t acc;
-    g1j_set_inf(&acc);
-    for (int i = 255; i >= 0; i--) {
-        g1j_double(&acc, &acc);
-        if ((s[i >> 6] >> (i & 63)) & 1) g1j_add(&acc, &acc, p);
-    }
-    *o = acc;
-}
-static void load_scalar_plain(u64 *s, const uint8_t *b) { /* reduce mod r like Fr import */
-    fr_t t;
-    memcpy(t.l, b, 32);
-    while (fr_geq_p(&t)) fr_sub_p(&t);
-    memcpy(s, t.l, 32);
-}
-
 /* standard generator, restated from setup/mpc-setup/src/conversions.rs:68-79 (u32 LE limbs) */
-static const uint32_t G1_GEN_X[12] = {0xdb22c6bb, 0xfb3af00a, 0xf97a1aef, 0x6c55e83f, 0x171bac58, 0xa14e3a3f,
+static const uint32_t g1_GEN_X[12] = {0xdb22c6bb, 0xfb3af00a, 0xf97a1aef, 0x6c55e83f, 0x171bac58, 0xa14e3a3f,
                                       0x9774b905, 0xc3688c4f, 0x4fa9ac0f, 0x2695638c, 0x3197d794, 0x17f1d3a7};
-static const uint32_t G1_GEN_Y[12] = {1187375073u, 212476713u,  2726857444u, 3493644100u, 738505709u,  14358731u,
+static const uint32_t g1_GEN_Y[12] = {1187375073u, 212476713u,  2726857444u, 3493644100u, 738505709u,  14358731u,
                                       3587181302u, 4243972245u, 1948093156u, 2694721773u, 3819610353u, 146011265u};
-void tko_g1_generator(uint8_t *out96) {
-    memcpy(out96, G1_GEN_X, 48);
-    memcpy(out96 + 48, G1_GEN_Y, 48);
-}
-int tko_g1_on_curve(const uint8_t *p96) {
-    tko_init();
-    g1a_t p;
-    g1a_load(&p, p96);
-    if (p.inf) return 1;
-    fq_t l, r;
-    fq_sqr(&l, &p.y);
-    fq_sqr(&r, &p.x);
-    fq_mul(&r, &r, &p.x);
-    fq_add(&r, &r, &FQ_B);
-    return fq_eq(&l, &r);
-}
-void tko_g1_add(const uint8_t *p96, const uint8_t *q96, uint8_t *out96) {
-    tko_init();
-    g1a_t p, q, r;
-    g1j_t pj, rj;
-    g1a_load(&p, p96);
-    g1a_load(&q, q96);
-    g1j_from_affine(&pj, &p);
-    g1j_add_affine(&rj, &pj, &q, 0);
-    g1j_to_affine(&r, &rj);
-    g1a_store(out96, &r);
-}
-void tko_g1_neg(const uint8_t *p96, uint8_t *out96) {
-    tko_init();
-    g1a_t p;
-    g1a_load(&p, p96);
-    if (!p.inf) fq_neg(&p.y, &p.y);
-    g1a_store(out96, &p);
-}
-void tko_g1_scalar_mul(const uint8_t *s32, const uint8_t *p96, uint8_t *out96) {
-    tko_init();
-    g1a_t p, r;
-    g1j_t pj, rj;
-    u64 s[4];
-    load_scalar_plain(s, s32);
-    g1a_load(&p, p96);
-    g1j_from_affine(&pj, &p);
-    g1j_scalar_mul(&rj, s, &pj);
-    g1j_to_affine(&r, &rj);
-    g1a_store(out96, &r);
-}
-void tko_g1_batch_scalar_mul(const uint8_t *s, const uint8_t *p96, size_t n, uint8_t *out) {
-    tko_init();
-#pragma omp parallel for schedule(dynamic, 16)
-    for (size_t i = 0; i < n; i++) tko_g1_scalar_mul(s + 32 * i, p96, out + 96 * i);
-}
-void tko_g1_random_bases(uint64_t seed, size_t first, size_t n, uint8_t *out) {
-    tko_init();
-    uint8_t g[96];
-    tko_g1_generator(g);
-#pragma omp parallel for schedule(dynamic, 16)
-    for (size_t i = 0; i < n; i++) {
-        fr_t h;
-        fr_random_plain(seed, first + i, &h);
-        tko_g1_scalar_mul((const uint8_t *)h.l, g, out + 96 * i);
-    }
-}
-void tko_g1_msm_naive(const uint8_t *s, const uint8_t *p, size_t n, uint8_t *out96) {
-    tko_init();
-    g1j_t acc;
-    g1j_set_inf(&acc);
-    for (size_t i = 0; i < n; i++) {
-        g1a_t a;
-        g1j_t pj, t;
-        u64 k[4];
-        load_scalar_plain(k, s + 32 * i);
-        g1a_load(&a, p + 96 * i);
-        g1j_from_affine(&pj, &a);
-        g1j_scalar_mul(&t, k, &pj);
-        g1j_add(&acc, &acc, &t);
-    }
-    g1a_t r;
-    g1j_to_affine(&r, &acc);
-    g1a_store(out96, &r);
-}
+#define FQ(x) fq_##x
+#define FS(x) fr_##x
+#define G(x) g1_##x
+#define TKO(x) tko_g1_##x
+#define FQB 48
+#include "tk_g1.inc"
+#undef FQ
+#undef FS
+#undef G
+#undef TKO
+#undef FQB
 
-/* Pippenger bucket method (the published algorithm ICICLE's CPU/CUDA msm backends implement):
- * unsigned c-bit windows, per-window buckets, running-sum reduction, Horner over windows.
- * Parallel over (window, slice of the points): every task owns a private bucket array; slice results of a window
- * are added before the Horner step. */
-void tko_g1_msm(const uint8_t *s, const uint8_t *p, size_t n, int threads, uint8_t *out96) {
-    tko_init();
-    if (n == 0) { memset(out96, 0, 96); return; }
-    int c = 4;
-    while (c < 16 && ((size_t)1 << (c + 4)) < n) c++;
-    int nwin = (255 + c - 1) / c;
-    g1a_t *pts = (g1a_t *)malloc(sizeof(g1a_t) * n);
-    u64 *sc = (u64 *)malloc(32 * n);
-#ifdef _OPENMP
-    if (threads <= 0) threads = omp_get_max_threads();
-#else
-    threads = 1;
-#endif
-#pragma omp parallel for schedule(static) num_threads(threads)
-    for (size_t i = 0; i < n; i++) {
-        g1a_load(&pts[i], p + 96 * i);
-        load_scalar_plain(sc + 4 * i, s + 32 * i);
-    }
-    /* slices: enough tasks for all threads, but at least ~2^c points per task so bucket set-up stays minor */
-    int slices = (threads + nwin - 1) / nwin;
-    while (slices > 1 && n / (size_t)slices < ((size_t)1 << c)) slices--;
-    if (slices < 1) slices = 1;
-    int ntask = nwin * slices;
-    g1j_t *tsum = (g1j_t *)malloc(sizeof(g1j_t) * ntask);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (int task = 0; task < ntask; task++) {
-        int w = task / slices, sl = task % slices;
-        size_t i0 = n * (size_t)sl / slices, i1 = n * (size_t)(sl + 1) / slices;
-        size_t nb = ((size_t)1 << c) - 1;
-        g1j_t *bk = (g1j_t *)malloc(sizeof(g1j_t) * nb);
-        for (size_t b = 0; b < nb; b++) g1j_set_inf(&bk[b]);
-        int lo = w * c;
-        for (size_t i = i0; i < i1; i++) {
-            const u64 *k = sc + 4 * i;
-            int li = lo >> 6, sh = lo & 63;
-            u64 d = k[li] >> sh;
-            if (sh + c > 64 && li < 3) d |= k[li + 1] << (64 - sh);
-            d &= ((u64)1 << c) - 1;
-            if (d) g1j_add_affine(&bk[d - 1], &bk[d - 1], &pts[i], 0);
-        }
-        g1j_t run, tot;
-        g1j_set_inf(&run);
-        g1j_set_inf(&tot);
-        for (size_t b = nb; b-- > 0;) {
-            g1j_add(&run, &run, &bk[b]);
-            g1j_add(&tot, &tot, &run);
-        }
-        tsum[task] = tot;
-        free(bk);
-    }
-    g1j_t acc;
-    g1j_set_inf(&acc);
-    for (int w = nwin - 1; w >= 0; w--) {
-        for (int k = 0; k < c; k++) g1j_double(&acc, &acc);
-        for (int sl = 0; sl < slices; sl++) g1j_add(&acc, &acc, &tsum[w * slices + sl]);
-    }
-    g1a_t r;
-    g1j_to_affine(&r, &acc);
-    g1a_store(out96, &r);
-    free(tsum);
-    free(sc);
-    free(pts);
-}
-
-void tko_g1_proj_to_affine(const uint8_t *p144, uint8_t *out96) {
-    tko_init();
-    fq_t x, y, z, zi;
-    fq_load(&x, p144);
-    fq_load(&y, p144 + 48);
-    fq_load(&z, p144 + 96);
-    if (fq_is_zero(&z)) { memset(out96, 0, 96); return; }
-    fq_inv(&zi, &z);
-    fq_mul(&x, &x, &zi);
-    fq_mul(&y, &y, &zi);
-    fq_store(out96, &x);
-    fq_store(out96 + 48, &y);
-}
+/* BN254 (alt_bn128): y^2 = x^3 + 3, generator (1, 2) (EIP-196).  No counterpart in the reference;
+ * present because BASELINE.json's configs name a BN254 MSM. */
+static const uint32_t bn_GEN_X[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+static const uint32_t bn_GEN_Y[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+#define FQ(x) bnq_##x
+#define FS(x) bnr_##x
+#define G(x) bn_##x
+#define TKO(x) tko_bn254_g1_##x
+#define FQB 32
+#include "tk_g1.inc"
+#undef FQ
+#undef FS
+#undef G
+#undef TKO
+#undef FQB
 
 /* ------------------------------------------------------------------------------------------
  * Bivariate coefficient-matrix routines: restatements of the HOST loops of DensePolynomialExt

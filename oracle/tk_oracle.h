@@ -90,6 +90,28 @@ void tko_g1_msm(const uint8_t *s, const uint8_t *p, size_t n, int threads, uint8
 /* homogeneous projective (X/Z, Y/Z) -> affine, 144 B -> 96 B (ICICLE G1Projective -> G1Affine) */
 void tko_g1_proj_to_affine(const uint8_t *p144, uint8_t *out96);
 
+/* ---- BN254 (alt_bn128) instantiation of the same field / G1 code (tk_g1.inc): Fr, Fq 32 B, affine 64 B, projective 96 B.
+ * Not used by the reference (BLS12-381 only); named by BASELINE.json's MSM configs. ---- */
+void tko_bn254_fr_add(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+void tko_bn254_fr_sub(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+void tko_bn254_fr_mul(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+void tko_bn254_fr_inv(const uint8_t *a, uint8_t *out, size_t n);
+void tko_bn254_fq_add(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+void tko_bn254_fq_sub(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+void tko_bn254_fq_mul(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+void tko_bn254_fq_inv(const uint8_t *a, uint8_t *out, size_t n);
+void tko_bn254_fr_random(uint64_t seed, size_t first, size_t n, uint8_t *out);
+void tko_bn254_g1_generator(uint8_t *out64);
+int  tko_bn254_g1_on_curve(const uint8_t *p64);
+void tko_bn254_g1_add(const uint8_t *p64, const uint8_t *q64, uint8_t *out64);
+void tko_bn254_g1_neg(const uint8_t *p64, uint8_t *out64);
+void tko_bn254_g1_scalar_mul(const uint8_t *s32, const uint8_t *p64, uint8_t *out64);
+void tko_bn254_g1_batch_scalar_mul(const uint8_t *s, const uint8_t *p64, size_t n, uint8_t *out);
+void tko_bn254_g1_random_bases(uint64_t seed, size_t first, size_t n, uint8_t *out);
+void tko_bn254_g1_msm_naive(const uint8_t *s, const uint8_t *p, size_t n, uint8_t *out64);
+void tko_bn254_g1_msm(const uint8_t *s, const uint8_t *p, size_t n, int threads, uint8_t *out64);
+void tko_bn254_g1_proj_to_affine(const uint8_t *p96, uint8_t *out64);
+
 /* ---- bivariate coefficient-matrix routines (DensePolynomialExt host loops; element (ix,iy) at ix*ys+iy) ---- */
 void tko_poly_find_degree(const uint8_t *c, size_t xs, size_t ys, int64_t *xd, int64_t *yd);
 void tko_poly_resized_dims(size_t tx, size_t ty, size_t *nx, size_t *ny);

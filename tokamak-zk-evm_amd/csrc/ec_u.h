@@ -22,7 +22,7 @@ struct ecu {
     using FS = ff<P>;
     using GS = ec<FS>;
     using E = typename FU::E;
-    struct A {  // affine base: strict, canonical (< p), Montgomery radix 2^(29L); never infinity on the fast path
+    struct A {  // affine base: strict, canonical (< p), Montgomery radix 2^(W L); never infinity on the fast path
         E x, y;
     };
     struct X {
@@ -39,7 +39,7 @@ struct ecu {
         r.inf = true;
         return r;
     }
-    // packed record written by k_convert_bases: {x 2^(29L) mod p, y 2^(29L) mod p} as 32-bit limbs; (0,0) = infinity
+    // packed record written by k_convert_bases: {x 2^(W L) mod p, y 2^(W L) mod p} as 32-bit limbs; (0,0) = infinity
     static FF_HD bool load_affine(A &q, const affine_t<FS> &rec) {
         if (FS::is_zero(rec.x) && FS::is_zero(rec.y)) return false;
         q.x = FU::from_packed(rec.x);
@@ -85,7 +85,7 @@ struct ecu {
         r.zzz = FU::to_sat_mont(p.zzz);
         return r;
     }
-    static FF_HD E from_sat_mont(const typename FS::E &s) {  // x 2^(32N) canonical -> x 2^(29L) strict canonical
+    static FF_HD E from_sat_mont(const typename FS::E &s) {  // x 2^(32N) canonical -> x 2^(W L) strict canonical
         typename FS::E k;
 #pragma unroll
         for (int i = 0; i < FS::N; i++) k.l[i] = P::KSATM[i];

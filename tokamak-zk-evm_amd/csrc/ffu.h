@@ -28,7 +28,7 @@ template <class P>
 struct ffu {
     static constexpr int L = P::LU;
     static constexpr int N = P::N;  // saturated limb count
-    static constexpr uint32_t W = 29, MASK = (1u << 29) - 1;
+    static constexpr uint32_t W = P::WU, MASK = (1u << P::WU) - 1;  // 29 bits for BLS12-381 Fq, 28 for BN254 Fq
     struct alignas(8) E {
         uint32_t l[L];
     };
@@ -40,7 +40,7 @@ struct ffu {
         for (int i = 0; i < L; i++) r.l[i] = 0;
         return r;
     }
-    static FF_HD E one() {  // Montgomery 1 (2^(29L) mod p)
+    static FF_HD E one() {  // Montgomery 1 (2^(W L) mod p)
         E r;
 #pragma unroll
         for (int i = 0; i < L; i++) r.l[i] = P::ONEU[i];
@@ -90,7 +90,7 @@ struct ffu {
         return norm(t);
     }
 
-    // Montgomery product a*b/2^(29L) mod p (redundant): strict operands, a*b < 2^20 p^2; strict result < 1.03 p.
+    // Montgomery product a*b/2^(W L) mod p (redundant): strict operands, a*b < 2^20 p^2; strict result < 1.03 p.
     // Product scanning; a 64-bit column accumulator cannot overflow: 2L products < 2^58 plus a carry < 2^35.
     static FF_HD E mul(const E &a, const E &b) {
         FFU_ASSERT(strict(a) && strict(b) && a.l[L - 1] <= MASK && b.l[L - 1] <= MASK);
@@ -153,16 +153,16 @@ struct ffu {
         return r;
     }
 
-    // quick filter for "a == j p for some 0 <= j <= jmax": the low 29 bits of j p determine j
+    // quick filter for "a == j p for some 0 <= j <= jmax": the low W bits of j p determine j
     static FF_HD bool maybe_multiple_of_p(const E &a, uint32_t jmax) { return ((a.l[0] * P::PINVU) & MASK) <= jmax; }
 
     // ---- conversions to / from the saturated layout (32-bit limbs) ----
-    // 32-bit-limb integer below 2^(29L) -> strict
+    // 32-bit-limb integer below 2^(W L) -> strict
     static FF_HD E unpack(const S &s) {
         E r;
 #pragma unroll
         for (int i = 0; i < L; i++) {
-            int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+            int bit = (int)W * i, w = bit >> 5, sh = bit & 31;
             uint32_t lo = w < N ? s.l[w] : 0u, hi = w + 1 < N ? s.l[w + 1] : 0u;
             uint32_t v = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
             r.l[i] = i < L - 1 ? (v & MASK) : v;
@@ -177,7 +177,7 @@ struct ffu {
             uint32_t v = 0;
 #pragma unroll
             for (int i = 0; i < L; i++) {
-                int lo = 29 * i - 32 * w;  // bit position of limb i relative to word w
+                int lo = (int)W * i - 32 * w;  // bit position of limb i relative to word w
                 if (lo >= 32 || lo + 32 <= 0) continue;
                 v |= lo >= 0 ? a.l[i] << lo : a.l[i] >> (-lo);
             }
@@ -201,14 +201,14 @@ struct ffu {
         for (int i = 0; i < L; i++) r.l[i] = (a.l[i] & keep) | (t.l[i] & ~keep);
         return r;
     }
-    // x*2^(29L) (redundant, < 2^10 p)  ->  saturated Montgomery form x*2^(32N), canonical
+    // x*2^(W L) (redundant, < 2^10 p)  ->  saturated Montgomery form x*2^(32N), canonical
     static FF_HD S to_sat_mont(const E &a) {
         E c;
 #pragma unroll
         for (int i = 0; i < L; i++) c.l[i] = P::RSATU[i];
         return pack(cond_sub_p(mul(a, c)));
     }
-    // packed canonical x*2^(29L) (what k_convert_bases stores)  ->  strict
+    // packed canonical x*2^(W L) (what k_convert_bases stores)  ->  strict
     static FF_HD E from_packed(const S &s) { return unpack(s); }
 };
 

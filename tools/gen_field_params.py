@@ -6,11 +6,13 @@ import os
 
 FIELDS = {
     # BLS12-381 (the reference's only curve: packages/backend/Cargo.toml:23)
-    "bls12_381_fr": dict(mod=0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, two_adicity=32, qnr=5),
+    "bls12_381_fr": dict(mod=0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, two_adicity=32, qnr=5, wu=28),
     "bls12_381_fq": dict(mod=0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB),
     # BN254 (second instantiation named by BASELINE.json configs; no counterpart in the reference)
-    "bn254_fr": dict(mod=21888242871839275222246405745257275088548364400416034343698204186575808495617, two_adicity=28, qnr=5),
-    "bn254_fq": dict(mod=21888242871839275222246405745257275088696311157297823662689037894645226208583),
+    "bn254_fr": dict(mod=21888242871839275222246405745257275088548364400416034343698204186575808495617, two_adicity=28, qnr=5, wu=28),
+    # 28-bit limbs: with 29 the top limb of 2p would be empty (10 limbs start at bit 261 > 254) and the dominating-limb
+    # subtraction constants of ffu::sub<K> need a non-zero top limb
+    "bn254_fq": dict(mod=21888242871839275222246405745257275088696311157297823662689037894645226208583, wu=28),
 }
 
 
@@ -114,11 +116,11 @@ def gen_linear(n, p):
     return L
 
 
-WU = 29  # limb width of the unsaturated (carry-free product) representation
+WU_DEFAULT = 29  # limb width of the unsaturated (carry-free product) representation
 
 
-def limbs_u(v, n):
-    """29-bit digits; the top limb takes whatever is left"""
+def limbs_u(v, n, WU):
+    """WU-bit digits; the top limb takes whatever is left"""
     out = []
     for i in range(n):
         out.append(v & ((1 << WU) - 1) if i < n - 1 else v)
@@ -127,7 +129,7 @@ def limbs_u(v, n):
     return ", ".join("0x%08xu" % x for x in out)
 
 
-def sub_const(k, p, n):
+def sub_const(k, p, n, WU):
     """K*p written with limbs that dominate any strict operand: c_0 = d_0 + 2^29, c_i = d_i + 2^29 - 1, c_top = d_top - 1"""
     v = k * p
     d = []
@@ -139,25 +141,27 @@ def sub_const(k, p, n):
     return c
 
 
-def gen_unsat(name, p):
-    """constants of the radix-2^29 representation (csrc/ffu.h)"""
+def gen_unsat(name, p, WU):
+    """constants of the radix-2^WU representation (csrc/ffu.h)"""
     nsat = (p.bit_length() + 31) // 32
-    L = -(-(p.bit_length() + 4) // WU)          # >= 4 spare bits so that values up to 16p keep a small top limb
+    L = -(-(p.bit_length() + 24) // WU)         # radix >= 2^24 p: a product of operands below 2^10 p stays below 1.07 p
+    assert (2 * p) >> (WU * (L - 1)) >= 2, "top limb of 2p must be non-zero (sub<K> constants)"
     Ru = 1 << (WU * L)
     Rs = 1 << (32 * nsat)
     o = []
     o.append("    // ---- unsaturated representation: %d limbs of %d bits, Montgomery radix 2^%d (csrc/ffu.h) ----" % (L, WU, WU * L))
     o.append("    static constexpr int LU = %d;" % L)
-    o.append("    static constexpr uint32_t INVU = 0x%08xu;   // -p^-1 mod 2^29" % ((-pow(p, -1, 1 << WU)) % (1 << WU)))
-    o.append("    static constexpr uint32_t PINVU = 0x%08xu;  // p^-1 mod 2^29" % pow(p, -1, 1 << WU))
-    o.append("    static constexpr uint32_t MODU[%d] = {%s};" % (L, limbs_u(p, L)))
-    o.append("    static constexpr uint32_t ONEU[%d] = {%s};   // 2^%d mod p" % (L, limbs_u(Ru % p, L), WU * L))
-    o.append("    static constexpr uint32_t RSATU[%d] = {%s};  // 2^%d mod p: mulU(v, RSATU) turns x*2^%d into x*2^%d" % (L, limbs_u(Rs % p, L), 32 * nsat, WU * L, 32 * nsat))
+    o.append("    static constexpr int WU = %d;" % WU)
+    o.append("    static constexpr uint32_t INVU = 0x%08xu;   // -p^-1 mod 2^WU" % ((-pow(p, -1, 1 << WU)) % (1 << WU)))
+    o.append("    static constexpr uint32_t PINVU = 0x%08xu;  // p^-1 mod 2^WU" % pow(p, -1, 1 << WU))
+    o.append("    static constexpr uint32_t MODU[%d] = {%s};" % (L, limbs_u(p, L, WU)))
+    o.append("    static constexpr uint32_t ONEU[%d] = {%s};   // 2^%d mod p" % (L, limbs_u(Ru % p, L, WU), WU * L))
+    o.append("    static constexpr uint32_t RSATU[%d] = {%s};  // 2^%d mod p: mulU(v, RSATU) turns x*2^%d into x*2^%d" % (L, limbs_u(Rs % p, L, WU), 32 * nsat, WU * L, 32 * nsat))
     o.append("    // saturated-side constants: mont_mul(x_plain, KSAT) = x*2^%d mod p;  mont_mul(x*2^%d, KSATM) = x*2^%d mod p" % (WU * L, 32 * nsat, WU * L))
     o.append("    static constexpr uint32_t KSAT[%d] = {%s};" % (nsat, limbs((Ru * Rs) % p, nsat)))
     o.append("    static constexpr uint32_t KSATM[%d] = {%s};" % (nsat, limbs(Ru % p, nsat)))
     for k in (2, 4, 8, 16):
-        c = sub_const(k, p, L)
+        c = sub_const(k, p, L, WU)
         o.append("    static constexpr uint32_t SUB%d[%d] = {%s};  // %d*p, dominating limbs; top limb %d" % (k, L, ", ".join("0x%08xu" % x for x in c), k, c[-1]))
     o.append("    static constexpr uint64_t TOP_PER_P_X1024 = %dull;  // floor(1024 * p / 2^%d): top-limb growth per multiple of p" % ((1024 * p) >> (WU * (L - 1)), WU * (L - 1)))
     return o
@@ -185,7 +189,7 @@ def main():
             out.append("    static constexpr int TWO_ADICITY = %d;" % s)
             out.append("    // w_{2^%d} = %d^((p-1)/2^%d), plain form" % (s, f["qnr"], s))
             out.append("    static constexpr uint32_t ROOT[%d] = {%s};" % (n, limbs(w, n)))
-        out.extend(gen_unsat(name, p))
+        out.extend(gen_unsat(name, p, f.get("wu", WU_DEFAULT)))
         out.append("#if defined(__HIP_DEVICE_COMPILE__)")
         out.append("    // r = a*b/2^(32N) in [0, 2p): product-scanning Montgomery product, 1 v_mad_u64_u32 + 1 v_addc_co_u32")
         out.append("    // per limb product, modulus limbs in SGPRs (see tools/gen_field_params.py:gen_mul)")
