@@ -216,6 +216,31 @@ tkmk_error tkmk_vec_suffix_product(const tkmk_fr *a_dev, uint64_t n, tkmk_fr *ou
 tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, uint32_t cols, const tkmk_vecops_config *cfg, tkmk_fr *out);
 
 /* ---------------------------------------------------------------------------------------------
+ * BN254 (alt_bn128) G1 MSM — the same Pippenger kernels instantiated over the 254-bit fields
+ * (ICICLE v3 exports the per-curve twin `bn254_msm`).  The reference links only icicle-bls12-381
+ * (packages/backend/Cargo.toml:23), so no reference call site exists for it; it is here
+ * because BASELINE.json's configs name a 2^24-point BN254 G1 MSM.  Same config struct, flags, digit/bucket
+ * pipeline and result convention ((x_affine, y_affine, 1) or (0, 1, 0)) as bls12_381_msm.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t limbs[8]; } tkmk_bn254_fr;             /* icicle_bn254::curve::ScalarField */
+typedef struct { uint32_t limbs[8]; } tkmk_bn254_fq;             /* BaseField */
+typedef struct { tkmk_bn254_fq x, y; } tkmk_bn254_g1_affine;     /* 64 B, (0,0) = infinity */
+typedef struct { tkmk_bn254_fq x, y, z; } tkmk_bn254_g1_projective; /* 96 B */
+tkmk_error bn254_msm(const tkmk_bn254_fr *scalars, const tkmk_bn254_g1_affine *bases, int msm_size,
+                     const tkmk_msm_config *cfg, tkmk_bn254_g1_projective *results);
+typedef struct {
+    const tkmk_bn254_fr *scalars;
+    const tkmk_bn254_g1_affine *bases;
+    int msm_size;
+} tkmk_bn254_msm_job;
+tkmk_error tkmk_bn254_msm_multi(const tkmk_bn254_msm_job *jobs, int n_jobs, const tkmk_msm_config *cfg,
+                                tkmk_bn254_g1_projective *results);
+/* input generation twins of tkmk_fr_random_device / tkmk_g1_batch_scalar_mul_device (below) */
+tkmk_error tkmk_bn254_fr_random_device(uint64_t seed, uint64_t first, uint64_t n, tkmk_bn254_fr *out_dev, tkmk_stream s);
+tkmk_error tkmk_bn254_g1_batch_scalar_mul_device(const tkmk_bn254_fr *scalars_dev, const tkmk_bn254_g1_affine *base_host,
+                                                 uint64_t n, tkmk_bn254_g1_affine *out_dev, tkmk_stream s);
+
+/* ---------------------------------------------------------------------------------------------
  * Deterministic input generation on the device — used by bench.py and the tests to
  * build 2^24-point inputs without a multi-GiB fixture; also the "MSM as batched scalar-mul" setup
  * path of libs/src/iotools/mod.rs:1113-1151 (n results = n independent [s_i]P).

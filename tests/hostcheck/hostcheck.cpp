@@ -183,44 +183,68 @@ extern "C" int hc_ntt(const uint8_t *in, uint32_t logn, uint64_t batch, int colu
 #include "ec_u.h"
 
 // plain Fq values in / out; op 0 mul, 1 sqr, 2 add, 3 sub<2> (a - b mod p), 4 pack(unpack) round trip
-extern "C" void hc_fqu_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) {
-    fq_t ksat;
-    for (int i = 0; i < 12; i++) ksat.l[i] = bls12_381_fq_params::KSAT[i];
+template <class P>
+static void fqu_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) {
+    using F = ff<P>;
+    using FU = ffu<P>;
+    const size_t sz = 4 * F::N;
+    typename F::E ksat;
+    for (int i = 0; i < F::N; i++) ksat.l[i] = P::KSAT[i];
     for (size_t i = 0; i < n; i++) {
-        fq_t x, y;
-        load<Fq>(x, a + 48 * i);
-        load<Fq>(y, b + 48 * i);
-        // plain -> x 2^(29L) mod p (what k_convert_bases does) -> strict limbs
-        fqu_t ux = Fqu::from_packed(Fq::mul(x, ksat)), uy = Fqu::from_packed(Fq::mul(y, ksat));
-        fqu_t r;
+        typename F::E x, y;
+        load<F>(x, a + sz * i);
+        load<F>(y, b + sz * i);
+        // plain -> x 2^(W L) mod p (what k_convert_bases does) -> strict limbs
+        typename FU::E ux = FU::from_packed(F::mul(x, ksat)), uy = FU::from_packed(F::mul(y, ksat));
+        typename FU::E r;
         switch (op) {
-            case 0: r = Fqu::mul(ux, uy); break;
-            case 1: r = Fqu::sqr(ux); break;
-            case 2: r = Fqu::add(ux, uy); break;
-            case 3: r = Fqu::sub<2>(ux, uy); break;
+            case 0: r = FU::mul(ux, uy); break;
+            case 1: r = FU::sqr(ux); break;
+            case 2: r = FU::add(ux, uy); break;
+            case 3: r = FU::template sub<2>(ux, uy); break;
             default: r = ux;
         }
-        // back: x 2^(29L) (redundant) -> saturated Montgomery -> plain
-        store<Fq>(o + 48 * i, Fq::from_mont(Fqu::to_sat_mont(r)));
+        // back: x 2^(W L) (redundant) -> saturated Montgomery -> plain
+        store<F>(o + sz * i, F::from_mont(FU::to_sat_mont(r)));
     }
 }
 // chain: acc = P0; acc += P_i (signed) for every following point, through the unsaturated mixed add; result affine plain
-extern "C" void hc_g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, uint8_t *out) {
-    fq_t ksat;
-    for (int i = 0; i < 12; i++) ksat.l[i] = bls12_381_fq_params::KSAT[i];
-    G1U::X acc = G1U::inf();
+template <class P>
+static void g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, uint8_t *out) {
+    using F = ff<P>;
+    using GU = ecu<P>;
+    using G = ec<F>;
+    const size_t sz = 4 * F::N;
+    typename F::E ksat;
+    for (int i = 0; i < F::N; i++) ksat.l[i] = P::KSAT[i];
+    typename GU::X acc = GU::inf();
     for (size_t i = 0; i < n; i++) {
-        g1_affine_t rec;
-        load<Fq>(rec.x, pts + 96 * i);
-        load<Fq>(rec.y, pts + 96 * i + 48);
-        if (!(Fq::is_zero(rec.x) && Fq::is_zero(rec.y))) {
-            rec.x = Fq::mul(rec.x, ksat);
-            rec.y = Fq::mul(rec.y, ksat);
+        affine_t<F> rec;
+        load<F>(rec.x, pts + 2 * sz * i);
+        load<F>(rec.y, pts + 2 * sz * i + sz);
+        if (!(F::is_zero(rec.x) && F::is_zero(rec.y))) {
+            rec.x = F::mul(rec.x, ksat);
+            rec.y = F::mul(rec.y, ksat);
         }
-        G1U::A q;
-        if (!G1U::load_affine(q, rec)) continue;
-        if (negate[i]) q = G1U::neg(q);
-        acc = G1U::add_mixed(acc, q);
+        typename GU::A q;
+        if (!GU::load_affine(q, rec)) continue;
+        if (negate[i]) q = GU::neg(q);
+        acc = GU::add_mixed(acc, q);
     }
-    store_aff(out, G1::to_affine(G1U::to_sat(acc)));
+    affine_t<F> r = G::to_affine(GU::to_sat(acc));
+    store<F>(out, F::from_mont(r.x));
+    store<F>(out + sz, F::from_mont(r.y));
+}
+extern "C" {
+void hc_fqu_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { fqu_op<bls12_381_fq_params>(op, a, b, o, n); }
+void hc_g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, uint8_t *out) {
+    g1u_accumulate<bls12_381_fq_params>(pts, negate, n, out);
+}
+// BN254 instantiation (8 saturated / 10 x 28-bit unsaturated limbs)
+void hc_bn254_fr_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { binop<ff<bn254_fr_params>>(op, a, b, o, n); }
+void hc_bn254_fq_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { binop<ff<bn254_fq_params>>(op, a, b, o, n); }
+void hc_bn254_fqu_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { fqu_op<bn254_fq_params>(op, a, b, o, n); }
+void hc_bn254_g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, uint8_t *out) {
+    g1u_accumulate<bn254_fq_params>(pts, negate, n, out);
+}
 }

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "tkmk.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = re.findall(r"\b((?:tkmk|bls12_381)_[a-z0-9_]+)\s*\(", hdr)
+    names = re.findall(r"\b((?:tkmk|bls12_381|bn254)_[a-z0-9_]+)\s*\(", hdr)
     return sorted(set(names))
 
 

@@ -144,3 +144,66 @@ def test_unsaturated_mixed_add_chain_matches_oracle(hc, oracle):
     hc.hc_g1u_accumulate(_p(buf), _p(flags), ctypes.c_size_t(len(seq2)), _p(out))
     assert (out == want).all()
     assert (want == P[1]).all()
+
+
+# ---- BN254 instantiation of the same templates (8 saturated limbs, 10 x 28-bit unsaturated limbs) ----
+@pytest.mark.parametrize("field", ["fr", "fq"])
+def test_bn254_field_templates(hc, oracle, field):
+    bn = oracle.bn254
+    rnd = random.Random(5)
+    mod = bn.R_MOD if field == "fr" else bn.P_MOD
+    fn = getattr(hc, "hc_bn254_%s_op" % field)
+    n = 200
+    a, b = _edge(mod, n, rnd), _edge(mod, n, rnd)
+    rnd.shuffle(b)
+    A, B = oracle.to_bytes(a, 32), oracle.to_bytes(b, 32)
+    out = np.empty_like(A)
+    o_add, o_sub, o_mul, o_inv = [getattr(bn, "%s_%s" % (field, k)) for k in ("add", "sub", "mul", "inv")]
+    for op, want in ((0, o_add(A, B)), (1, o_sub(A, B)), (2, o_mul(A, B)), (3, o_mul(A, B)), (4, o_inv(A)),
+                     (5, o_sub(np.zeros_like(A), A))):
+        fn(op, _p(A), _p(B), _p(out), ctypes.c_size_t(n))
+        assert (out == want).all(), "op %d" % op
+    # and against plain Python integers (the oracle's BN254 fields are new code too)
+    assert oracle.to_ints(o_mul(A, B), 32) == [x * y % mod for x, y in zip(a, b)]
+    assert oracle.to_ints(o_inv(A), 32) == [pow(x, -1, mod) if x else 0 for x in a]
+
+
+def test_bn254_unsaturated_field_and_chain(hc, oracle):
+    bn = oracle.bn254
+    rnd = random.Random(19)
+    mod = bn.P_MOD
+    a, b = _edge(mod, 400, rnd), _edge(mod, 400, rnd)
+    rnd.shuffle(b)
+    a += [mod - 1] * 4 + [(1 << 253) - 1, (1 << 252) - 1]
+    b += [mod - 1, 1, 0, mod - 2, (1 << 253) - 1, (1 << 28) - 1]
+    n = len(a)
+    A, B = oracle.to_bytes(a, 32), oracle.to_bytes(b, 32)
+    out = np.empty_like(A)
+    for op, want in ((0, bn.fq_mul(A, B)), (1, bn.fq_mul(A, A)), (2, bn.fq_add(A, B)), (3, bn.fq_sub(A, B)), (4, A)):
+        hc.hc_bn254_fqu_op(op, _p(A), _p(B), _p(out), ctypes.c_size_t(n))
+        assert (out == want).all(), "op %d" % op
+    # accumulation chain with infinity records, a doubling, a cancellation to infinity and a restart
+    pts = bn.g1_random_bases(78, 40)
+    P = [pts[64 * i:64 * (i + 1)].copy() for i in range(40)]
+    seq = P[:10] + [np.zeros(64, np.uint8)] + [P[10], P[10]] + P[11:20] + [P[3]] + P[20:]
+    neg = [0] * len(seq)
+    neg[4] = neg[15] = 1
+    acc = np.zeros(64, np.uint8)
+    for q, s in zip(seq, neg):
+        acc = bn.g1_add(acc, bn.g1_neg(q) if s else q)
+    seq2 = seq + [acc] + [P[0], P[0], P[1]]
+    neg2 = neg + [1] + [0, 1, 0]
+    flags = np.array(neg2, np.uint8)
+    buf = np.concatenate(seq2)
+    out = np.empty(64, np.uint8)
+    hc.hc_bn254_g1u_accumulate(_p(buf), _p(flags), ctypes.c_size_t(len(seq2)), _p(out))
+    assert (out == P[1]).all()
+    # a long random chain keeps every bound assertion of ffu / ecu satisfied
+    pts = bn.g1_random_bases(79, 300)
+    flags = np.array([rnd.randrange(2) for _ in range(300)], np.uint8)
+    want = np.zeros(64, np.uint8)
+    for i in range(300):
+        q = pts[64 * i:64 * (i + 1)].copy()
+        want = bn.g1_add(want, bn.g1_neg(q) if flags[i] else q)
+    hc.hc_bn254_g1u_accumulate(_p(pts), _p(flags), ctypes.c_size_t(300), _p(out))
+    assert (out == want).all()

@@ -242,3 +242,56 @@ def test_suffix_product_definition(oracle):
     vals = [3, 5, 7, 11, 13]
     out = oracle.to_ints(oracle.fr_suffix_product(oracle.to_bytes(vals, 32)), 32)
     assert out == [5 * 7 * 11 * 13, 7 * 11 * 13, 11 * 13, 13, 1]
+
+
+def test_bn254_constants(oracle):
+    """BN254 (alt_bn128) has no counterpart in the reference; its oracle instantiation is pinned on the published curve
+    constants (EIP-196): p, r, generator (1, 2) on y^2 = x^3 + 3, 2G, r G = O, and on plain Python integer arithmetic."""
+    bn = oracle.bn254
+    p, r = bn.P_MOD, bn.R_MOD
+    assert p == 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+    assert r == 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+    # BN parameterisation: p = 36u^4+36u^3+24u^2+6u+1, r = 36u^4+36u^3+18u^2+6u+1 with u = 4965661367192848881
+    u = 4965661367192848881
+    assert p == 36 * u**4 + 36 * u**3 + 24 * u**2 + 6 * u + 1 and r == 36 * u**4 + 36 * u**3 + 18 * u**2 + 6 * u + 1
+    g = bn.g1_generator()
+    assert oracle.to_ints(g, 32) == [1, 2] and bn.g1_on_curve(g)
+    two = oracle.to_ints(bn.g1_add(g, g), 32)
+    assert two == [1368015179489954701390400359078579693043519447331113978918064868415326638035,
+                   9918110051302171585080402603319702774565515993150576347155970296011118125764]
+    assert (two[1] ** 2 - two[0] ** 3 - 3) % p == 0
+    assert (bn.g1_scalar_mul(oracle.to_bytes([r - 1], 32), g) == bn.g1_neg(g)).all()
+    assert not bn.g1_scalar_mul(oracle.to_bytes([0], 32), g).any()
+
+    def add(A, B):
+        if A is None or B is None:
+            return A or B
+        (x1, y1), (x2, y2) = A, B
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return x3, (lam * (x1 - x3) - y1) % p
+
+    def mul(k, A):
+        R = None
+        while k:
+            if k & 1:
+                R = add(R, A)
+            A = add(A, A)
+            k >>= 1
+        return R
+
+    s = bn.fr_random(3, 8)
+    pts = bn.g1_random_bases(4, 8)
+    acc = None
+    for i in range(8):
+        k = oracle.to_ints(s[32 * i:32 * i + 32], 32)[0]
+        P = tuple(oracle.to_ints(pts[64 * i:64 * i + 64], 32))
+        assert (P[1] ** 2 - P[0] ** 3 - 3) % p == 0
+        acc = add(acc, mul(k, P))
+    assert oracle.to_ints(bn.g1_msm(s, pts), 32) == list(acc)
+    assert (bn.g1_msm(s, pts) == bn.g1_msm_naive(s, pts)).all()

@@ -12,7 +12,9 @@ __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t idx) {
 }
 
 // element i = outputs 4i..4i+3 of the stream as little-endian 64-bit limbs, reduced mod r
-__global__ __launch_bounds__(256) void k_fr_random(uint64_t seed, uint64_t first, uint64_t n, fr_t *__restrict__ out) {
+template <class Fr>
+__global__ __launch_bounds__(256) void k_fr_random(uint64_t seed, uint64_t first, uint64_t n, typename Fr::E *__restrict__ out) {
+    using fr_t = typename Fr::E;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     fr_t x;
@@ -26,8 +28,13 @@ __global__ __launch_bounds__(256) void k_fr_random(uint64_t seed, uint64_t first
 }
 
 // out[i] = [s_i] P through a 4-bit fixed-window table of P held in LDS (15 multiples, XYZZ)
-__global__ __launch_bounds__(128) void k_g1_batch_scalar_mul(const fr_t *__restrict__ scalars, g1_affine_t base, uint64_t n,
-                                                            g1_affine_t *__restrict__ out) {
+template <class Fr, class Fq>
+__global__ __launch_bounds__(128) void k_g1_batch_scalar_mul(const typename Fr::E *__restrict__ scalars, affine_t<Fq> base, uint64_t n,
+                                                            affine_t<Fq> *__restrict__ out) {
+    using fr_t = typename Fr::E;
+    using G1 = ec<Fq>;
+    using g1_affine_t = affine_t<Fq>;
+    using g1_xyzz_t = xyzz_t<Fq>;
     __shared__ g1_xyzz_t table[16];
     if (threadIdx.x == 0) {
         table[0] = G1::inf();
@@ -55,32 +62,50 @@ __global__ __launch_bounds__(128) void k_g1_batch_scalar_mul(const fr_t *__restr
     tk_store(out + i, r);
 }
 
-TK_API tkmk_error tkmk_fr_random_device(uint64_t seed, uint64_t first, uint64_t n, tkmk_fr *out_dev, tkmk_stream s) {
+template <class Fr>
+static tkmk_error fr_random_device(uint64_t seed, uint64_t first, uint64_t n, void *out_dev, tkmk_stream s) {
     if (!out_dev && n) return TKMK_ERR_INVALID_POINTER;
     TK_TRY(tk_require_device());
     if (n == 0) return TKMK_SUCCESS;
-    hipLaunchKernelGGL(k_fr_random, tk_div_up(n, 256), 256, 0, tk_stream(s), seed, first, n, (fr_t *)out_dev);
+    hipLaunchKernelGGL((k_fr_random<Fr>), tk_div_up(n, 256), 256, 0, tk_stream(s), seed, first, n, (typename Fr::E *)out_dev);
     TK_HIP(hipGetLastError());
     TK_HIP(hipStreamSynchronize(tk_stream(s)));
     return TKMK_SUCCESS;
 }
+TK_API tkmk_error tkmk_fr_random_device(uint64_t seed, uint64_t first, uint64_t n, tkmk_fr *out_dev, tkmk_stream s) {
+    return fr_random_device<Fr>(seed, first, n, out_dev, s);
+}
+TK_API tkmk_error tkmk_bn254_fr_random_device(uint64_t seed, uint64_t first, uint64_t n, tkmk_bn254_fr *out_dev, tkmk_stream s) {
+    return fr_random_device<ff<bn254_fr_params>>(seed, first, n, out_dev, s);
+}
 
-TK_API tkmk_error tkmk_g1_batch_scalar_mul_device(const tkmk_fr *scalars_dev, const tkmk_g1_affine *base_host, uint64_t n,
-                                                  tkmk_g1_affine *out_dev, tkmk_stream s) {
+template <class Fr, class Fq>
+static tkmk_error g1_batch_scalar_mul_device(const void *scalars_dev, const uint32_t *base_x, const uint32_t *base_y, uint64_t n,
+                                             void *out_dev, tkmk_stream s) {
     if ((!scalars_dev || !out_dev) && n) return TKMK_ERR_INVALID_POINTER;
-    if (!base_host) return TKMK_ERR_INVALID_POINTER;
     TK_TRY(tk_require_device());
     if (n == 0) return TKMK_SUCCESS;
-    g1_affine_t b;
-    for (int i = 0; i < 12; i++) {
-        b.x.l[i] = base_host->x.limbs[i];
-        b.y.l[i] = base_host->y.limbs[i];
+    affine_t<Fq> b;
+    for (int i = 0; i < Fq::N; i++) {
+        b.x.l[i] = base_x[i];
+        b.y.l[i] = base_y[i];
     }
-    hipLaunchKernelGGL(k_g1_batch_scalar_mul, tk_div_up(n, 128), 128, 0, tk_stream(s), (const fr_t *)scalars_dev, b, n,
-                       (g1_affine_t *)out_dev);
+    hipLaunchKernelGGL((k_g1_batch_scalar_mul<Fr, Fq>), tk_div_up(n, 128), 128, 0, tk_stream(s), (const typename Fr::E *)scalars_dev, b,
+                       n, (affine_t<Fq> *)out_dev);
     TK_HIP(hipGetLastError());
     TK_HIP(hipStreamSynchronize(tk_stream(s)));
     return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_g1_batch_scalar_mul_device(const tkmk_fr *scalars_dev, const tkmk_g1_affine *base_host, uint64_t n,
+                                                  tkmk_g1_affine *out_dev, tkmk_stream s) {
+    if (!base_host) return TKMK_ERR_INVALID_POINTER;
+    return g1_batch_scalar_mul_device<Fr, Fq>(scalars_dev, base_host->x.limbs, base_host->y.limbs, n, out_dev, s);
+}
+TK_API tkmk_error tkmk_bn254_g1_batch_scalar_mul_device(const tkmk_bn254_fr *scalars_dev, const tkmk_bn254_g1_affine *base_host,
+                                                        uint64_t n, tkmk_bn254_g1_affine *out_dev, tkmk_stream s) {
+    if (!base_host) return TKMK_ERR_INVALID_POINTER;
+    return g1_batch_scalar_mul_device<ff<bn254_fr_params>, ff<bn254_fq_params>>(scalars_dev, base_host->x.limbs, base_host->y.limbs, n,
+                                                                               out_dev, s);
 }
 
 // dst[i] = src[idx[i]] for rows of row_bytes (multiple of 16): the device-side gather behind the binding

@@ -82,7 +82,8 @@ SYMBOLS = [
     "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
     "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
     "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
-    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm", "tkmk_msm_multi",
+    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "tkmk_bn254_fr_random_device",
+    "tkmk_bn254_g1_batch_scalar_mul_device",
     "tkmk_ntt_default_config", "bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain",
     "bls12_381_ntt", "tkmk_bintt", "tkmk_vecops_default_config", "bls12_381_vector_add", "bls12_381_vector_sub",
     "bls12_381_vector_mul", "bls12_381_vector_div", "bls12_381_vector_inv", "bls12_381_scalar_add_vec",
@@ -322,8 +323,16 @@ def _len(a):
 
 
 # ---- MSM (reference: libs/src/iotools/mod.rs:2093-2099, group_structures/mod.rs:108-143) ----
-def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize=0, stream=None):
-    """returns `batch` projective results (144 B each) on the host"""
+# curve -> (msm symbol, multi symbol, fr_random symbol, batch scalar-mul symbol, affine bytes)
+_CURVES = {
+    "bls12_381": ("bls12_381_msm", "tkmk_msm_multi", "tkmk_fr_random_device", "tkmk_g1_batch_scalar_mul_device", 96),
+    "bn254": ("bn254_msm", "tkmk_bn254_msm_multi", "tkmk_bn254_fr_random_device", "tkmk_bn254_g1_batch_scalar_mul_device", 64),
+}
+
+
+def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize=0, stream=None, curve="bls12_381"):
+    """returns `batch` projective results (144 B each; 96 B for bn254) on the host"""
+    sym, _, _, _, aff = _CURVES[curve]
     cfg = lib().tkmk_msm_default_config()
     n = _len(scalars) // batch if msm_size is None else msm_size
     cfg.batch_size = batch
@@ -333,8 +342,8 @@ def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize
     cfg.c = c
     cfg.bitsize = bitsize
     cfg.stream_handle = stream
-    out = np.empty(144 * batch, np.uint8)
-    _check(lib().bls12_381_msm(_p(scalars), _p(bases), int(n), ctypes.byref(cfg), _p(out)), "bls12_381_msm")
+    out = np.empty(aff // 2 * 3 * batch, np.uint8)
+    _check(getattr(lib(), sym)(_p(scalars), _p(bases), int(n), ctypes.byref(cfg), _p(out)), sym)
     return out
 
 
@@ -342,9 +351,10 @@ class MsmJob(ctypes.Structure):
     _fields_ = [("scalars", ctypes.c_void_p), ("bases", ctypes.c_void_p), ("msm_size", ctypes.c_int)]
 
 
-def msm_multi(jobs, c=0, bitsize=0, stream=None):
+def msm_multi(jobs, c=0, bitsize=0, stream=None, curve="bls12_381"):
     """jobs = [(scalars, bases[, msm_size])...], all host buffers or all DeviceBuffers; returns len(jobs) projective
-    results (144 B each) on the host.  Independent MSMs are pipelined over internal streams (tkmk_msm_multi)."""
+    results on the host.  Independent MSMs are pipelined over internal streams (tkmk_msm_multi)."""
+    _, sym, _, _, aff = _CURVES[curve]
     cfg = lib().tkmk_msm_default_config()
     if not jobs:
         return np.empty(0, np.uint8)
@@ -361,32 +371,34 @@ def msm_multi(jobs, c=0, bitsize=0, stream=None):
     for k, j in enumerate(jobs):
         n = j[2] if len(j) > 2 else _len(j[0])
         arr[k] = MsmJob(_p(j[0]).value, _p(j[1]).value, int(n))
-    out = np.empty(144 * len(jobs), np.uint8)
-    _check(lib().tkmk_msm_multi(arr, len(jobs), ctypes.byref(cfg), _p(out)), "tkmk_msm_multi")
+    out = np.empty(aff // 2 * 3 * len(jobs), np.uint8)
+    _check(getattr(lib(), sym)(arr, len(jobs), ctypes.byref(cfg), _p(out)), sym)
     return out
 
 
-def projective_to_affine_bytes(p144):
+def projective_to_affine_bytes(proj, curve="bls12_381"):
     """ABI results are canonical (x_aff, y_aff, 1) / (0,1,0): dropping z is the affine conversion"""
+    aff = _CURVES[curve][4]
+    pb = aff // 2 * 3
     out = []
-    for i in range(0, p144.size, 144):
-        z = p144[i + 96:i + 144]
-        out.append(np.zeros(96, np.uint8) if not z.any() else p144[i:i + 96].copy())
+    for i in range(0, proj.size, pb):
+        z = proj[i + aff:i + pb]
+        out.append(np.zeros(aff, np.uint8) if not z.any() else proj[i:i + aff].copy())
     return np.concatenate(out)
 
 
 # ---- deterministic device-side input generation (SURVEY.md §8d) ----
-def fr_random_device(seed, n, first=0, out=None):
+def fr_random_device(seed, n, first=0, out=None, curve="bls12_381"):
+    sym = _CURVES[curve][2]
     out = DeviceBuffer(32 * n) if out is None else out
-    _check(lib().tkmk_fr_random_device(ctypes.c_uint64(seed), ctypes.c_uint64(first), ctypes.c_uint64(n), _p(out), None),
-           "tkmk_fr_random_device")
+    _check(getattr(lib(), sym)(ctypes.c_uint64(seed), ctypes.c_uint64(first), ctypes.c_uint64(n), _p(out), None), sym)
     return out
 
 
-def g1_batch_scalar_mul_device(scalars_dev, base_host, n, out=None):
-    out = DeviceBuffer(96 * n) if out is None else out
-    _check(lib().tkmk_g1_batch_scalar_mul_device(_p(scalars_dev), _p(base_host), ctypes.c_uint64(n), _p(out), None),
-           "tkmk_g1_batch_scalar_mul_device")
+def g1_batch_scalar_mul_device(scalars_dev, base_host, n, out=None, curve="bls12_381"):
+    sym, aff = _CURVES[curve][3], _CURVES[curve][4]
+    out = DeviceBuffer(aff * n) if out is None else out
+    _check(getattr(lib(), sym)(_p(scalars_dev), _p(base_host), ctypes.c_uint64(n), _p(out), None), sym)
     return out
 
 
