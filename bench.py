@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--cpu-sample-logn", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true", help="skip the secondary NTT measurements (BASELINE.json configs[2], _biNTT)")
+    ap.add_argument("--no-bn254", action="store_true", help="skip the secondary BN254 G1 MSM measurement (BASELINE.json configs[1] as worded)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --dist-backend gloo)")
     args = ap.parse_args()
@@ -152,9 +153,12 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(tkmk, args.cpu_sample_logn)
-        if not args.no_ntt:
+        if not args.no_bn254 or not args.no_ntt:
             scalars.free()
             bases.free()
+        if not args.no_bn254:
+            out["bn254_msm"] = _bn254_secondary(tkmk, args.logn)
+        if not args.no_ntt:
             out["ntt"] = _ntt_secondary(tkmk)
         out["result_x_lo"] = int.from_bytes(bytes(result[:8]), "little")
         print(json.dumps(out), flush=True)
@@ -169,6 +173,36 @@ def _generator():
     y = [1187375073, 212476713, 2726857444, 3493644100, 738505709, 14358731, 3587181302, 4243972245, 1948093156,
          2694721773, 3819610353, 146011265]
     return b"".join(int(v).to_bytes(4, "little") for v in x + y)
+
+
+def _bn254_secondary(tkmk, logn):
+    """BASELINE.json configs[1] as worded ("2^24-point BN254 G1 Pippenger MSM"): the same kernels instantiated over the
+    254-bit fields (csrc/msm_bn254.hip).  Secondary because the reference has no BN254 path."""
+    n = 1 << logn
+    s = tkmk.fr_random_device(SEED + 5, n, curve="bn254")
+    h = tkmk.fr_random_device(SEED + 6, n, curve="bn254")
+    g = np.zeros(64, np.uint8)
+    g[0], g[32] = 1, 2
+    b = tkmk.g1_batch_scalar_mul_device(h, g, n, curve="bn254")
+    h.free()
+    tkmk.msm(s, b, curve="bn254")
+    tkmk.profile_enable(True)
+    tkmk.profile_reset()
+    tkmk.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tkmk.msm(s, b, curve="bn254")
+    tkmk.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tkmk.profile_enable(False)
+    acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
+    s.free()
+    b.free()
+    return {"workload": "2^%d-point BN254 G1 Pippenger MSM, inputs resident in HBM" % logn, "ms_per_msm": dt * 1e3,
+            "points_per_s": n / dt, "group_adds_per_s": n / dt * ADDS_PER_POINT,
+            "accumulate_kernel_ms": acc_ms / acc_cnt if acc_cnt else None,
+            "hbm_frac_of_peak": (n * (32 + 64) / (acc_ms / acc_cnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if acc_cnt else None}
 
 
 def _traffic_from_profiles(logn):
