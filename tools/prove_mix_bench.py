@@ -21,7 +21,11 @@ from tkmk.poly import DensePolynomialExt as P  # noqa: E402
 from tkmk.sigma import Sigma1  # noqa: E402
 
 tkmk.set_device(0)
-n, s_max, m_i = 4096, 256, 4096
+S_MAX = 256
+for a in sys.argv[1:]:
+    if a.startswith("--s-max="):
+        S_MAX = int(a.split("=")[1])    # 256 = production library; 1024 = the "2^22-constraint" shape of SURVEY.md section 8d cfg 4
+n, s_max, m_i = 4096, S_MAX, 4096
 tkmk.init_ntt_domain_for_size(4 * max(m_i, n) * 2 * s_max)            # libs/src/utils/mod.rs:51-58
 rs_x, rs_y = max(2 * n, 2 * m_i), 2 * s_max                            # xy_powers: 8192 x 512 = 2^22 points
 
@@ -61,7 +65,7 @@ def run():
     polys = [P.from_rou_evals(e, n, s_max) for e in ev]
     tick("init.intt", t0)
     t0 = time.perf_counter()
-    commits(((128, 1), (728, 1), (1 << 19, 1), (1 << 19, 1)), 20)     # A_free, O_pub, O_mid, O_prv (order of magnitude)
+    commits(((128, 1), (728, 1), (2048 * s_max, 1), (2048 * s_max, 1)), 20)     # A_free, O_pub, O_mid, O_prv (order of magnitude)
     tick("init.binding_msm", t0)
     u, v, w = polys[1], polys[2], polys[3]
     # ---- prove0: p0 = u*v - w (2 fwd + 1 inv NTT at 8192x512), div_by_vanishing_opt, 6 commits
@@ -72,7 +76,7 @@ def run():
     q_ax, q_ay = p0.div_by_vanishing_opt(n, s_max)
     tick("prove0.div_by_vanishing", t0)
     t0 = time.perf_counter()
-    commits(((4097, 257), (4097, 257), (4097, 257), (4096, 256), (4096, 256), (4099, 259)), 30)   # U,V,W,Q_AX,Q_AY,B
+    commits(((n + 1, s_max + 1), (n + 1, s_max + 1), (n + 1, s_max + 1), (n, s_max), (n, s_max), (n + 3, s_max + 3)), 30)   # U,V,W,Q_AX,Q_AY,B
     tick("prove0.encode", t0)
     # ---- prove1: 2 fwd NTT 4096x256, batched division, 2 transposes, 1 iNTT, 1 commit
     t0 = time.perf_counter()
@@ -84,7 +88,7 @@ def run():
     r_poly = P.from_rou_evals(tr2, n, s_max)
     tick("prove1.poly", t0)
     t0 = time.perf_counter()
-    commits(((4097, 257),), 31)
+    commits(((n + 1, s_max + 1),), 31)
     tick("prove1.encode", t0)
     # ---- prove2: 2 scale_coeffs, 3 Lagrange iNTTs, p_comb fused on 16384x512 (7 leaf NTTs + ~15 pointwise + 1 inverse),
     #              div_by_vanishing_opt, 2 commits
@@ -109,7 +113,7 @@ def run():
     q_cx, q_cy = p_comb.div_by_vanishing_opt(m_i, s_max)
     tick("prove2.div_by_vanishing", t0)
     t0 = time.perf_counter()
-    commits(((8192, 511), (8191, 257)), 32)
+    commits(((2 * m_i, 2 * s_max - 1), (2 * m_i - 1, s_max + 1)), 32)
     tick("prove2.encode", t0)
     # ---- prove3: 4 bivariate evaluations, 2 scale_coeffs
     t0 = time.perf_counter()
@@ -120,14 +124,15 @@ def run():
     tick("prove3.poly", t0)
     # ---- prove4: 5 div_by_ruffini, a few _mul at 8192x512, 9 commits
     t0 = time.perf_counter()
-    big = P.from_coeffs(tkmk.fr_random_device(50, 8192 * 512), 8192, 512)
+    big = P.from_coeffs(tkmk.fr_random_device(50, 2 * m_i * 2 * s_max), 2 * m_i, 2 * s_max)
     for k in range(5):
         big.div_by_ruffini(chi, zeta)
     for k in range(3):
         _ = u * v
     tick("prove4.poly", t0)
     t0 = time.perf_counter()
-    commits(((4825, 258), (4097, 511), (4098, 511), (8191, 511), (1, 256), (1, 256), (1, 510), (1, 510), (127, 1)), 33)
+    commits(((4825, s_max + 2), (n + 1, 2 * s_max - 1), (n + 2, 2 * s_max - 1), (2 * m_i - 1, 2 * s_max - 1), (1, s_max), (1, s_max), (1, 2 * s_max - 2),
+             (1, 2 * s_max - 2), (127, 1)), 33)
     tick("prove4.encode", t0)
     return t
 
@@ -137,7 +142,7 @@ t0 = time.perf_counter()
 sections = run()
 total = time.perf_counter() - t0
 slots = n * s_max
-print(json.dumps({"commits": "tkmk_msm_multi per round" if MULTI else "sequential bls12_381_msm", "workload": "prove hot-path replay, production shape n=4096 s_max=256 m_I=4096 (2^20 constraint slots), synthetic data",
+print(json.dumps({"commits": "tkmk_msm_multi per round" if MULTI else "sequential bls12_381_msm", "workload": "prove hot-path replay, n=%d s_max=%d m_I=%d (2^%d constraint slots%s), synthetic data" % (n, s_max, m_i, (n * s_max).bit_length() - 1, ", production shape" if s_max == 256 else ""),
                   "total_s": total, "constraint_slots_per_s": slots / total,
                   "msm_s": sum(v for k, v in sections.items() if "encode" in k or "msm" in k),
                   "poly_s": sum(v for k, v in sections.items() if "encode" not in k and "msm" not in k),
