@@ -28,7 +28,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MAD_PEAK_PER_S = 3.2e13          # measured v_mad_u64_u32 issue rate, lane-ops/s (profiles/r01_arith_microbench_v3.json)
-MADS_PER_BUCKET_ADD = 8 * 392 + 2 * 301   # madd-2008-s on 14 x 29-bit limbs: 8 products + 2 squares (csrc/ffu.h)
+MADS_PER_BUCKET_ADD = 7 * 392 + 196 + 2 * 301   # madd-2008-s on 14 x 29-bit limbs: 8 products (two share one reduction) + 2 squares (csrc/ffu.h, ec_u.h)
 ADDS_PER_POINT = 16              # SURVEY.md §8d cfg 2: N * ceil(b/c) at c = 16, b = 255
 ALG_BYTES_PER_POINT = 32 + 96    # each scalar and base read once
 SEED = 0x746F6B616D616B00

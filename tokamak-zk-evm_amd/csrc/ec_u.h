@@ -4,13 +4,13 @@
 // the saturated implementation (ec.h), so there is a single place where they are decided.
 //
 // Value bounds (multiples of p; every operand of a product must stay below 2^10 p, every subtrahend below the K of
-// its sub<K>).  Products return < 1.03 p.  With the accumulator invariant X1 < 5.03p, Y1 < 3.03p, ZZ1, ZZZ1 < 1.03p:
+// its sub<K>).  Products return < 1.03 p.  With the accumulator invariant X1 < 5.03p, Y1, ZZ1, ZZZ1 < 1.03p:
 //   U2 = X2 ZZ1, S2 = Y2 ZZZ1                    < 1.03
 //   P  = U2 - X1  (sub<8>)   in (2.97, 9.03)     == 0 mod p  <=>  P in {3p..9p}
-//   R  = S2 - Y1  (sub<4>)   in (0.97, 5.03)
+//   R  = S2 - Y1  (sub<2>)   in (0.97, 3.03)
 //   PP = P^2, PPP = P PP, Q = X1 PP              < 1.03
 //   X3 = R^2 - (PPP + 2Q)  (sub<4>, t < 3.09)    < 5.03      (invariant restored)
-//   Y3 = R (Q - X3) - Y1 PPP  (sub<8>, sub<2>)   < 3.03
+//   Y3 = [R (Q - X3) + (2p - Y1) PPP] / R'       < 1.03      (sub<8>, sub<2>; ONE reduction for both products)
 //   ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP                < 1.03
 #pragma once
 #include "ec.h"
@@ -117,7 +117,7 @@ struct ecu {
         E pd = FU::template sub<8>(u2, p.x);
         // P == 0 mod p  <=>  P = j p with 3 <= j <= 9: only then can q share its x with the accumulator
         if (FU::maybe_multiple_of_p(pd, 9)) return add_mixed_slow(p, q);
-        E rd = FU::template sub<4>(s2, p.y);
+        E rd = FU::template sub<2>(s2, p.y);
         E pp = FU::sqr(pd);
         E ppp = FU::mul(pd, pp);
         E qq = FU::mul(p.x, pp);
@@ -126,7 +126,7 @@ struct ecu {
         E t = FU::add(ppp, FU::dbl(qq));
         r.x = FU::template sub<4>(FU::sqr(rd), t);
         E d = FU::template sub<8>(qq, r.x);
-        r.y = FU::template sub<2>(FU::mul(rd, d), FU::mul(p.y, ppp));
+        r.y = FU::mul_add(rd, d, FU::template sub<2>(FU::zero(), p.y), ppp);  // R (Q - X3) + (2p - Y1) PPP, one reduction
         r.zz = FU::mul(p.zz, pp);
         r.zzz = FU::mul(p.zzz, ppp);
         return r;

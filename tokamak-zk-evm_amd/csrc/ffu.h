@@ -120,6 +120,43 @@ struct ffu {
         r.l[L - 1] = (uint32_t)acc;
         return r;
     }
+    // (a*b + c*d)/2^(W L) mod p with ONE Montgomery reduction (the reduction is a third of a product's multiply-adds):
+    // strict operands with top limbs <= MASK, a*b + c*d < 2^20 p^2; strict result < 1.03 p.  A column holds up to 3L
+    // products < 2^(2W): 42 * 2^58 (W = 29, L = 14) and 30 * 2^56 (W = 28, L = 10) are both below 2^64.
+    static FF_HD E mul_add(const E &a, const E &b, const E &c, const E &d) {
+        static_assert(3 * L < (1 << (64 - 2 * (int)W)), "column accumulator would overflow");
+        FFU_ASSERT(strict(a) && strict(b) && strict(c) && strict(d));
+        FFU_ASSERT(a.l[L - 1] <= MASK && b.l[L - 1] <= MASK && c.l[L - 1] <= MASK && d.l[L - 1] <= MASK);
+        uint32_t m[L];
+        uint64_t acc = 0;
+        E r;
+#pragma unroll
+        for (int k = 0; k < L; k++) {
+#pragma unroll
+            for (int j = 0; j <= k; j++) {
+                acc += (uint64_t)a.l[j] * b.l[k - j];
+                acc += (uint64_t)c.l[j] * d.l[k - j];
+            }
+#pragma unroll
+            for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * P::MODU[k - j];
+            m[k] = ((uint32_t)acc * P::INVU) & MASK;
+            acc += (uint64_t)m[k] * P::MODU[0];
+            acc >>= W;
+        }
+#pragma unroll
+        for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+            for (int j = k - L + 1; j < L; j++) {
+                acc += (uint64_t)a.l[j] * b.l[k - j];
+                acc += (uint64_t)c.l[j] * d.l[k - j];
+                acc += (uint64_t)m[j] * P::MODU[k - j];
+            }
+            r.l[k - L] = (uint32_t)acc & MASK;
+            acc >>= W;
+        }
+        r.l[L - 1] = (uint32_t)acc;
+        return r;
+    }
     // a^2: off-diagonal products once against 2a (limbs < 2^30; column bound still below 2^63)
     static FF_HD E sqr(const E &a) {
         FFU_ASSERT(strict(a) && a.l[L - 1] <= MASK);
