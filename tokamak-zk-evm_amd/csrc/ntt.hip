@@ -15,6 +15,7 @@
 // not by HBM; no MFMA (integer modular arithmetic, not a dense contraction).
 #include <stdio.h>
 
+#include <map>
 #include <mutex>
 
 #include "common.h"
@@ -29,6 +30,11 @@ struct ntt_domain_t {
     fr_t *tw = nullptr;  // tw[i] = w_N^i (Montgomery), i < N
     uint32_t logN = 0;
     fr_t root_plain;
+    // inter-pass (Stockham) twiddle tables, built on first use and kept until the domain is released:
+    // key (logNs, logR, inverse) -> table[r << logNs | jm] = w_{Ns R}^{+-jm r}.  Gathering these from tw[] costs more
+    // than the pass's butterflies (each lane hits its own cache line: 7 ms of an 11 ms pass at 256 x 2^20); in this
+    // layout consecutive lines read consecutive entries, like the data itself.
+    std::map<uint32_t, fr_t *> stockham;
 };
 static ntt_domain_t g_dom;
 static std::mutex g_dom_mu;
@@ -42,6 +48,13 @@ __global__ __launch_bounds__(256) void k_build_twiddles(fr_t *__restrict__ tw, c
     for (uint32_t b = 0; b < logn; b++)
         if ((i >> b) & 1) acc = Fr::mul(acc, tk_load(pw + b));
     tk_store(tw + i, acc);
+}
+// table[(r << logNs) + jm] = w_{Ns R}^{jm r} in the pass direction (copied out of tw[])
+__global__ __launch_bounds__(256) void k_build_stockham(fr_t *__restrict__ out, const fr_t *__restrict__ tw, ntt_pass_t p) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> (p.logNs + p.logR)) return;
+    uint64_t r = i >> p.logNs, jm = i & (((uint64_t)1 << p.logNs) - 1);
+    tk_store(out + i, tk_load(tw + ntt_tw_index(p, p.logNs + p.logR, jm * r)));
 }
 // out[i] = scale * g^i (Montgomery): the coset pre-/post-scale table of one NTT call
 __global__ __launch_bounds__(256) void k_build_powers(fr_t *__restrict__ out, fr_t g, fr_t scale, uint64_t n) {
@@ -67,8 +80,9 @@ struct lds_elem {
 
 // One Stockham pass over one tile per workgroup.  post_mode: 0 none, 1 multiply by post_const, 2 by post[pos].
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(ntt_pass_t p, const fr_t *__restrict__ in, fr_t *__restrict__ out,
-                                                         const fr_t *__restrict__ tw, const fr_t *__restrict__ pre,
-                                                         const fr_t *__restrict__ post, fr_t post_const, int post_mode) {
+                                                         const fr_t *__restrict__ tw, const fr_t *__restrict__ stw,
+                                                         const fr_t *__restrict__ pre, const fr_t *__restrict__ post, fr_t post_const,
+                                                         int post_mode) {
     __shared__ uint4 lo[NTT_TILE], hi[NTT_TILE];
     __shared__ fr_t twl[1 << (NTT_MAX_LOGR - 1)];
     const uint32_t tid = threadIdx.x;
@@ -91,7 +105,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(ntt_pass_t p, const fr
                 x = Fr::canon(x);
                 if (pre) x = Fr::mul(x, tk_load(pre + pos));
             }
-            if (p.logNs) x = Fr::mul(x, tk_load(tw + ntt_tw_index(p, p.logNs + logR, ntt_stockham_exp(p, ln.j, r))));
+            if (p.logNs) {
+                const fr_t *t = stw ? stw + ((uint64_t)r << p.logNs) + (ln.j & (((uint64_t)1 << p.logNs) - 1))
+                                    : tw + ntt_tw_index(p, p.logNs + logR, ntt_stockham_exp(p, ln.j, r));
+                x = Fr::mul(x, tk_load(t));
+            }
         }
         lds_elem::put(lo, hi, ntt_slot(logT, l, ntt_bitrev(r, logR)), x);
     }
@@ -215,6 +233,8 @@ TK_API tkmk_error bls12_381_ntt_release_domain(void) {
         (void)hipDeviceSynchronize();
         (void)hipFree(g_dom.tw);
     }
+    for (auto &kv : g_dom.stockham) (void)hipFree(kv.second);
+    g_dom.stockham.clear();
     g_dom.tw = nullptr;
     g_dom.logN = 0;
     return TKMK_SUCCESS;
@@ -245,11 +265,39 @@ struct ntt_job_t {
 
 struct pass_launch_t {
     ntt_pass_t p;
+    const fr_t *stw;  // Stockham table of this pass (nullptr: first pass, or too large -> gathered from tw[])
     const fr_t *pre;
     const fr_t *post;
     fr_t post_const;
     int post_mode;
 };
+
+// Stockham table of pass p from the domain's cache (g_dom_mu held by the caller); built once, synchronously.
+#define NTT_STOCKHAM_MAX_LOG 25  // 1 GiB per table; beyond that the pass gathers from tw[]
+static tkmk_error stockham_table(const ntt_pass_t &p, hipStream_t s, const fr_t **out) {
+    *out = nullptr;
+    if (p.logNs == 0 || p.logNs + p.logR > NTT_STOCKHAM_MAX_LOG) return TKMK_SUCCESS;
+    const uint32_t key = (p.logNs << 8) | (p.logR << 1) | p.inverse;
+    auto it = g_dom.stockham.find(key);
+    if (it != g_dom.stockham.end()) {
+        *out = it->second;
+        return TKMK_SUCCESS;
+    }
+    const uint64_t entries = 1ull << (p.logNs + p.logR);
+    fr_t *t = nullptr;
+    if (hipMalloc((void **)&t, entries * sizeof(fr_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        return TKMK_SUCCESS;  // no room for the table: fall back to the gather
+    }
+    hipLaunchKernelGGL(k_build_stockham, tk_div_up(entries, 256), 256, 0, s, t, (const fr_t *)g_dom.tw, p);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipFree(t);
+        return TKMK_ERR_UNKNOWN;
+    }
+    g_dom.stockham[key] = t;
+    *out = t;
+    return TKMK_SUCCESS;
+}
 
 // Appends the passes of one job; allocates the coset tables it needs from `tables`.
 static tkmk_error plan_job(const ntt_job_t &job, bool inverse, uint32_t logN, hipStream_t s, tk_scratch *tables, int &n_tables,
@@ -286,6 +334,7 @@ static tkmk_error plan_job(const ntt_job_t &job, bool inverse, uint32_t logN, hi
         pass_launch_t &L = out[n_out++];
         ntt_pass_t &p = L.p;
         p = ntt_make_pass(job.logn, job.batch, job.columns, inverse, logN, logR, passes, k, NTT_LOG_TILE);
+        TK_TRY(stockham_table(p, s, &L.stw));
         L.pre = (!inverse && has_coset && p.first) ? table : nullptr;
         L.post = nullptr;
         L.post_mode = 0;
@@ -320,7 +369,7 @@ static tkmk_error run_passes(pass_launch_t *L, int n, const fr_t *in, fr_t *out,
         fr_t *dst = ((n - 1 - k) % 2 == 0) ? out : A;
         if (k == 0 && B) dst = B;
         if (L[k].p.tiles == 0 || L[k].p.tiles > 0x7fffffffull) return TKMK_ERR_INVALID_ARGUMENT;
-        hipLaunchKernelGGL(k_ntt_pass, (unsigned)L[k].p.tiles, NTT_THREADS, 0, s, L[k].p, src, dst, tw, L[k].pre, L[k].post,
+        hipLaunchKernelGGL(k_ntt_pass, (unsigned)L[k].p.tiles, NTT_THREADS, 0, s, L[k].p, src, dst, tw, L[k].stw, L[k].pre, L[k].post,
                            L[k].post_const, L[k].post_mode);
         TK_HIP(hipGetLastError());
         char name[32];
