@@ -115,24 +115,51 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(ntt_pass_t p, const fr
     }
     __syncthreads();
 
-    // radix-2 DIT stages on bit-reversed rows; l is the fastest thread index so a 16-lane LDS group touches
-    // consecutive 16-byte slots.  In the early stages (many groups, few twiddles) the group index runs faster than the
-    // twiddle index, so a whole wave shares one twiddle and the w = 1 butterflies (pos == 0: 1/2 of stage 1, 1/4 of
-    // stage 2, ...) skip their product through a wave-uniform branch: ~0.5 of the ~3.5 products per element per pass.
-    for (uint32_t s = 0; s < logR; s++) {
-        const uint32_t h = 1u << s;
-        const uint32_t lg = logR - 1 - s;              // log2(number of butterfly groups)
-        const bool grp_fast = logT + lg >= 6;          // 64 consecutive lanes then share pos
+    // DIT stages on bit-reversed rows, two at a time: a lane holds the 4 elements r0 + {0, h, 2h, 3h} in registers
+    // and does both stages' 4 butterflies between one LDS read and one LDS write (half the LDS traffic, address
+    // arithmetic and barriers of a stage-by-stage loop).  l is the fastest lane index so a 16-lane LDS group touches
+    // consecutive 16-byte slots; the group index runs faster than the twiddle index while there are enough groups, so
+    // a whole wave shares its twiddles and the w = 1 products (pos == 0: all of stage 0, 1/2 of stage 1, 1/4 of stage
+    // 2, ...) are skipped through a wave-uniform branch: ~0.5 of the ~3.5 products per element per pass.
+    uint32_t s = 0;
+    if (logR & 1) {  // odd radix: stage 0 alone (h = 1: every twiddle is 1)
         for (uint32_t q = tid; q < (NTT_TILE >> 1); q += NTT_THREADS) {
-            uint32_t l = q & (T - 1), qq = q >> logT;
-            uint32_t pos = grp_fast ? qq >> lg : qq & (h - 1);
-            uint32_t grp = grp_fast ? qq & ((1u << lg) - 1) : qq >> s;
-            uint32_t r0 = (grp << (s + 1)) + pos, r1 = r0 + h;
-            uint32_t s0 = ntt_slot(logT, l, r0), s1 = ntt_slot(logT, l, r1);
+            uint32_t l = q & (T - 1), r0 = (q >> logT) << 1;
+            uint32_t s0 = ntt_slot(logT, l, r0), s1 = ntt_slot(logT, l, r0 + 1);
             fr_t a = lds_elem::get(lo, hi, s0), b = lds_elem::get(lo, hi, s1);
-            if (grp_fast ? pos != 0 : s != 0) b = Fr::mul(b, twl[pos << lg]);
             lds_elem::put(lo, hi, s0, Fr::add(a, b));
             lds_elem::put(lo, hi, s1, Fr::sub(a, b));
+        }
+        __syncthreads();
+        s = 1;
+    }
+    for (; s + 1 < logR; s += 2) {
+        const uint32_t h = 1u << s;
+        const uint32_t lg = logR - 1 - s;              // stage s: twiddle of pos is twl[pos << lg]
+        const uint32_t lG = logR - 2 - s;              // log2(number of 4-element groups per line)
+        const bool grp_fast = logT + lG >= 6;          // 64 consecutive lanes then share pos
+        for (uint32_t q = tid; q < (NTT_TILE >> 2); q += NTT_THREADS) {
+            uint32_t l = q & (T - 1), qq = q >> logT;
+            uint32_t pos = grp_fast ? qq >> lG : qq & (h - 1);
+            uint32_t grp = grp_fast ? qq & ((1u << lG) - 1) : qq >> s;
+            uint32_t r0 = (grp << (s + 2)) + pos;
+            uint32_t a0 = ntt_slot(logT, l, r0), a1 = ntt_slot(logT, l, r0 + h), a2 = ntt_slot(logT, l, r0 + 2 * h),
+                     a3 = ntt_slot(logT, l, r0 + 3 * h);
+            fr_t e0 = lds_elem::get(lo, hi, a0), e1 = lds_elem::get(lo, hi, a1), e2 = lds_elem::get(lo, hi, a2),
+                 e3 = lds_elem::get(lo, hi, a3);
+            const bool unit = pos == 0 && (grp_fast || h == 1);   // wave-uniform: t1 = t2 = 1
+            if (!unit) {
+                fr_t t1 = twl[pos << lg];
+                e1 = Fr::mul(e1, t1);
+                e3 = Fr::mul(e3, t1);
+            }
+            fr_t f0 = Fr::add(e0, e1), f1 = Fr::sub(e0, e1), f2 = Fr::add(e2, e3), f3 = Fr::sub(e2, e3);
+            if (!unit) f2 = Fr::mul(f2, twl[pos << (lg - 1)]);
+            f3 = Fr::mul(f3, twl[(pos + h) << (lg - 1)]);
+            lds_elem::put(lo, hi, a0, Fr::add(f0, f2));
+            lds_elem::put(lo, hi, a2, Fr::sub(f0, f2));
+            lds_elem::put(lo, hi, a1, Fr::add(f1, f3));
+            lds_elem::put(lo, hi, a3, Fr::sub(f1, f3));
         }
         __syncthreads();
     }
