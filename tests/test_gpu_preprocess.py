@@ -1,0 +1,62 @@
+"""gpu tier: the `preprocess` round (tkmk/preprocess.py, work-alike of Preprocess::gen, packages/backend/preprocess/src/lib.rs:32-82)
+end to end over the device path on a small synthetic shape with a fixed-tau CRS: the three commitments must equal
+[s0(tau_x, tau_y)]G, [s1(tau_x, tau_y)]G and [sum_i a_i k_i]G computed with the oracle's scalar arithmetic
+(trusted-setup/src/main.rs:236-246 commit identity), and survive the Solidity formatting round trip.  The reference
+ships no preprocess.json / CRS fixtures, so this identity is the pin."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_preprocess_round(gpu, oracle):
+    from tkmk.preprocess import Preprocess
+    from tkmk.sigma import Sigma1
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pins.json")))
+    R = oracle.R_MOD
+    tx, ty = int(pins["tau_x"], 16), int(pins["tau_y"], 16)
+    g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
+    sp = {"l": 8, "l_free": 5, "l_user": 3, "l_user_out": 1, "l_D": 40, "n": 16, "s_max": 8, "m_D": 60, "s_D": 2}
+    m_i, s_max = sp["l_D"] - sp["l"], sp["s_max"]
+    rs_x, rs_y = max(2 * sp["n"], 2 * m_i), 2 * s_max
+    mon = [pow(tx, i, R) * pow(ty, j, R) % R for i in range(rs_x) for j in range(rs_y)]
+    sigma = Sigma1(gpu.g1_batch_scalar_mul_device(gpu.DeviceBuffer.from_host(oracle.to_bytes(mon, 32)), g, rs_x * rs_y), rs_x, rs_y)
+    rnd = random.Random(4)
+    ks = [rnd.randrange(1, R) for _ in range(sp["l"])]
+    gamma = gpu.g1_batch_scalar_mul_device(gpu.DeviceBuffer.from_host(oracle.to_bytes(ks, 32)), g, sp["l"])
+    a_fn = [rnd.randrange(R) for _ in range(sp["l"] - sp["l_free"])]
+    instance = {"a_pub_user": [], "a_pub_block": [], "a_pub_function": ["0x%x" % a for a in a_fn]}
+    cells = [(r, c) for r in range(m_i) for c in range(s_max)]
+    src = rnd.sample(cells, 60)
+    dst = src[1:] + src[:1]                                   # one 60-cycle of wire copies
+    perm = [{"row": r, "col": c, "X": X, "Y": Y} for (r, c), (X, Y) in zip(src, dst)]
+
+    pre = Preprocess.gen(sigma, gamma, perm, instance, sp)
+
+    wx = oracle.to_ints(oracle.root_of_unity(m_i), 32)[0]
+    wy = oracle.to_ints(oracle.root_of_unity(s_max), 32)[0]
+    s0 = [[pow(wx, r, R)] * s_max for r in range(m_i)]
+    s1 = [[pow(wy, c, R) for c in range(s_max)] for _ in range(m_i)]
+    for p in perm:
+        s0[p["row"]][p["col"]] = pow(wx, p["X"], R)
+        s1[p["row"]][p["col"]] = pow(wy, p["Y"], R)
+    TX, TY = oracle.to_bytes([tx], 32), oracle.to_bytes([ty], 32)
+    for got, ev in ((pre.s0, s0), (pre.s1, s1)):
+        coeffs = oracle.bintt(oracle.to_bytes([v for row in ev for v in row], 32), m_i, s_max, inverse=True)
+        assert (got == oracle.g1_scalar_mul(oracle.poly_eval(coeffs, m_i, s_max, TX, TY), g)).all()
+    start = sp["l"] - len(a_fn)
+    dot = sum(a * k for a, k in zip(a_fn, ks[start:])) % R
+    assert (pre.O_pub_fix == oracle.g1_scalar_mul(oracle.to_bytes([dot], 32), g)).all()
+    # host-resident gamma table gives the same point; m_function == 0 gives G1serde::zero(); length mismatch raises
+    from tkmk.preprocess import encode_O_pub_fix
+    assert (encode_O_pub_fix(gamma.to_host(), instance["a_pub_function"], sp) == pre.O_pub_fix).all()
+    assert not encode_O_pub_fix(gamma, [], dict(sp, l_free=sp["l"])).any()
+    with pytest.raises(ValueError):
+        encode_O_pub_fix(gamma, instance["a_pub_function"][:-1], sp)
+    fmt = pre.convert_format_for_solidity_verifier()
+    back = Preprocess.recover_from_format(json.loads(json.dumps(fmt)))
+    assert (back.s0 == pre.s0).all() and (back.s1 == pre.s1).all() and (back.O_pub_fix == pre.O_pub_fix).all()
