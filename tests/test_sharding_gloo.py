@@ -129,3 +129,48 @@ def test_sharded_bintt_all_to_all_world2_gloo():
         p.join(240)
         assert p.exitcode == 0
     assert dict(q.get(timeout=10) for _ in range(world)) == {0: True, 1: True}
+
+
+def _commit_worker(rank, world, port, sizes, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tokamak-zk-evm_amd"))
+    import torch.distributed as dist
+    import oracle
+    from tkmk import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        jobs = [(oracle.fr_random(20 + k, n), oracle.g1_random_bases(40 + k, n), n) for k, n in enumerate(sizes)]
+        touched = []
+
+        def oracle_multi(js):                    # test-only stand-in for tkmk.msm_multi: 96-byte affine results
+            touched.extend(j[2] for j in js)
+            return np.concatenate([oracle.g1_msm(s, p, threads=1) for s, p, _ in js])
+
+        got = sharding.commits_sharded(oracle_multi, dist, jobs, result_bytes=96, device="cpu")
+        want = np.stack([oracle.g1_msm(s, p, threads=1) for s, p, _ in jobs])
+        mine = [sizes[j] for j in sharding.jobs_of_rank(len(sizes), rank, world)]
+        q.put((rank, bool((got == want).all()) and touched == mine))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_round_commits_sharded_world2_gloo():
+    """independent commits of one round: job j on rank j mod G, one all_gather, results in job order on every rank;
+    an odd job count leaves the last slot of rank 1 empty"""
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_commit_worker, args=(r, world, port, [40, 7, 19, 64, 3], q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=10) for _ in range(world)) == {0: True, 1: True}

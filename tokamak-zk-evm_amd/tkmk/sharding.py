@@ -87,3 +87,37 @@ def bintt_sharded(ops, dist, slab, x_size, y_size, inverse=False, coset_x=None, 
 def shard_batch(n_batch, rank, world):
     """independent NTTs: contiguous batch range of this rank (no communication)"""
     return shard_range(n_batch, rank, world)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Independent commits of one prover round distributed over the ranks (SURVEY.md §8e row 4): the rounds are
+# sequential (Fiat-Shamir), but inside a round the 6 (prove0) / 9 (prove4) encode_poly MSMs are independent.
+# Job j runs on rank j mod G (through the pipelined multi-MSM of that GPU); ONE all_gather of ceil(J/G) results
+# per rank returns every commitment to every rank, in job order.
+# ---------------------------------------------------------------------------------------------------
+def jobs_of_rank(n_jobs, rank, world):
+    return list(range(rank, n_jobs, world))
+
+
+def commits_sharded(msm_multi, dist, jobs, result_bytes=144, device="cuda"):
+    """jobs: the same list on every rank (each rank only touches the operands of its own jobs);
+    msm_multi(list of jobs) -> concatenated results of result_bytes each.  Returns (n_jobs, result_bytes) uint8."""
+    import torch
+    n = len(jobs)
+    if dist is None or dist.get_world_size() == 1:
+        return np.asarray(msm_multi(jobs)).reshape(n, result_bytes)
+    G, r = dist.get_world_size(), dist.get_rank()
+    mine = jobs_of_rank(n, r, G)
+    slots = (n + G - 1) // G
+    buf = np.zeros((slots, result_bytes), np.uint8)
+    if mine:
+        buf[:len(mine)] = np.asarray(msm_multi([jobs[j] for j in mine])).reshape(len(mine), result_bytes)
+    t = torch.from_numpy(buf).to(device)
+    out = [torch.empty_like(t) for _ in range(G)]
+    dist.all_gather(out, t)
+    res = np.zeros((n, result_bytes), np.uint8)
+    for q in range(G):
+        got = out[q].cpu().numpy()
+        for k, j in enumerate(jobs_of_rank(n, q, G)):
+            res[j] = got[k]
+    return res
