@@ -60,3 +60,57 @@ def test_preprocess_round(gpu, oracle):
     fmt = pre.convert_format_for_solidity_verifier()
     back = Preprocess.recover_from_format(json.loads(json.dumps(fmt)))
     assert (back.s0 == pre.s0).all() and (back.s1 == pre.s1).all() and (back.O_pub_fix == pre.O_pub_fix).all()
+
+
+def test_preprocess_cli_files_in_files_out(gpu, oracle, tmp_path):
+    """the process-level surface of `preprocess` (preprocess/src/main.rs): directories in, preprocess.json out; the CRS is
+    staged as the TKCRS001 payload, generated from the fixed tau on the GPU"""
+    import subprocess
+    import sys
+    from tkmk import crs, proofio
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pins.json")))
+    R = oracle.R_MOD
+    tx, ty = int(pins["tau_x"], 16), int(pins["tau_y"], 16)
+    g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
+    sp = {"l": 8, "l_free": 5, "l_user": 3, "l_user_out": 1, "l_D": 24, "n": 16, "s_max": 4, "m_D": 30, "s_D": 2}
+    m_i, s_max = sp["l_D"] - sp["l"], sp["s_max"]
+    rs_x, rs_y = max(2 * sp["n"], 2 * m_i), 2 * s_max
+    rnd = random.Random(8)
+
+    def pts(scalars):
+        return gpu.g1_batch_scalar_mul_device(gpu.DeviceBuffer.from_host(oracle.to_bytes(scalars, 32)), g, len(scalars)).to_host()
+
+    ks = [rnd.randrange(1, R) for _ in range(sp["l"])]
+    sections = {"g1": pts([1, tx, ty, 5, 7, 11]), "g2": bytes(10 * 192),
+                "xy_powers": pts([pow(tx, i, R) * pow(ty, j, R) % R for i in range(rs_x) for j in range(rs_y)]),
+                "gamma_inv_o_inst": pts(ks),
+                "eta_inv_li_o_inter_alpha4_kj": pts([rnd.randrange(1, R) for _ in range(m_i * s_max)]),
+                "delta_inv_li_o_prv": pts([rnd.randrange(1, R) for _ in range((sp["m_D"] - sp["l_D"]) * s_max)]),
+                "delta_inv_alphak_xh_tx": pts(list(range(2, 11))), "delta_inv_alpha4_xj_tx": pts([3, 4]),
+                "delta_inv_alphak_yi_ty": pts(list(range(20, 32)))}
+    for d in ("crs", "synth", "lib", "out"):
+        (tmp_path / d).mkdir()
+    (tmp_path / "crs" / "combined_sigma.tkcrs").write_bytes(crs.build_payload(sections))
+    json.dump(sp, open(tmp_path / "lib" / "setupParams.json", "w"))
+    a_fn = [rnd.randrange(R) for _ in range(sp["l"] - sp["l_free"])]
+    json.dump({"a_pub_user": [], "a_pub_block": [], "a_pub_function": ["0x%x" % a for a in a_fn]}, open(tmp_path / "synth" / "instance.json", "w"))
+    perm = [{"row": 1, "col": 2, "X": 5, "Y": 0}, {"row": 5, "col": 0, "X": 1, "Y": 2}]
+    json.dump(perm, open(tmp_path / "synth" / "permutation.json", "w"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "tokamak-zk-evm_amd"))
+    subprocess.run([sys.executable, "-m", "tkmk.cli", "preprocess", "--crs", str(tmp_path / "crs"), "--synthesizer-stat", str(tmp_path / "synth"),
+                    "--output", str(tmp_path / "out"), "--subcircuit-library", str(tmp_path / "lib")], check=True, env=env, timeout=300)
+    got = proofio.recover_preprocess(json.load(open(tmp_path / "out" / "preprocess.json")))
+    dot = sum(a * k for a, k in zip(a_fn, ks[sp["l_free"]:])) % R
+    assert (got["O_pub_fix"] == oracle.g1_scalar_mul(oracle.to_bytes([dot], 32), g)).all()
+    wx = oracle.to_ints(oracle.root_of_unity(m_i), 32)[0]
+    s0 = [[pow(wx, r, R)] * s_max for r in range(m_i)]
+    for p in perm:
+        s0[p["row"]][p["col"]] = pow(wx, p["X"], R)
+    coeffs = oracle.bintt(oracle.to_bytes([v for row in s0 for v in row], 32), m_i, s_max, inverse=True)
+    val = oracle.poly_eval(coeffs, m_i, s_max, oracle.to_bytes([tx], 32), oracle.to_bytes([ty], 32))
+    assert (got["s0"] == oracle.g1_scalar_mul(val, g)).all()
+    # a missing CRS is a loud failure, as in the reference ("No reference string is found")
+    r = subprocess.run([sys.executable, "-m", "tkmk.cli", "preprocess", "--crs", str(tmp_path / "lib"), "--synthesizer-stat", str(tmp_path / "synth"),
+                        "--output", str(tmp_path / "out"), "--subcircuit-library", str(tmp_path / "lib")], env=env, capture_output=True, timeout=300)
+    assert r.returncode != 0 and b"No reference string is found" in r.stderr
