@@ -151,6 +151,8 @@ def main():
                               "peak": MAD_PEAK_PER_S,
                               "frac": n * ADDS_PER_POINT * MADS_PER_BUCKET_ADD / (kernel_ms * 1e-3) / MAD_PEAK_PER_S},
         }
+        if world > 1:      # the CPU baseline and the secondary figures are N = 1 material; keep the scaling runs lean
+            args.no_cpu_baseline = args.no_bn254 = args.no_ntt = True
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(tkmk, args.cpu_sample_logn)
         if not args.no_bn254 or not args.no_ntt:
