@@ -226,3 +226,27 @@ def test_msm_batch_pipeline_large(gpu, oracle):
         sv = oracle.to_ints(sh[32 * n * b:32 * n * (b + 1)], 32)
         dot = sum(x * y for x, y in zip(sv, kk)) % oracle.R_MOD
         assert (got[96 * b:96 * (b + 1)] == oracle.g1_scalar_mul(oracle.to_bytes([dot], 32), base.copy())).all()
+
+
+def test_msm_giant_bucket_multi_workgroup_path(gpu, oracle):
+    # witness MSMs put millions of "wire = 1" scalars into ONE bucket: above 2048 chunk fragments
+    # (131072 entries) a bucket is summed by 32 workgroups + a final wave (k_combine_giant_*), below by one workgroup
+    n = 300000
+    k = gpu.fr_random_device(71, n)
+    g = oracle.g1_generator()
+    bases = gpu.g1_batch_scalar_mul_device(k, g, n)
+    kv = oracle.to_ints(k.to_host(), 32)
+    R = oracle.R_MOD
+    sv = [1] * n
+    for i in range(0, n, 7):
+        sv[i] = 0
+    for i in range(3, n, 1000):
+        sv[i] = (i * 0x9E3779B97F4A7C15 + 12345) % R             # a sprinkle of full-width scalars
+    for i in range(5, n, 50):
+        sv[i] = 1 << 16                                           # a second giant-ish bucket in window 1 (c = 16)
+    s = gpu.DeviceBuffer.from_host(oracle.to_bytes(sv, 32))
+    got = _msm_affine(gpu, s, bases)
+    dot = sum(a * b for a, b in zip(sv, kv)) % R
+    assert (got == oracle.g1_scalar_mul(oracle.to_bytes([dot], 32), g.copy())).all()
+    # same inputs with an explicit narrow window (more windows, same giant bucket in window 0)
+    assert (_msm_affine(gpu, s, bases, c=13) == got).all()
