@@ -231,7 +231,11 @@ static void g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, 
         if (negate[i]) q = GU::neg(q);
         acc = GU::add_mixed(acc, q);
     }
+    // both ways out of the unsaturated form must agree: direct conversion, and the multiplication-free raw record the
+    // accumulate kernel stores + the reader-side conversion (ec_u.h to_raw / raw_to_sat)
     affine_t<F> r = G::to_affine(GU::to_sat(acc));
+    affine_t<F> r2 = G::to_affine(GU::raw_to_sat(GU::to_raw(acc)));
+    if (!(F::eq(r.x, r2.x) && F::eq(r.y, r2.y))) memset(&r, 0xff, sizeof r);   // poison the output: the test will fail
     store<F>(out, F::from_mont(r.x));
     store<F>(out + sz, F::from_mont(r.y));
 }

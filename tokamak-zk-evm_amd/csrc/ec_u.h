@@ -85,6 +85,29 @@ struct ecu {
         r.zzz = FU::to_sat_mont(p.zzz);
         return r;
     }
+    // "raw" record: the unsaturated coordinates as they are (x R' mod p, redundant: X < 5.03p, the others < 1.03p — both
+    // fit the 32N-bit words), normalised and packed, all-zero = infinity.  Writing it costs no multiplication, which
+    // matters inside the accumulate loop: lanes leave a bucket at different iterations, so a flush is executed by the
+    // whole wave for one or two active lanes; the four conversion products of to_sat() are done later, convergently,
+    // by whoever reads the record (raw_to_sat).
+    static FF_HD xyzz_t<FS> to_raw(const X &p) {
+        xyzz_t<FS> r;
+        if (p.inf) return GS::inf();
+        r.x = FU::pack(FU::norm(p.x));
+        r.y = FU::pack(FU::norm(p.y));
+        r.zz = FU::pack(FU::norm(p.zz));
+        r.zzz = FU::pack(FU::norm(p.zzz));
+        return r;
+    }
+    static FF_HD xyzz_t<FS> raw_to_sat(const xyzz_t<FS> &raw) {
+        if (FS::is_zero(raw.zz)) return GS::inf();   // zz == 0 exactly only for the infinity record (zz != 0 mod p otherwise)
+        xyzz_t<FS> r;
+        r.x = FU::to_sat_mont(FU::unpack(raw.x));
+        r.y = FU::to_sat_mont(FU::unpack(raw.y));
+        r.zz = FU::to_sat_mont(FU::unpack(raw.zz));
+        r.zzz = FU::to_sat_mont(FU::unpack(raw.zzz));
+        return r;
+    }
     static FF_HD E from_sat_mont(const typename FS::E &s) {  // x 2^(32N) canonical -> x 2^(W L) strict canonical
         typename FS::E k;
 #pragma unroll
