@@ -239,7 +239,62 @@ static void g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, 
     store<F>(out, F::from_mont(r.x));
     store<F>(out + sz, F::from_mont(r.y));
 }
+// general add / doubling on the unsaturated form (the combine / bucket-reduction kernels): out = affine plain of
+//   mode 0: A + B      mode 1: 2A      mode 2: A + A' (A' = the same point reached by another addition order: doubling branch)
+//   mode 3: A + (-A')  (infinity)      mode 4: [k] A by double-and-add (k = 16-bit)
+// where A = p0 + p1 + p2 and B = p3 + p4 are built with the mixed adder so that ZZ, ZZZ != 1; records go through to_raw / from_raw
+template <class P>
+static void g1u_full(int mode, const uint8_t *pts, uint32_t k, uint8_t *out) {
+    using F = ff<P>;
+    using GU = ecu<P>;
+    using G = ec<F>;
+    const size_t sz = 4 * F::N;
+    typename F::E ksat;
+    for (int i = 0; i < F::N; i++) ksat.l[i] = P::KSAT[i];
+    typename GU::A q[5];
+    for (int i = 0; i < 5; i++) {
+        affine_t<F> rec;
+        load<F>(rec.x, pts + 2 * sz * i);
+        load<F>(rec.y, pts + 2 * sz * i + sz);
+        rec.x = F::mul(rec.x, ksat);
+        rec.y = F::mul(rec.y, ksat);
+        GU::load_affine(q[i], rec);
+    }
+    auto chain = [&](int a, int b, int c) {
+        typename GU::X x = GU::add_mixed(GU::inf(), q[a]);
+        x = GU::add_mixed(x, q[b]);
+        if (c >= 0) x = GU::add_mixed(x, q[c]);
+        return GU::from_raw(GU::to_raw(x));
+    };
+    typename GU::X A = chain(0, 1, 2), B = chain(3, 4, -1), r;
+    switch (mode) {
+        case 0: r = GU::add(A, B); break;
+        case 1: r = GU::dbl(A); break;
+        case 2: r = GU::add(A, chain(2, 0, 1)); break;
+        case 3: {
+            typename GU::X n = chain(1, 2, 0);
+            typename GU::A ny;
+            ny.x = n.y;
+            ny.y = n.y;
+            n.y = GU::neg(ny).y;    // p - y (strict); same bound as a canonical y
+            r = GU::add(A, n);
+            break;
+        }
+        default: {
+            r = GU::inf();
+            for (int bit = 15; bit >= 0; bit--) {
+                r = GU::dbl(r);
+                if ((k >> bit) & 1) r = GU::add(r, A);
+            }
+        }
+    }
+    affine_t<F> a = G::to_affine(GU::raw_to_sat(GU::to_raw(r)));
+    store<F>(out, F::from_mont(a.x));
+    store<F>(out + sz, F::from_mont(a.y));
+}
 extern "C" {
+void hc_g1u_full(int mode, const uint8_t *pts, uint32_t k, uint8_t *out) { g1u_full<bls12_381_fq_params>(mode, pts, k, out); }
+void hc_bn254_g1u_full(int mode, const uint8_t *pts, uint32_t k, uint8_t *out) { g1u_full<bn254_fq_params>(mode, pts, k, out); }
 void hc_fqu_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { fqu_op<bls12_381_fq_params>(op, a, b, o, n); }
 void hc_g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, uint8_t *out) {
     g1u_accumulate<bls12_381_fq_params>(pts, negate, n, out);

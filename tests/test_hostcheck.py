@@ -207,3 +207,24 @@ def test_bn254_unsaturated_field_and_chain(hc, oracle):
         want = bn.g1_add(want, bn.g1_neg(q) if flags[i] else q)
     hc.hc_bn254_g1u_accumulate(_p(pts), _p(flags), ctypes.c_size_t(300), _p(out))
     assert (out == want).all()
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_unsaturated_full_add_and_doubling(hc, oracle, curve):
+    """csrc/ec_u.h add / dbl (tail kernels of the MSM) with every bound assertion on, incl. the doubling and cancellation
+    branches reached through projectively different representations of the same point, and a double-and-add chain"""
+    o = oracle if curve == "bls12_381" else oracle.bn254
+    fn = hc.hc_g1u_full if curve == "bls12_381" else hc.hc_bn254_g1u_full
+    sz = 96 if curve == "bls12_381" else 64
+    for seed in (5, 6, 7):
+        pts = o.g1_random_bases(seed, 5)
+        P = [pts[sz * i:sz * (i + 1)].copy() for i in range(5)]
+        A = o.g1_add(o.g1_add(P[0], P[1]), P[2])
+        B = o.g1_add(P[3], P[4])
+        out = np.empty(sz, np.uint8)
+        k = 0xB5C3 + seed
+        want = {0: o.g1_add(A, B), 1: o.g1_add(A, A), 2: o.g1_add(A, A), 3: np.zeros(sz, np.uint8),
+                4: o.g1_scalar_mul(oracle.to_bytes([k], 32), A)}
+        for mode, w in want.items():
+            fn(mode, _p(pts), ctypes.c_uint32(k), _p(out))
+            assert (out == w).all(), (curve, seed, mode)

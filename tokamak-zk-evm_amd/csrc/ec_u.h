@@ -108,6 +108,17 @@ struct ecu {
         r.zzz = FU::to_sat_mont(FU::unpack(raw.zzz));
         return r;
     }
+    // raw record -> unsaturated point: unpack only (the bounds of to_raw's inputs carry over)
+    static FF_HD X from_raw(const xyzz_t<FS> &raw) {
+        X r;
+        r.inf = FS::is_zero(raw.zz);
+        if (r.inf) return inf();
+        r.x = FU::unpack(raw.x);
+        r.y = FU::unpack(raw.y);
+        r.zz = FU::unpack(raw.zz);
+        r.zzz = FU::unpack(raw.zzz);
+        return r;
+    }
     static FF_HD E from_sat_mont(const typename FS::E &s) {  // x 2^(32N) canonical -> x 2^(W L) strict canonical
         typename FS::E k;
 #pragma unroll
@@ -130,6 +141,50 @@ struct ecu {
         qs.x = FU::to_sat_mont(q.x);
         qs.y = FU::to_sat_mont(q.y);
         return from_sat(GS::add_mixed(to_sat(p), qs));
+    }
+
+    // general addition (add-2008-s, 12M + 2S, one shared reduction) for the combine / bucket-reduction kernels.  With both
+    // operands in the accumulator invariant (X < 5.03p, Y, ZZ, ZZZ < 1.03p):
+    //   U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1      < 1.03
+    //   P = U2 - U1 (sub<2>), R = S2 - S1 (sub<2>)                 in (0.97, 3.03);  P == 0 mod p <=> P in {p, 2p, 3p}
+    //   X3 = R^2 - (PPP + 2Q)  (sub<4>)  < 5.03;  Y3 = [R (Q - X3) + (2p - S1) PPP]/R' < 1.03;  ZZ3, ZZZ3 < 1.03
+    static FF_HD X add_slow(const X &p, const X &q) { return from_sat(GS::add(to_sat(p), to_sat(q))); }
+    static FF_HD X add(const X &p, const X &q) {
+        if (p.inf) return q;
+        if (q.inf) return p;
+        E u1 = FU::mul(p.x, q.zz), u2 = FU::mul(q.x, p.zz);
+        E s1 = FU::mul(p.y, q.zzz), s2 = FU::mul(q.y, p.zzz);
+        E pd = FU::template sub<2>(u2, u1);
+        if (FU::maybe_multiple_of_p(pd, 3)) return add_slow(p, q);   // same x: doubling or cancellation, decided in ec.h
+        E rd = FU::template sub<2>(s2, s1);
+        E pp = FU::sqr(pd);
+        E ppp = FU::mul(pd, pp);
+        E qq = FU::mul(u1, pp);
+        X r;
+        r.inf = false;
+        r.x = FU::template sub<4>(FU::sqr(rd), FU::add(ppp, FU::dbl(qq)));
+        r.y = FU::mul_add(rd, FU::template sub<8>(qq, r.x), FU::template sub<2>(FU::zero(), s1), ppp);
+        r.zz = FU::mul(FU::mul(p.zz, q.zz), pp);
+        r.zzz = FU::mul(FU::mul(p.zzz, q.zzz), ppp);
+        return r;
+    }
+    // doubling (dbl-2008-s-1, a = 0): U = 2Y1 < 2.06, V = U^2, W = U V, S = X1 V, M = 3 X1^2 < 3.09,
+    //   X3 = M^2 - 2S (sub<4>) < 5.03,  Y3 = [M (S - X3) + (2p - W) Y1]/R' < 1.03,  ZZ3 = V ZZ1, ZZZ3 = W ZZZ1
+    static FF_HD X dbl(const X &p) {
+        if (p.inf) return p;
+        E u = FU::dbl(p.y);
+        E v = FU::sqr(u);
+        E w = FU::mul(u, v);
+        E sx = FU::mul(p.x, v);
+        E x2 = FU::sqr(p.x);
+        E m = FU::add(FU::dbl(x2), x2);
+        X r;
+        r.inf = false;
+        r.x = FU::template sub<4>(FU::sqr(m), FU::dbl(sx));
+        r.y = FU::mul_add(m, FU::template sub<8>(sx, r.x), FU::template sub<2>(FU::zero(), w), p.y);
+        r.zz = FU::mul(v, p.zz);
+        r.zzz = FU::mul(w, p.zzz);
+        return r;
     }
 
     // p + q, q an affine point (not infinity)
