@@ -98,7 +98,7 @@ int tkmk_is_hip_build(void);
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
     tkmk_stream stream_handle;          /* NULL = default stream */
-    int precompute_factor;              /* 1; >1 is rejected with API_NOT_IMPLEMENTED */
+    int precompute_factor;              /* 1 = none; F > 1: `bases` is the table made by bls12_381_msm_precompute_bases */
     int c;                              /* window bits (2..18); 0 = choose from size */
     int bitsize;                        /* scalar bits to process; 0 = 255 */
     int batch_size;                     /* number of MSMs; results = batch_size points */
@@ -120,6 +120,17 @@ tkmk_msm_config tkmk_msm_default_config(void);            /* MSMConfig::default(
  * (libs/src/iotools/mod.rs:2112) yields the unique affine point. */
 tkmk_error bls12_381_msm(const tkmk_fr *scalars, const tkmk_g1_affine *bases, int msm_size,
                          const tkmk_msm_config *cfg, tkmk_g1_projective *results);
+
+/* Precomputed bases (ICICLE msm_precompute_bases; MSMConfig::precompute_factor): output_bases receives
+ * msm_size * F' points (F' = min(cfg->precompute_factor, windows)) — the 2^(c W' j) multiples of every base, in the
+ * library's converted form — on the device if cfg->are_results_on_device, else on the host.  A later bls12_381_msm /
+ * tkmk_msm_multi call with the same c, bitsize and precompute_factor takes that table as `bases` and runs W' =
+ * ceil(windows / F') windows over msm_size * F' points: the same number of bucket additions, no per-call base
+ * conversion, 1/F' of the buckets.  The reference leaves precompute_factor at 1 (MSMConfig::default(),
+ * libs/src/iotools/mod.rs:2096).  Measured gain on MI355X is modest (2^20 points: 4.5 -> 4.1 ms at F = 4) because the
+ * bucket reduction is a latency chain whose length does not depend on the number of windows. */
+tkmk_error bls12_381_msm_precompute_bases(const tkmk_g1_affine *bases, int msm_size, const tkmk_msm_config *cfg,
+                                          tkmk_g1_affine *output_bases);
 
 /* Several independent MSMs (own scalars, own bases, own size) in one call, e.g. the commits the prover issues
  * between two transcript challenges (prove/src/lib.rs prove0..prove4 call encode_poly back to back on
@@ -233,6 +244,8 @@ typedef struct {
     const tkmk_bn254_g1_affine *bases;
     int msm_size;
 } tkmk_bn254_msm_job;
+tkmk_error bn254_msm_precompute_bases(const tkmk_bn254_g1_affine *bases, int msm_size, const tkmk_msm_config *cfg,
+                                      tkmk_bn254_g1_affine *output_bases);
 tkmk_error tkmk_bn254_msm_multi(const tkmk_bn254_msm_job *jobs, int n_jobs, const tkmk_msm_config *cfg,
                                 tkmk_bn254_g1_projective *results);
 /* input generation twins of tkmk_fr_random_device / tkmk_g1_batch_scalar_mul_device (below) */

@@ -250,3 +250,46 @@ def test_msm_giant_bucket_multi_workgroup_path(gpu, oracle):
     assert (got == oracle.g1_scalar_mul(oracle.to_bytes([dot], 32), g.copy())).all()
     # same inputs with an explicit narrow window (more windows, same giant bucket in window 0)
     assert (_msm_affine(gpu, s, bases, c=13) == got).all()
+
+
+@pytest.mark.parametrize("factor,c", [(2, 0), (3, 7), (8, 0), (16, 16), (100, 0)])
+def test_msm_precomputed_bases(gpu, oracle, factor, c):
+    """precompute_factor (ICICLE msm_precompute_bases): the expanded table 2^(c W' j) P_i gives the same result as the
+    plain MSM for factors that divide the window count, that do not (padding windows), and that exceed it (clamped)"""
+    n = 700
+    s = oracle.fr_random(500 + factor, n)
+    sv = oracle.to_ints(s, 32)
+    sv[:4] = [0, 1, oracle.R_MOD - 1, 1 << 254]
+    s = oracle.to_bytes(sv, 32)
+    p = oracle.g1_random_bases(600 + factor, n)
+    p[96 * 5:96 * 6] = 0                                   # an infinity base stays infinity in every table row
+    want = oracle.g1_msm(s, p)
+    table = gpu.msm_precompute_bases(p, n, factor, c=c)
+    rows = min(factor, gpu.msm_windows(n, c))
+    assert table.nbytes == 96 * n * rows
+    got = _msm_affine(gpu, s, table, msm_size=n, c=c, precompute_factor=factor)
+    assert (got == want).all()
+    # device-resident scalars, twice (table reuse), and through the pipelined multi entry with two jobs
+    sd = gpu.DeviceBuffer.from_host(s)
+    for _ in range(2):
+        assert (_msm_affine(gpu, sd, table, msm_size=n, c=c, precompute_factor=factor) == want).all()
+    s2 = oracle.fr_random(700 + factor, n)
+    res = gpu.projective_to_affine_bytes(gpu.msm_multi([(sd, table, n), (gpu.DeviceBuffer.from_host(s2), table, n)], c=c,
+                                                       precompute_factor=factor))
+    assert (res[:96] == want).all() and (res[96:] == oracle.g1_msm(s2, p)).all()
+
+
+def test_msm_precomputed_bases_large_identity(gpu, oracle):
+    # 2^18 points, full precompute (one window group): sum s_i (k_i G) == (sum s_i k_i) G
+    n = 1 << 18
+    k = gpu.fr_random_device(93, n)
+    g = oracle.g1_generator()
+    bases = gpu.g1_batch_scalar_mul_device(k, g, n)
+    sd = gpu.fr_random_device(94, n)
+    f = gpu.msm_windows(n)
+    table = gpu.msm_precompute_bases(bases, n, f)
+    got = _msm_affine(gpu, sd, table, msm_size=n, precompute_factor=f)
+    assert (got == _msm_affine(gpu, sd, bases)).all()
+    kv, sv = oracle.to_ints(k.to_host(), 32), oracle.to_ints(sd.to_host(), 32)
+    dot = sum(a * b for a, b in zip(kv, sv)) % oracle.R_MOD
+    assert (got == oracle.g1_scalar_mul(oracle.to_bytes([dot], 32), g.copy())).all()

@@ -21,4 +21,5 @@
 #define TK_MSM_ABI_JOB tkmk_msm_job
 #define TK_MSM_SYM_MSM bls12_381_msm
 #define TK_MSM_SYM_MULTI tkmk_msm_multi
+#define TK_MSM_SYM_PRECOMPUTE bls12_381_msm_precompute_bases
 #include "msm_impl.inc"

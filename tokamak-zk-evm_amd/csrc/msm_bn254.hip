@@ -22,4 +22,5 @@
 #define TK_MSM_ABI_JOB tkmk_bn254_msm_job
 #define TK_MSM_SYM_MSM bn254_msm
 #define TK_MSM_SYM_MULTI tkmk_bn254_msm_multi
+#define TK_MSM_SYM_PRECOMPUTE bn254_msm_precompute_bases
 #include "msm_impl.inc"

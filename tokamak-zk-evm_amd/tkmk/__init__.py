@@ -82,7 +82,7 @@ SYMBOLS = [
     "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
     "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
     "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
-    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "tkmk_bn254_fr_random_device",
+    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm", "bls12_381_msm_precompute_bases", "bn254_msm_precompute_bases", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "tkmk_bn254_fr_random_device",
     "tkmk_bn254_g1_batch_scalar_mul_device",
     "tkmk_ntt_default_config", "bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain",
     "bls12_381_ntt", "tkmk_bintt", "tkmk_vecops_default_config", "bls12_381_vector_add", "bls12_381_vector_sub",
@@ -325,14 +325,48 @@ def _len(a):
 # ---- MSM (reference: libs/src/iotools/mod.rs:2093-2099, group_structures/mod.rs:108-143) ----
 # curve -> (msm symbol, multi symbol, fr_random symbol, batch scalar-mul symbol, affine bytes)
 _CURVES = {
-    "bls12_381": ("bls12_381_msm", "tkmk_msm_multi", "tkmk_fr_random_device", "tkmk_g1_batch_scalar_mul_device", 96),
-    "bn254": ("bn254_msm", "tkmk_bn254_msm_multi", "tkmk_bn254_fr_random_device", "tkmk_bn254_g1_batch_scalar_mul_device", 64),
+    "bls12_381": ("bls12_381_msm", "tkmk_msm_multi", "tkmk_fr_random_device", "tkmk_g1_batch_scalar_mul_device", 96,
+                  "bls12_381_msm_precompute_bases"),
+    "bn254": ("bn254_msm", "tkmk_bn254_msm_multi", "tkmk_bn254_fr_random_device", "tkmk_bn254_g1_batch_scalar_mul_device", 64,
+              "bn254_msm_precompute_bases"),
 }
 
 
-def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize=0, stream=None, curve="bls12_381"):
+def msm_windows(n, c=0, bitsize=0, curve="bls12_381"):
+    """number of scalar windows the library uses for an n-point MSM (c = 0: its own choice), i.e. the largest useful
+    precompute factor; mirrors choose_c / msm_resolve_c in csrc/msm_impl.inc"""
+    bits = bitsize or (255 if curve == "bls12_381" else 254)
+    if not c:
+        best, cost = 2, None
+        for cc in range(2, 17):
+            v = (255 // cc + 1) * (n + 4.0 * (1 << (cc - 1)))
+            if cost is None or v < cost:
+                best, cost = cc, v
+        c = best
+    c = min(max(c, 2), 18)
+    if c > 16 and n < (1 << 18):
+        c = 16
+    return bits // c + 1
+
+
+def msm_precompute_bases(bases, n, factor, c=0, bitsize=0, curve="bls12_381"):
+    """-> DeviceBuffer with the n * min(factor, windows) expanded points (converted form) for msm(..., precompute_factor=factor)"""
+    sym, aff = _CURVES[curve][5], _CURVES[curve][4]
+    cfg = lib().tkmk_msm_default_config()
+    cfg.precompute_factor = factor
+    cfg.c, cfg.bitsize = c, bitsize
+    cfg.are_points_on_device = _on_dev(bases)
+    cfg.are_results_on_device = True
+    f = min(factor, msm_windows(n, c, bitsize, curve))
+    out = DeviceBuffer(aff * n * f)
+    _check(getattr(lib(), sym)(_p(bases), int(n), ctypes.byref(cfg), _p(out)), sym)
+    return out
+
+
+def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize=0, stream=None, curve="bls12_381",
+        precompute_factor=1):
     """returns `batch` projective results (144 B each; 96 B for bn254) on the host"""
-    sym, _, _, _, aff = _CURVES[curve]
+    sym, aff = _CURVES[curve][0], _CURVES[curve][4]
     cfg = lib().tkmk_msm_default_config()
     n = _len(scalars) // batch if msm_size is None else msm_size
     cfg.batch_size = batch
@@ -342,6 +376,7 @@ def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize
     cfg.c = c
     cfg.bitsize = bitsize
     cfg.stream_handle = stream
+    cfg.precompute_factor = precompute_factor
     out = np.empty(aff // 2 * 3 * batch, np.uint8)
     _check(getattr(lib(), sym)(_p(scalars), _p(bases), int(n), ctypes.byref(cfg), _p(out)), sym)
     return out
@@ -351,11 +386,12 @@ class MsmJob(ctypes.Structure):
     _fields_ = [("scalars", ctypes.c_void_p), ("bases", ctypes.c_void_p), ("msm_size", ctypes.c_int)]
 
 
-def msm_multi(jobs, c=0, bitsize=0, stream=None, curve="bls12_381"):
+def msm_multi(jobs, c=0, bitsize=0, stream=None, curve="bls12_381", precompute_factor=1):
     """jobs = [(scalars, bases[, msm_size])...], all host buffers or all DeviceBuffers; returns len(jobs) projective
     results on the host.  Independent MSMs are pipelined over internal streams (tkmk_msm_multi)."""
-    _, sym, _, _, aff = _CURVES[curve]
+    sym, aff = _CURVES[curve][1], _CURVES[curve][4]
     cfg = lib().tkmk_msm_default_config()
+    cfg.precompute_factor = precompute_factor
     if not jobs:
         return np.empty(0, np.uint8)
     on_dev_s = {_on_dev(j[0]) for j in jobs}
