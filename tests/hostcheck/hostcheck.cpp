@@ -1,33 +1,7 @@
 // hostcheck.cpp — TEST-ONLY: runs the product's __host__ __device__ field / curve templates
 // (tokamak-zk-evm_amd/csrc/ff.h, ec.h) on the CPU so the not-gpu test tier can compare the exact
 // code the kernels inline against the oracle.  Never linked into libtkmk_hip.so.
-#include <string.h>
-
-#include "ec.h"
-
-template <class F>
-static void load(typename F::E &e, const uint8_t *p) { memcpy(e.l, p, 4 * F::N); }
-template <class F>
-static void store(uint8_t *p, const typename F::E &e) { memcpy(p, e.l, 4 * F::N); }
-
-template <class F>
-static void binop(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) {
-    for (size_t i = 0; i < n; i++) {
-        typename F::E x, y, z;
-        load<F>(x, a + 4 * F::N * i);
-        load<F>(y, b + 4 * F::N * i);
-        switch (op) {
-            case 0: z = F::add(x, y); break;
-            case 1: z = F::sub(x, y); break;
-            case 2: z = F::from_mont(F::mul(F::to_mont(x), F::to_mont(y))); break;
-            case 3: z = F::mul(x, F::to_mont(y)); break;  // plain * mont -> plain (NTT butterfly form)
-            case 4: z = F::from_mont(F::inv(F::to_mont(x))); break;
-            case 5: z = F::neg(x); break;
-            default: z = F::zero();
-        }
-        store<F>(o + 4 * F::N * i, z);
-    }
-}
+#include "hostcheck_common.h"
 
 extern "C" {
 void hc_fr_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { binop<Fr>(op, a, b, o, n); }
@@ -176,134 +150,3 @@ extern "C" int hc_ntt(const uint8_t *in, uint32_t logn, uint64_t batch, int colu
     return passes;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// unsaturated (radix 2^29) field / curve path of the MSM accumulate loop (csrc/ffu.h, ec_u.h), on the host with
-// every bound assertion enabled.
-// ---------------------------------------------------------------------------------------------------
-#include "ec_u.h"
-
-// plain Fq values in / out; op 0 mul, 1 sqr, 2 add, 3 sub<2> (a - b mod p), 4 pack(unpack) round trip
-template <class P>
-static void fqu_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) {
-    using F = ff<P>;
-    using FU = ffu<P>;
-    const size_t sz = 4 * F::N;
-    typename F::E ksat;
-    for (int i = 0; i < F::N; i++) ksat.l[i] = P::KSAT[i];
-    for (size_t i = 0; i < n; i++) {
-        typename F::E x, y;
-        load<F>(x, a + sz * i);
-        load<F>(y, b + sz * i);
-        // plain -> x 2^(W L) mod p (what k_convert_bases does) -> strict limbs
-        typename FU::E ux = FU::from_packed(F::mul(x, ksat)), uy = FU::from_packed(F::mul(y, ksat));
-        typename FU::E r;
-        switch (op) {
-            case 0: r = FU::mul(ux, uy); break;
-            case 1: r = FU::sqr(ux); break;
-            case 2: r = FU::add(ux, uy); break;
-            case 3: r = FU::template sub<2>(ux, uy); break;
-            default: r = ux;
-        }
-        // back: x 2^(W L) (redundant) -> saturated Montgomery -> plain
-        store<F>(o + sz * i, F::from_mont(FU::to_sat_mont(r)));
-    }
-}
-// chain: acc = P0; acc += P_i (signed) for every following point, through the unsaturated mixed add; result affine plain
-template <class P>
-static void g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, uint8_t *out) {
-    using F = ff<P>;
-    using GU = ecu<P>;
-    using G = ec<F>;
-    const size_t sz = 4 * F::N;
-    typename F::E ksat;
-    for (int i = 0; i < F::N; i++) ksat.l[i] = P::KSAT[i];
-    typename GU::X acc = GU::inf();
-    for (size_t i = 0; i < n; i++) {
-        affine_t<F> rec;
-        load<F>(rec.x, pts + 2 * sz * i);
-        load<F>(rec.y, pts + 2 * sz * i + sz);
-        if (!(F::is_zero(rec.x) && F::is_zero(rec.y))) {
-            rec.x = F::mul(rec.x, ksat);
-            rec.y = F::mul(rec.y, ksat);
-        }
-        typename GU::A q;
-        if (!GU::load_affine(q, rec)) continue;
-        if (negate[i]) q = GU::neg(q);
-        acc = GU::add_mixed(acc, q);
-    }
-    // both ways out of the unsaturated form must agree: direct conversion, and the multiplication-free raw record the
-    // accumulate kernel stores + the reader-side conversion (ec_u.h to_raw / raw_to_sat)
-    affine_t<F> r = G::to_affine(GU::to_sat(acc));
-    affine_t<F> r2 = G::to_affine(GU::raw_to_sat(GU::to_raw(acc)));
-    if (!(F::eq(r.x, r2.x) && F::eq(r.y, r2.y))) memset(&r, 0xff, sizeof r);   // poison the output: the test will fail
-    store<F>(out, F::from_mont(r.x));
-    store<F>(out + sz, F::from_mont(r.y));
-}
-// general add / doubling on the unsaturated form (the combine / bucket-reduction kernels): out = affine plain of
-//   mode 0: A + B      mode 1: 2A      mode 2: A + A' (A' = the same point reached by another addition order: doubling branch)
-//   mode 3: A + (-A')  (infinity)      mode 4: [k] A by double-and-add (k = 16-bit)
-// where A = p0 + p1 + p2 and B = p3 + p4 are built with the mixed adder so that ZZ, ZZZ != 1; records go through to_raw / from_raw
-template <class P>
-static void g1u_full(int mode, const uint8_t *pts, uint32_t k, uint8_t *out) {
-    using F = ff<P>;
-    using GU = ecu<P>;
-    using G = ec<F>;
-    const size_t sz = 4 * F::N;
-    typename F::E ksat;
-    for (int i = 0; i < F::N; i++) ksat.l[i] = P::KSAT[i];
-    typename GU::A q[5];
-    for (int i = 0; i < 5; i++) {
-        affine_t<F> rec;
-        load<F>(rec.x, pts + 2 * sz * i);
-        load<F>(rec.y, pts + 2 * sz * i + sz);
-        rec.x = F::mul(rec.x, ksat);
-        rec.y = F::mul(rec.y, ksat);
-        GU::load_affine(q[i], rec);
-    }
-    auto chain = [&](int a, int b, int c) {
-        typename GU::X x = GU::add_mixed(GU::inf(), q[a]);
-        x = GU::add_mixed(x, q[b]);
-        if (c >= 0) x = GU::add_mixed(x, q[c]);
-        return GU::from_raw(GU::to_raw(x));
-    };
-    typename GU::X A = chain(0, 1, 2), B = chain(3, 4, -1), r;
-    switch (mode) {
-        case 0: r = GU::add(A, B); break;
-        case 1: r = GU::dbl(A); break;
-        case 2: r = GU::add(A, chain(2, 0, 1)); break;
-        case 3: {
-            typename GU::X n = chain(1, 2, 0);
-            typename GU::A ny;
-            ny.x = n.y;
-            ny.y = n.y;
-            n.y = GU::neg(ny).y;    // p - y (strict); same bound as a canonical y
-            r = GU::add(A, n);
-            break;
-        }
-        default: {
-            r = GU::inf();
-            for (int bit = 15; bit >= 0; bit--) {
-                r = GU::dbl(r);
-                if ((k >> bit) & 1) r = GU::add(r, A);
-            }
-        }
-    }
-    affine_t<F> a = G::to_affine(GU::raw_to_sat(GU::to_raw(r)));
-    store<F>(out, F::from_mont(a.x));
-    store<F>(out + sz, F::from_mont(a.y));
-}
-extern "C" {
-void hc_g1u_full(int mode, const uint8_t *pts, uint32_t k, uint8_t *out) { g1u_full<bls12_381_fq_params>(mode, pts, k, out); }
-void hc_bn254_g1u_full(int mode, const uint8_t *pts, uint32_t k, uint8_t *out) { g1u_full<bn254_fq_params>(mode, pts, k, out); }
-void hc_fqu_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { fqu_op<bls12_381_fq_params>(op, a, b, o, n); }
-void hc_g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, uint8_t *out) {
-    g1u_accumulate<bls12_381_fq_params>(pts, negate, n, out);
-}
-// BN254 instantiation (8 saturated / 10 x 28-bit unsaturated limbs)
-void hc_bn254_fr_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { binop<ff<bn254_fr_params>>(op, a, b, o, n); }
-void hc_bn254_fq_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { binop<ff<bn254_fq_params>>(op, a, b, o, n); }
-void hc_bn254_fqu_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *o, size_t n) { fqu_op<bn254_fq_params>(op, a, b, o, n); }
-void hc_bn254_g1u_accumulate(const uint8_t *pts, const uint8_t *negate, size_t n, uint8_t *out) {
-    g1u_accumulate<bn254_fq_params>(pts, negate, n, out);
-}
-}

@@ -17,13 +17,13 @@ CSRC = os.path.join(ROOT, "tokamak-zk-evm_amd", "csrc")
 
 @pytest.fixture(scope="module")
 def hc():
-    src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
-    so = os.path.join(HERE, "hostcheck", "libhostcheck.so")
-    deps = [src] + [os.path.join(CSRC, f) for f in ("ff.h", "ec.h", "field_params.h", "ntt_plan.h", "ffu.h", "ec_u.h")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
-        if shutil.which("hipcc") is None:
-            pytest.skip("hipcc not available")
-        subprocess.run(["hipcc", "-O2", "-fPIC", "-shared", "--offload-host-only", "-I" + CSRC, src, "-o", so], check=True)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hostcheck_build", os.path.join(HERE, "hostcheck", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    so = mod.build()
+    if so is None:
+        pytest.skip("hipcc not available")
     return ctypes.CDLL(so)
 
 
