@@ -107,3 +107,27 @@ def test_release_scratch_returns_memory(gpu, oracle):
     _, free_after = gpu.available_memory()
     assert free_after > free_before
     assert (gpu.msm(s, p) == r1).all()          # arenas regrow transparently
+
+
+def test_long_vector_inverse_and_division(gpu, oracle):
+    # >= 2^16 elements take the 16-per-lane batched inversion (csrc/vecops.hip k_vec_inv<., 16>): ragged length, zeros
+    # sprinkled through every lane's batch (a zero must not poison its neighbours), in-place output over either operand
+    n = (1 << 17) + 12345
+    av = oracle.to_ints(oracle.fr_random(31, n), 32)
+    for i in list(range(0, n, 97)) + [1, 2, n - 1, n - 2]:
+        av[i] = 0
+    a = oracle.to_bytes(av, 32)
+    b = oracle.fr_random(32, n)
+    inv = oracle.fr_inv(a)
+    assert (gpu.vec_inv(a) == inv).all()
+    quot = oracle.fr_mul(b, inv)
+    assert (gpu.vec_div(b, a) == quot).all()
+    da, db = gpu.DeviceBuffer.from_host(a), gpu.DeviceBuffer.from_host(b)
+    gpu.vec_div(db, da, out=db)                       # numerator overwritten
+    assert (db.to_host() == quot).all()
+    db = gpu.DeviceBuffer.from_host(b)
+    gpu.vec_div(db, da, out=da)                       # denominator overwritten
+    assert (da.to_host() == quot).all()
+    da = gpu.DeviceBuffer.from_host(a)
+    gpu.vec_inv(da, out=da)
+    assert (da.to_host() == inv).all()

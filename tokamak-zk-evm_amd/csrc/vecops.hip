@@ -30,46 +30,41 @@ __global__ __launch_bounds__(256) void k_vec(const fr_t *__restrict__ a, const f
                 tk_store(out + i, r);
     }
 }
-// Division / inversion: 4 elements per lane share one Fermat inversion (Montgomery's trick:
-// 1 inversion + 9 products per 4 elements instead of 4 x ~380 products).
-template <bool DIV>
+// Division / inversion: K elements per lane share one Fermat inversion (Montgomery's trick: 1 inversion + 6 products
+// per element instead of ~380).  K = 16 for long vectors: the K prefix products stay in registers and the operands are
+// read again on the way back (a second coalesced read is far cheaper than 16 more live field elements per lane).
+template <bool DIV, int K>
 __global__ __launch_bounds__(256) void k_vec_inv(const fr_t *__restrict__ a, const fr_t *__restrict__ b,
                                                 fr_t *__restrict__ out, uint64_t n) {
-    // lane handles 4 consecutive-stride elements: i, i+S, i+2S, i+3S (S = total threads) so that every
-    // load/store instruction stays coalesced.  x = denominators (Montgomery), zero-safe: inv(0) = 0.
+    // lane handles K stride-S elements: i, i+S, ..., i+(K-1)S (S = total threads) so that every load/store instruction
+    // stays coalesced.  Denominators in Montgomery form, zero-safe: inv(0) = 0 (a zero contributes 1 to the products).
     uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t S = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t base = tid; base < n; base += 4 * S) {
-        fr_t x[4], pre[4];
-        bool z[4], live[4];
+    for (uint64_t base = tid; base < n; base += (uint64_t)K * S) {
+        fr_t pre[K];
         fr_t acc = Fr::one();
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < K; k++) {
             uint64_t i = base + k * S;
-            live[k] = i < n;
-            x[k] = Fr::one();
-            z[k] = true;
-            if (live[k]) {
-                fr_t v = Fr::canon(tk_load((DIV ? b : a) + i));
-                z[k] = Fr::is_zero(v);
-                if (!z[k]) x[k] = Fr::to_mont(v);
-            }
             pre[k] = acc;
-            acc = Fr::mul(acc, x[k]);
-        }
-        fr_t ia = Fr::inv(acc);  // (x0 x1 x2 x3)^-1, Montgomery
-#pragma unroll
-        for (int k = 3; k >= 0; k--) {
-            fr_t xi = Fr::mul(ia, pre[k]);  // x_k^-1 (Montgomery)
-            ia = Fr::mul(ia, x[k]);
-            uint64_t i = base + k * S;
-            if (live[k]) {
-                fr_t r;
-                if (z[k]) r = Fr::zero();
-                else if (DIV) r = Fr::mul(xi, Fr::canon(tk_load(a + i)));  // Mont * plain -> plain
-                else r = Fr::from_mont(xi);
-                tk_store(out + i, r);
+            if (i < n) {
+                fr_t v = Fr::canon(tk_load((DIV ? b : a) + i));
+                if (!Fr::is_zero(v)) acc = Fr::mul(acc, Fr::to_mont(v));
             }
+        }
+        fr_t ia = Fr::inv(acc);  // (prod of the non-zero x_k)^-1, Montgomery
+#pragma unroll
+        for (int k = K - 1; k >= 0; k--) {
+            uint64_t i = base + k * S;
+            if (i >= n) continue;
+            fr_t v = Fr::canon(tk_load((DIV ? b : a) + i));   // read again instead of keeping K operands live
+            fr_t r = Fr::zero();
+            if (!Fr::is_zero(v)) {
+                fr_t xi = Fr::mul(ia, pre[k]);  // x_k^-1 (Montgomery)
+                ia = Fr::mul(ia, Fr::to_mont(v));
+                r = DIV ? Fr::mul(xi, Fr::canon(tk_load(a + i))) : Fr::from_mont(xi);  // Mont * plain -> plain
+            }
+            tk_store(out + i, r);
         }
     }
 }
@@ -154,8 +149,14 @@ static tkmk_error vec_entry(int op, const tkmk_fr *a, const tkmk_fr *b, uint64_t
         case OP_SADD: hipLaunchKernelGGL(k_vec<OP_SADD>, g, 256, 0, s, pa, pb, po, total); break;
         case OP_SSUB: hipLaunchKernelGGL(k_vec<OP_SSUB>, g, 256, 0, s, pa, pb, po, total); break;
         case OP_SMUL: hipLaunchKernelGGL(k_vec<OP_SMUL>, g, 256, 0, s, pa, pb, po, total); break;
-        case OP_DIV: hipLaunchKernelGGL(k_vec_inv<true>, grid_for(total, 1024), 256, 0, s, pa, pb, po, total); break;
-        case OP_INV: hipLaunchKernelGGL(k_vec_inv<false>, grid_for(total, 1024), 256, 0, s, pa, pa, po, total); break;
+        case OP_DIV:
+            if (total >= (1u << 16)) hipLaunchKernelGGL((k_vec_inv<true, 16>), grid_for(total, 4096), 256, 0, s, pa, pb, po, total);
+            else hipLaunchKernelGGL((k_vec_inv<true, 4>), grid_for(total, 1024), 256, 0, s, pa, pb, po, total);
+            break;
+        case OP_INV:
+            if (total >= (1u << 16)) hipLaunchKernelGGL((k_vec_inv<false, 16>), grid_for(total, 4096), 256, 0, s, pa, pa, po, total);
+            else hipLaunchKernelGGL((k_vec_inv<false, 4>), grid_for(total, 1024), 256, 0, s, pa, pa, po, total);
+            break;
         default: return TKMK_ERR_INVALID_ARGUMENT;
     }
     TK_HIP(hipGetLastError());
