@@ -289,6 +289,23 @@ tkmk_error tkmk_poly_scale_coeffs(const tkmk_fr *src_dev, uint32_t x_size, uint3
 /* dst[i][j] = evals[i][j] * (w_x^i - 1): PolyExpr::MulXMinusOne on the evaluation domain (mod.rs:372-378, 504-518) */
 tkmk_error tkmk_poly_mul_x_minus_one_evals(const tkmk_fr *evals_dev, uint32_t x_size, uint32_t y_size, tkmk_fr *dst_dev,
                                            tkmk_stream stream);
+
+/* One-pass evaluation of a pointwise expression over evaluation-domain matrices: the device side of
+ * PolyExpr::evaluate_fused_with_domain / evaluate_on_domain (libs/src/bivariate_polynomial/mod.rs:227-260, 311-435), which in
+ * the reference runs one pass (and one fresh 256 MiB buffer) per tree node — prove2's p_comb is ~15 passes over 2^23
+ * elements.  `prog` is the tree in postfix order over a stack of at most 6 values:
+ *   LEAF k   push leaves_dev[k][e]          CONST k  push consts[k]          ADD / SUB / MUL   (second op top)
+ *   SCALE k  top *= consts[k]               MUL_X_MINUS_ONE  top *= (w_x^ix - 1), w_x of order x_size (mod.rs:372-378)
+ * Every leaf is an x_size * y_size device matrix of evaluations (plain form, as tkmk_bintt writes them); consts are
+ * host scalars; out_dev may alias a leaf.  At most 16 leaves, 16 constants, 128 steps after form conversions. */
+typedef enum {
+    TKMK_EXPR_LEAF = 0, TKMK_EXPR_CONST = 1, TKMK_EXPR_ADD = 2, TKMK_EXPR_SUB = 3, TKMK_EXPR_MUL = 4, TKMK_EXPR_SCALE = 5,
+    TKMK_EXPR_MUL_X_MINUS_ONE = 6
+} tkmk_expr_opcode;
+typedef struct { uint8_t op; uint8_t arg; } tkmk_expr_instr;
+tkmk_error tkmk_poly_expr_eval(const tkmk_expr_instr *prog, uint32_t n_instr, const tkmk_fr *const *leaves_dev, uint32_t n_leaves,
+                               const tkmk_fr *consts, uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev,
+                               tkmk_stream stream);
 /* eval_x / eval_y / eval (mod.rs:1719-1750): out_dev has y_size / x_size elements; out_host one */
 tkmk_error tkmk_poly_eval_x(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, tkmk_fr *out_dev,
                             tkmk_stream stream);

@@ -273,3 +273,57 @@ def test_witness_and_permutation_polynomials(P, gpu, oracle):
         for c in range(s_max):
             X, Y = tgt.get((r, c), (r, c))
             assert e0[r * s_max + c] == pow(wx, X, R) and e1[r * s_max + c] == pow(wy, Y, R)
+
+
+def test_expr_one_pass_kernel(P, gpu, oracle):
+    """tkmk_poly_expr_eval (csrc/expr.hip): the postfix program of a whole expression in ONE pass over the leaves ==
+    the node-by-node route, element for element; form tracking (plain / Montgomery) exercised through every operand
+    combination; malformed programs are rejected; over-deep trees fall back to the node-by-node route."""
+    from tkmk.poly import PolyExpr as E
+    xs, ys = 32, 8
+    n = xs * ys
+    la, lb, lc = (oracle.fr_random(50 + k, n) for k in range(3))
+    k1, k2 = oracle.fr_random(60, 1), oracle.fr_random(61, 1)
+    da, db, dc = (gpu.DeviceBuffer.from_host(v) for v in (la, lb, lc))
+    consts = np.concatenate([k1, k2])
+    wx = oracle.to_ints(oracle.root_of_unity(xs), 32)[0]
+    R = oracle.R_MOD
+    xm1 = oracle.to_bytes([(pow(wx, i, R) - 1) % R for i in range(xs) for _ in range(ys)], 32)
+    mul, add, sub = oracle.fr_mul, oracle.fr_add, oracle.fr_sub
+    sc = lambda s, v: oracle.fr_scalar_mul(s, v)   # noqa: E731
+    LEAF, CONST, ADD, SUB, MUL, SCALE, XM1 = range(7)
+    cases = [
+        ([(LEAF, 0), (LEAF, 1), (MUL, 0)], mul(la, lb)),                                   # plain * plain
+        ([(LEAF, 0), (CONST, 0), (MUL, 0), (LEAF, 1), (ADD, 0)], add(sc(k1, la), lb)),       # plain * mont -> plain
+        ([(CONST, 0), (CONST, 1), (MUL, 0), (LEAF, 2), (SUB, 0)], sub(np.tile(mul(k1, k2), n), lc)),   # mont - plain
+        ([(LEAF, 2), (CONST, 1), (SUB, 0)], sub(lc, np.tile(k2, n))),                       # plain - mont
+        ([(LEAF, 0), (XM1, 0), (SCALE, 1), (LEAF, 1), (LEAF, 2), (MUL, 0), (SUB, 0)], sub(sc(k2, mul(la, xm1)), mul(lb, lc))),
+        ([(LEAF, 0), (LEAF, 0), (MUL, 0), (LEAF, 0), (MUL, 0)], mul(mul(la, la), la)),        # a leaf used three times
+        ([(CONST, 1)], np.tile(k2, n)),
+    ]
+    for prog, want in cases:
+        got = gpu.poly_expr_eval(prog, [da, db, dc], consts, 2, xs, ys).to_host()
+        assert (got == want).all(), prog
+    # output may alias a leaf
+    tmp = gpu.DeviceBuffer.from_host(la)
+    gpu.poly_expr_eval([(LEAF, 0), (LEAF, 1), (MUL, 0), (LEAF, 0), (ADD, 0)], [tmp, db], consts, 2, xs, ys, out=tmp)
+    assert (tmp.to_host() == add(mul(la, lb), la)).all()
+    for bad in ([(ADD, 0)], [(LEAF, 0), (LEAF, 1)], [(LEAF, 7)], [(CONST, 5)], [(LEAF, 0), (SCALE, 9)], [(9, 0)],
+                [(LEAF, 0)] * 7 + [(ADD, 0)] * 6):
+        with pytest.raises(gpu.TkmkError):
+            gpu.poly_expr_eval(bad, [da, db, dc], consts, 2, xs, ys)
+    # PolyExpr: one-pass == node-by-node, and a right-deep tree beyond the stack limit still evaluates (fallback)
+    A, B, C = (P.from_rou_evals(gpu.DeviceBuffer.from_host(v), xs, ys) for v in (la, lb, lc))
+    expr = E.sub(E.mul(E.add(E.poly(A), E.poly(B)), E.scale(k1, E.mul_x_minus_one(E.poly(C)))), E.weighted_sum([(k2, E.poly(A)), (k1, E.scalar(k2))]))
+    one = expr._one_pass(2 * xs, 2 * ys, {})
+    assert one is not None
+    node, _ = expr._on_domain(2 * xs, 2 * ys, {})
+    assert (one.to_host() == node.to_host()).all()
+    deep = E.poly(A)
+    for _ in range(8):
+        deep = E.add(E.poly(B), deep)                       # B + (B + (B + ... A)): needs 9 stack levels left to right
+    assert deep._one_pass(xs, ys, {}) is None
+    want = A
+    for _ in range(8):
+        want = B + want
+    assert (deep.evaluate_fused_with_domain(xs, ys).copy_coeffs() == want.copy_coeffs()).all()

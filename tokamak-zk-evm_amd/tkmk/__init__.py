@@ -90,7 +90,7 @@ SYMBOLS = [
     "bls12_381_scalar_sub_vec", "bls12_381_scalar_mul_vec", "bls12_381_vector_sum", "bls12_381_vector_product",
     "bls12_381_matrix_transpose", "tkmk_vec_suffix_product", "tkmk_fr_random_device", "tkmk_gather_rows_device", "tkmk_g1_batch_scalar_mul_device", "tkmk_profile_enable",
     "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench", "tkmk_diag_field_mul", "tkmk_poly_find_degree",
-    "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
+    "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_expr_eval", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
     "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini", "tkmk_r1cs_eval_rows",
 ]
 
@@ -477,6 +477,22 @@ def gather_rows_device(src, row_bytes, idx, out=None):
     out = DeviceBuffer(row_bytes * n) if out is None else out
     _check(lib().tkmk_gather_rows_device(_p(src), ctypes.c_uint32(row_bytes), _p(idx), ctypes.c_uint64(n), _p(out), None),
            "tkmk_gather_rows_device")
+    return out
+
+
+class ExprInstr(ctypes.Structure):
+    _fields_ = [("op", ctypes.c_uint8), ("arg", ctypes.c_uint8)]
+
+
+def poly_expr_eval(prog, leaves, consts, n_consts, x_size, y_size, out=None):
+    """prog: [(opcode, arg), ...] in postfix order (tkmk_expr_opcode); leaves: DeviceBuffers of x_size*y_size evaluations;
+    consts: numpy uint8 (32 bytes per constant).  One kernel pass; returns the DeviceBuffer of result evaluations."""
+    arr = (ExprInstr * len(prog))(*[ExprInstr(int(o), int(a)) for o, a in prog])
+    ptrs = (ctypes.c_void_p * max(1, len(leaves)))(*[b.ptr for b in leaves])
+    out = DeviceBuffer(32 * x_size * y_size) if out is None else out
+    _check(lib().tkmk_poly_expr_eval(arr, ctypes.c_uint32(len(prog)), ptrs, ctypes.c_uint32(len(leaves)), _p(consts),
+                                     ctypes.c_uint32(n_consts), ctypes.c_uint32(x_size), ctypes.c_uint32(y_size), _p(out), None),
+           "tkmk_poly_expr_eval")
     return out
 
 

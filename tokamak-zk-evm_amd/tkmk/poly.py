@@ -308,8 +308,74 @@ class PolyExpr:
         if (_next_pow2(xd + 1) if xd >= 0 else 1) > target_x_size or (_next_pow2(yd + 1) if yd >= 0 else 1) > target_y_size:
             raise ValueError("Fused polynomial expression domain is too small for the expression degree.")
         cache = {}
-        evals, _ = self._on_domain(target_x_size, target_y_size, cache)
+        evals = self._one_pass(target_x_size, target_y_size, cache)
+        if evals is None:       # too deep / too many operands for the one-pass kernel: node-by-node route
+            evals, _ = self._on_domain(target_x_size, target_y_size, cache)
         return DensePolynomialExt.from_rou_evals(evals, target_x_size, target_y_size)
+
+    # -- one-pass route: the whole tree in ONE kernel over the leaves (tkmk_poly_expr_eval, csrc/expr.hip) --
+    _OPS = {"add": 2, "sub": 3, "mul": 4}
+    MAX_DEPTH, MAX_LEAVES, MAX_CONSTS, MAX_INSTR = 6, 16, 16, 100
+
+    def _compile(self, prog, leaves, consts, depth):
+        """appends the postfix program of this node; returns the stack depth it needs on top of `depth`, or None"""
+        k, a = self.kind, self.args
+
+        def const_index(c):
+            key = bytes(c)
+            if key not in consts:
+                consts[key] = len(consts)
+            return consts[key]
+
+        if k == "poly":
+            if id(a[0]) not in leaves:
+                leaves[id(a[0])] = (len(leaves), a[0])
+            prog.append((0, leaves[id(a[0])][0]))
+            return 1
+        if k == "scalar":
+            prog.append((1, const_index(a[0])))
+            return 1
+        if k in self._OPS:
+            l = a[0]._compile(prog, leaves, consts, depth)
+            if l is None:
+                return None
+            r = a[1]._compile(prog, leaves, consts, depth + 1)
+            if r is None:
+                return None
+            prog.append((self._OPS[k], 0))
+            return max(l, 1 + r)
+        if k in ("scale", "xm1"):
+            d = a[-1]._compile(prog, leaves, consts, depth)
+            if d is None:
+                return None
+            prog.append((5, const_index(a[0])) if k == "scale" else (6, 0))
+            return d
+        need = 0                          # weighted sum: running total on the stack
+        if not a[0]:
+            prog.append((1, const_index(np.zeros(32, np.uint8))))
+            return 1
+        for i, t in enumerate(a[0]):
+            d = t._compile(prog, leaves, consts, depth + (1 if i else 0))
+            if d is None:
+                return None
+            need = max(need, d + (1 if i else 0))
+            if i:
+                prog.append((2, 0))
+        return need
+
+    def _one_pass(self, xs, ys, cache):
+        prog, leaves, consts = [], {}, {}
+        need = self._compile(prog, leaves, consts, 0)
+        if (need is None or need > self.MAX_DEPTH or len(leaves) > self.MAX_LEAVES or len(consts) > self.MAX_CONSTS
+                or len(prog) > self.MAX_INSTR or not leaves):
+            return None
+        bufs = [None] * len(leaves)
+        for idx, p in leaves.values():
+            bufs[idx] = PolyExpr.poly(p)._on_domain(xs, ys, cache)[0]        # leaf NTTs, cached by identity and domain
+        cst = np.zeros(32 * max(1, len(consts)), np.uint8)
+        for key, i in consts.items():
+            cst[32 * i:32 * i + 32] = np.frombuffer(key, np.uint8)
+        return tkmk.poly_expr_eval(prog, bufs, cst, len(consts), xs, ys)
 
     def _on_domain(self, xs, ys, cache):
         """-> (DeviceBuffer of evaluations, owned): owned buffers are temporaries that may be overwritten in place"""
