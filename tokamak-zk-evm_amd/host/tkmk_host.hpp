@@ -393,6 +393,19 @@ class PolyExpr {
         if (domain_size_for_degree(d.first) > target_x_size || domain_size_for_degree(d.second) > target_y_size)
             throw Error("Fused polynomial expression domain is too small for the expression degree.");
         std::map<const DensePolynomialExt *, std::shared_ptr<DeviceVec<ScalarField>>> cache;
+        // one kernel pass over the leaf evaluations when the tree fits the device evaluator (tkmk_poly_expr_eval);
+        // otherwise node by node
+        Program pg;
+        int need = compile(pg, 0);
+        if (need > 0 && need <= 6 && !pg.leaves.empty() && pg.leaves.size() <= 16 && pg.consts.size() <= 16 && pg.code.size() <= 100) {
+            std::vector<const tkmk_fr *> ptrs;
+            for (const DensePolynomialExt *l : pg.leaves) ptrs.push_back(leaf_evals(l, target_x_size, target_y_size, cache)->ptr());
+            DeviceVec<ScalarField> out(target_x_size * target_y_size);
+            check(tkmk_poly_expr_eval(pg.code.data(), (uint32_t)pg.code.size(), ptrs.data(), (uint32_t)ptrs.size(), pg.consts.data(),
+                                      (uint32_t)pg.consts.size(), (uint32_t)target_x_size, (uint32_t)target_y_size, out.ptr(), nullptr),
+                  "tkmk_poly_expr_eval");
+            return DensePolynomialExt::from_rou_evals(out, target_x_size, target_y_size);
+        }
         DeviceVec<ScalarField> evals = on_domain(target_x_size, target_y_size, cache);
         return DensePolynomialExt::from_rou_evals(evals, target_x_size, target_y_size);
     }
@@ -405,21 +418,84 @@ class PolyExpr {
         e.kids.push_back(std::move(r));
         return e;
     }
+    using LeafCache = std::map<const DensePolynomialExt *, std::shared_ptr<DeviceVec<ScalarField>>>;
+    static std::shared_ptr<DeviceVec<ScalarField>> leaf_evals(const DensePolynomialExt *leaf, size_t xs, size_t ys, LeafCache &cache) {
+        auto it = cache.find(leaf);
+        if (it == cache.end()) {
+            DensePolynomialExt r = leaf->clone();
+            r.resize(xs, ys);
+            check(tkmk_bintt(r.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, r.poly.ptr()), "_biNTT");
+            it = cache.emplace(leaf, std::make_shared<DeviceVec<ScalarField>>(std::move(r.poly))).first;
+        }
+        return it->second;
+    }
+    // postfix program for tkmk_poly_expr_eval; compile() returns the stack depth the node needs, or -1
+    struct Program {
+        std::vector<tkmk_expr_instr> code;
+        std::vector<const DensePolynomialExt *> leaves;
+        std::vector<ScalarField> consts;
+        uint8_t leaf_index(const DensePolynomialExt *p) {
+            for (size_t i = 0; i < leaves.size(); i++)
+                if (leaves[i] == p) return (uint8_t)i;
+            leaves.push_back(p);
+            return (uint8_t)(leaves.size() - 1);
+        }
+        uint8_t const_index(const ScalarField &c) {
+            for (size_t i = 0; i < consts.size(); i++)
+                if (fr_eq(consts[i], c)) return (uint8_t)i;
+            consts.push_back(c);
+            return (uint8_t)(consts.size() - 1);
+        }
+    };
+    int compile(Program &pg, int depth) const {
+        if (pg.leaves.size() > 200 || pg.consts.size() > 200 || pg.code.size() > 1000) return -1;
+        switch (kind) {
+            case Poly: pg.code.push_back({TKMK_EXPR_LEAF, pg.leaf_index(leaf)}); return 1;
+            case Scalar: pg.code.push_back({TKMK_EXPR_CONST, pg.const_index(scalar_)}); return 1;
+            case Add:
+            case Sub:
+            case Mul: {
+                int l = kids[0].compile(pg, depth);
+                if (l < 0) return -1;
+                int r = kids[1].compile(pg, depth + 1);
+                if (r < 0) return -1;
+                pg.code.push_back({(uint8_t)(kind == Add ? TKMK_EXPR_ADD : kind == Sub ? TKMK_EXPR_SUB : TKMK_EXPR_MUL), 0});
+                return std::max(l, 1 + r);
+            }
+            case Scale: {
+                int d = kids[0].compile(pg, depth);
+                if (d < 0) return -1;
+                pg.code.push_back({TKMK_EXPR_SCALE, pg.const_index(scalar_)});
+                return d;
+            }
+            case MulXMinusOne: {
+                int d = kids[0].compile(pg, depth);
+                if (d < 0) return -1;
+                pg.code.push_back({TKMK_EXPR_MUL_X_MINUS_ONE, 0});
+                return d;
+            }
+            default: {
+                if (kids.empty()) {
+                    pg.code.push_back({TKMK_EXPR_CONST, pg.const_index(ScalarField{})});
+                    return 1;
+                }
+                int need = 0;
+                for (size_t i = 0; i < kids.size(); i++) {
+                    int d = kids[i].compile(pg, depth + (i ? 1 : 0));
+                    if (d < 0) return -1;
+                    need = std::max(need, d + (i ? 1 : 0));
+                    if (i) pg.code.push_back({TKMK_EXPR_ADD, 0});
+                }
+                return need;
+            }
+        }
+    }
     // every node returns a buffer it owns (leaf evaluations are copied out of the cache like the reference does)
     DeviceVec<ScalarField> on_domain(size_t xs, size_t ys, std::map<const DensePolynomialExt *, std::shared_ptr<DeviceVec<ScalarField>>> &cache) const {
         size_t n = xs * ys;
         tkmk_vecops_config c = dev_cfg();
         switch (kind) {
-            case Poly: {
-                auto it = cache.find(leaf);
-                if (it == cache.end()) {
-                    DensePolynomialExt r = leaf->clone();
-                    r.resize(xs, ys);
-                    check(tkmk_bintt(r.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, r.poly.ptr()), "_biNTT");
-                    it = cache.emplace(leaf, std::make_shared<DeviceVec<ScalarField>>(std::move(r.poly))).first;
-                }
-                return it->second->clone();
-            }
+            case Poly: return leaf_evals(leaf, xs, ys, cache)->clone();
             case Scalar: {
                 std::vector<ScalarField> v(n, scalar_);
                 return DeviceVec<ScalarField>::from_host(v);
