@@ -162,9 +162,12 @@ tkmk_error tk_staged::copy_back(void *dst, size_t bytes, bool on_device, hipStre
 }
 
 // frees every per-stream scratch arena (they are grow-only otherwise: a 2^24-point MSM leaves ~7 GiB parked)
+void tk_alloc_cache_release();
+size_t tk_alloc_cache_bytes();
 TK_API tkmk_error tkmk_release_scratch(void) {
     std::lock_guard<std::mutex> lk(g_arena_mu);
     (void)hipDeviceSynchronize();
+    tk_alloc_cache_release();
     for (auto &kv : g_arenas) {
         tk_arena *a = kv.second;
         if (a->depth > 0) return TKMK_ERR_INVALID_ARGUMENT;  // a call is in progress on that stream
@@ -198,46 +201,142 @@ TK_API tkmk_error tkmk_get_available_memory(size_t *total, size_t *free_bytes) {
     size_t f = 0, t = 0;
     TK_HIP(hipMemGetInfo(&f, &t));
     if (total) *total = t;
-    if (free_bytes) *free_bytes = f;
+    if (free_bytes) *free_bytes = f + tk_alloc_cache_bytes();   // cached blocks are available to the next tkmk_malloc
     return TKMK_SUCCESS;
 }
+// ---- caller-visible device allocations (DeviceVec::device_malloc / Drop in the reference) ----
+// hipMalloc + hipFree of a large block cost ~0.13 ms and hipFree synchronises the device; the polynomial layer above the
+// ABI allocates and drops a 256 MiB temporary per operation (as the reference does).  Freed blocks are therefore kept in
+// size-class free lists and handed out again; a block is reused only after the event recorded at its release has
+// completed.  (hipMallocAsync's pool is not used: recycled pool memory read stale data across XCD L2s on this ROCm — see
+// tools/coherence_test.hip.)  tkmk_release_scratch() returns everything to the driver.
+namespace {
+struct cached_block {
+    void *p;
+    hipEvent_t ev;
+};
+std::mutex g_alloc_mu;
+std::map<void *, size_t> g_live;                       // block -> class size
+std::map<size_t, std::vector<cached_block>> g_cache;   // class size -> free blocks
+size_t g_cached_bytes = 0;
+
+size_t alloc_class(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    const size_t g = bytes < ((size_t)1 << 20) ? (size_t)4096 : ((size_t)2 << 20);
+    return (bytes + g - 1) / g * g;
+}
+size_t alloc_cache_cap() {
+    static const size_t cap = [] {
+        const char *e = getenv("TKMK_ALLOC_CACHE_GB");
+        return (size_t)(e ? atoi(e) : 64) << 30;
+    }();
+    return cap;
+}
+void alloc_cache_flush_locked() {
+    for (auto &kv : g_cache)
+        for (auto &b : kv.second) {
+            (void)hipEventSynchronize(b.ev);
+            (void)hipEventDestroy(b.ev);
+            (void)hipFree(b.p);
+        }
+    g_cache.clear();
+    g_cached_bytes = 0;
+}
+tkmk_error cached_malloc(void **ptr, size_t bytes) {
+    const size_t cls = alloc_class(bytes);
+    cached_block blk{nullptr, nullptr};
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        auto it = g_cache.find(cls);
+        if (it != g_cache.end() && !it->second.empty()) {
+            blk = it->second.back();
+            it->second.pop_back();
+            g_cached_bytes -= cls;
+            g_live[blk.p] = cls;
+        }
+    }
+    if (blk.p) {
+        (void)hipEventSynchronize(blk.ev);   // work queued before the release has finished
+        (void)hipEventDestroy(blk.ev);
+        *ptr = blk.p;
+        return TKMK_SUCCESS;
+    }
+    hipError_t e = hipMalloc(ptr, cls);
+    if (e != hipSuccess) {   // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(g_alloc_mu);
+            alloc_cache_flush_locked();
+        }
+        e = hipMalloc(ptr, cls);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return e == hipErrorOutOfMemory ? TKMK_ERR_OUT_OF_MEMORY : TKMK_ERR_ALLOCATION_FAILED;
+    }
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_live[*ptr] = cls;
+    return TKMK_SUCCESS;
+}
+tkmk_error cached_free(void *ptr, hipStream_t s) {
+    size_t cls = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        auto it = g_live.find(ptr);
+        if (it != g_live.end()) {
+            cls = it->second;
+            g_live.erase(it);
+        }
+    }
+    if (!cls || cls > alloc_cache_cap()) {   // not one of ours (or too large to keep): plain release
+        if (hipFree(ptr) != hipSuccess) {
+            (void)hipGetLastError();
+            return TKMK_ERR_DEALLOCATION_FAILED;
+        }
+        return TKMK_SUCCESS;
+    }
+    cached_block blk{ptr, nullptr};
+    if (hipEventCreateWithFlags(&blk.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(blk.ev, s) != hipSuccess) {
+        (void)hipGetLastError();
+        if (blk.ev) (void)hipEventDestroy(blk.ev);
+        return hipFree(ptr) == hipSuccess ? TKMK_SUCCESS : TKMK_ERR_DEALLOCATION_FAILED;
+    }
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    if (g_cached_bytes + cls > alloc_cache_cap()) alloc_cache_flush_locked();
+    g_cache[cls].push_back(blk);
+    g_cached_bytes += cls;
+    return TKMK_SUCCESS;
+}
+}  // namespace
+
+void tk_alloc_cache_release() {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    alloc_cache_flush_locked();
+}
+size_t tk_alloc_cache_bytes() {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    return g_cached_bytes;
+}
+
 TK_API tkmk_error tkmk_malloc(void **ptr, size_t bytes) {
     if (!ptr) return TKMK_ERR_INVALID_POINTER;
     TK_TRY(tk_require_device());
-    hipError_t e = hipMalloc(ptr, bytes ? bytes : 16);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        *ptr = nullptr;
-        return e == hipErrorOutOfMemory ? TKMK_ERR_OUT_OF_MEMORY : TKMK_ERR_ALLOCATION_FAILED;
-    }
-    return TKMK_SUCCESS;
+    return cached_malloc(ptr, bytes);
 }
 TK_API tkmk_error tkmk_malloc_async(void **ptr, size_t bytes, tkmk_stream s) {
+    (void)s;  // a cached block is ready when it is handed out; a fresh one comes from hipMalloc
     if (!ptr) return TKMK_ERR_INVALID_POINTER;
     TK_TRY(tk_require_device());
-    hipError_t e = hipMallocAsync(ptr, bytes ? bytes : 16, tk_stream(s));
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        *ptr = nullptr;
-        return e == hipErrorOutOfMemory ? TKMK_ERR_OUT_OF_MEMORY : TKMK_ERR_ALLOCATION_FAILED;
-    }
-    return TKMK_SUCCESS;
+    return cached_malloc(ptr, bytes);
 }
 TK_API tkmk_error tkmk_free(void *ptr) {
     if (!ptr) return TKMK_SUCCESS;
-    if (hipFree(ptr) != hipSuccess) {
-        (void)hipGetLastError();
-        return TKMK_ERR_DEALLOCATION_FAILED;
-    }
-    return TKMK_SUCCESS;
+    return cached_free(ptr, nullptr);
 }
 TK_API tkmk_error tkmk_free_async(void *ptr, tkmk_stream s) {
     if (!ptr) return TKMK_SUCCESS;
-    if (hipFreeAsync(ptr, tk_stream(s)) != hipSuccess) {
-        (void)hipGetLastError();
-        return TKMK_ERR_DEALLOCATION_FAILED;
-    }
-    return TKMK_SUCCESS;
+    return cached_free(ptr, tk_stream(s));
 }
 static tkmk_error copy(void *dst, const void *src, size_t bytes, hipMemcpyKind k) {
     if (bytes == 0) return TKMK_SUCCESS;
