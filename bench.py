@@ -246,6 +246,23 @@ def _ntt_secondary(tkmk):
     return res
 
 
+def _usable_cpus(omp_threads):
+    """threads the CPU baseline may really use: OpenMP's default counts every hardware thread of the host, but a one-GPU
+    box only gets a share of them (affinity mask and / or cgroup CPU quota); oversubscribing that share slows the run"""
+    n = omp_threads
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _cpu_baseline(tkmk, sample_logn):
     """The oracle's Pippenger (a C port; the reference's Rust+ICICLE CPU path cannot be built offline) on a
     bounded sample of the same workload, all host threads, checked against the GPU on that sample."""
@@ -256,11 +273,12 @@ def _cpu_baseline(tkmk, sample_logn):
     g = np.frombuffer(bytes(_generator()), np.uint8).copy()
     b = tkmk.g1_batch_scalar_mul_device(hh, g, m)
     sh, bh = s.to_host(), b.to_host()
+    threads = _usable_cpus(oracle.num_threads())
     t0 = time.perf_counter()
-    want = oracle.g1_msm(sh, bh)
+    want = oracle.g1_msm(sh, bh, threads=threads)
     dt = time.perf_counter() - t0
     got = tkmk.projective_to_affine_bytes(tkmk.msm(s, b))
-    return {"value": m / dt * ADDS_PER_POINT, "unit": "group-adds/s", "cores": oracle.num_threads(), "kind": "port",
+    return {"value": m / dt * ADDS_PER_POINT, "unit": "group-adds/s", "cores": threads, "kind": "port",
             "sample": "one 2^%d-point MSM (first 2^%d points of the benchmark stream), %.2f s" % (sample_logn, sample_logn, dt),
             "points_per_s": m / dt, "matches_gpu": bool((got == want).all())}
 
