@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'/root/repo/tokamak-zk-evm_amd')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tokamak-zk-evm_amd'))
 import tkmk
 tkmk.set_device(0)
 for mb in (1, 32, 256, 1024):

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tokamak-zk-evm_amd')
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tokamak-zk-evm_amd'))
 import tkmk, oracle
 tkmk.set_device(0)
 p = oracle.g1_random_bases(3, 8)
