@@ -2,6 +2,7 @@
 // They answer SURVEY.md §8d's open question: the sustained v_mad_u64_u32 rate on gfx950, which is the
 // roofline that actually bounds MSM / NTT (integer VALU issue, not HBM, not MFMA).
 #include "common.h"
+#include "ffu.h"
 
 // kind 0: Fr Montgomery products, 1: Fq products, 2: raw v_mad_u64_u32, 3: G1 XYZZ mixed additions,
 // 4: Fr add/sub pairs, 5: Fq sqr
@@ -60,6 +61,37 @@ __global__ __launch_bounds__(256) void k_diag(uint32_t iters, uint32_t *sink) {
         a.l[0] ^= t;
         for (uint32_t i = 0; i < iters; i++) a = Fq::sqr(a);
         if (a.l[0] == 0x12345) sink[t] = a.l[1];
+    } else if (KIND == 6) {   // Fr product in the tightest unsaturated form (9 x 29 bits, 162 multiply-adds, no carries)
+        using FU = ffu<bls12_381_fr9_params>;
+        typename FU::E a = FU::one(), b = FU::one();
+        a.l[0] ^= t & 0xffff;
+        b.l[1] ^= 0x1234;
+        for (uint32_t i = 0; i < iters; i++) a = FU::mul(a, b);
+        if (a.l[0] == 0x12345) sink[t] = a.l[1];
+    } else if (KIND == 7) {   // one butterfly's worth in that form: product + add + sub (limb-wise, one carry sweep each)
+        using FU = ffu<bls12_381_fr9_params>;
+        typename FU::E a = FU::one(), b = FU::one(), w = FU::one();
+        a.l[0] ^= t & 0xffff;
+        w.l[1] ^= 0x1234;
+        for (uint32_t i = 0; i < iters; i++) {
+            typename FU::E m = FU::mul(b, w);
+            typename FU::E s = FU::add(a, m);
+            b = FU::template sub<2>(a, m);
+            a = FU::cond_sub_p(FU::cond_sub_p(s));   // keep the chain bounded like a real pass would every few stages
+            b = FU::cond_sub_p(FU::cond_sub_p(FU::cond_sub_p(b)));
+        }
+        if (a.l[0] == 0x12345) sink[t] = b.l[1];
+    } else if (KIND == 8) {   // the same butterfly on the saturated form (what k_ntt_pass runs)
+        fr_t a = Fr::one(), b = Fr::r2(), w = Fr::r2();
+        a.l[0] ^= t;
+        a = Fr::canon(a);
+        for (uint32_t i = 0; i < iters; i++) {
+            fr_t m = Fr::mul(b, w);
+            fr_t s = Fr::add(a, m);
+            b = Fr::sub(a, m);
+            a = s;
+        }
+        if (a.l[0] == 0x12345) sink[t] = b.l[1];
     }
 }
 
@@ -177,6 +209,9 @@ TK_API tkmk_error tkmk_diag_bench(int kind, uint32_t iters, uint32_t blocks, int
             case 3: hipLaunchKernelGGL(k_diag<3>, blocks, 256, 0, 0, iters, sink); break;
             case 4: hipLaunchKernelGGL(k_diag<4>, blocks, 256, 0, 0, iters, sink); break;
             case 5: hipLaunchKernelGGL(k_diag<5>, blocks, 256, 0, 0, iters, sink); break;
+            case 6: hipLaunchKernelGGL(k_diag<6>, blocks, 256, 0, 0, iters, sink); break;
+            case 7: hipLaunchKernelGGL(k_diag<7>, blocks, 256, 0, 0, iters, sink); break;
+            case 8: hipLaunchKernelGGL(k_diag<8>, blocks, 256, 0, 0, iters, sink); break;
             case 100: hipLaunchKernelGGL(k_probe_add_co, blocks, 256, 0, 0, iters, sink); break;
             case 101: hipLaunchKernelGGL(k_probe_addc, blocks, 256, 0, 0, iters, sink); break;
             case 102: hipLaunchKernelGGL(k_probe_add, blocks, 256, 0, 0, iters, sink); break;

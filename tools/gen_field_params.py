@@ -9,6 +9,9 @@ FIELDS = {
     "bls12_381_fr": dict(mod=0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, two_adicity=32, qnr=5, wu=28),
     "bls12_381_fq": dict(mod=0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB),
     # BN254 (second instantiation named by BASELINE.json configs; no counterpart in the reference)
+    # experiment: Fr with the tightest unsaturated form (9 x 29 bits = 261 bits, only 6 spare bits: operands must stay below
+    # a few r; csrc/diag.hip kind 6 measures its product against the saturated one)
+    "bls12_381_fr9": dict(mod=0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, wu=29, lu=9),
     "bn254_fr": dict(mod=21888242871839275222246405745257275088548364400416034343698204186575808495617, two_adicity=28, qnr=5, wu=28),
     # 28-bit limbs: with 29 the top limb of 2p would be empty (10 limbs start at bit 261 > 254) and the dominating-limb
     # subtraction constants of ffu::sub<K> need a non-zero top limb
@@ -141,10 +144,10 @@ def sub_const(k, p, n, WU):
     return c
 
 
-def gen_unsat(name, p, WU):
+def gen_unsat(name, p, WU, L_override=None):
     """constants of the radix-2^WU representation (csrc/ffu.h)"""
     nsat = (p.bit_length() + 31) // 32
-    L = -(-(p.bit_length() + 24) // WU)         # radix >= 2^24 p: a product of operands below 2^10 p stays below 1.07 p
+    L = L_override or -(-(p.bit_length() + 24) // WU)   # radix >= 2^24 p: a product of operands below 2^10 p stays below 1.07 p
     assert (2 * p) >> (WU * (L - 1)) >= 2, "top limb of 2p must be non-zero (sub<K> constants)"
     Ru = 1 << (WU * L)
     Rs = 1 << (32 * nsat)
@@ -189,7 +192,7 @@ def main():
             out.append("    static constexpr int TWO_ADICITY = %d;" % s)
             out.append("    // w_{2^%d} = %d^((p-1)/2^%d), plain form" % (s, f["qnr"], s))
             out.append("    static constexpr uint32_t ROOT[%d] = {%s};" % (n, limbs(w, n)))
-        out.extend(gen_unsat(name, p, f.get("wu", WU_DEFAULT)))
+        out.extend(gen_unsat(name, p, f.get("wu", WU_DEFAULT), f.get("lu")))
         out.append("#if defined(__HIP_DEVICE_COMPILE__)")
         out.append("    // r = a*b/2^(32N) in [0, 2p): product-scanning Montgomery product, 1 v_mad_u64_u32 + 1 v_addc_co_u32")
         out.append("    // per limb product, modulus limbs in SGPRs (see tools/gen_field_params.py:gen_mul)")
