@@ -32,6 +32,8 @@ def lib():
         _LIB.tko_get_root_of_unity.restype = ctypes.c_int
         _LIB.tko_g1_on_curve.restype = ctypes.c_int
         _LIB.tko_bn254_g1_on_curve.restype = ctypes.c_int
+        for f in ("tko_bn254_ntt", "tko_bn254_bintt", "tko_bn254_dft_naive", "tko_bn254_get_root_of_unity"):
+            getattr(_LIB, f).restype = ctypes.c_int
         _LIB.tko_num_threads.restype = ctypes.c_int
         _LIB.tko_poly_mul_monomial.restype = ctypes.c_int
         _LIB.tko_poly_div_by_vanishing_opt.restype = ctypes.c_int
@@ -240,6 +242,30 @@ class _Bn254:
     def fr_random(self, seed, n, first=0):
         out = np.empty(32 * n, np.uint8)
         lib().tko_bn254_fr_random(_u64(seed), _sz(first), _sz(n), _p(out))
+        return out
+
+    def root_of_unity(self, max_size):
+        out = np.empty(32, np.uint8)
+        if lib().tko_bn254_get_root_of_unity(_u64(max_size), _p(out)) != 0:
+            raise ValueError("no root of unity of that order")
+        return out
+
+    def ntt(self, a, n, batch=1, columns_batch=False, inverse=False, coset_gen=None):
+        out = np.empty_like(a)
+        if lib().tko_bn254_ntt(_p(a), _sz(n), _sz(batch), int(columns_batch), int(inverse), _p(coset_gen), _p(out)) != 0:
+            raise ValueError("tko_bn254_ntt failed")
+        return out
+
+    def bintt(self, a, x_size, y_size, inverse=False, coset_x=None, coset_y=None):
+        out = np.empty_like(a)
+        if lib().tko_bn254_bintt(_p(a), _sz(x_size), _sz(y_size), int(inverse), _p(coset_x), _p(coset_y), _p(out)) != 0:
+            raise ValueError("tko_bn254_bintt failed")
+        return out
+
+    def dft_naive(self, a, n):
+        out = np.empty_like(a)
+        if lib().tko_bn254_dft_naive(_p(a), _sz(n), _p(out)) != 0:
+            raise ValueError("tko_bn254_dft_naive failed")
         return out
 
     def g1_generator(self):

@@ -187,6 +187,7 @@ static const u64 BNQ_MOD[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb
 static fq_t g1_CURVE_B;  /* curve constant 4 (Montgomery) */
 static bnq_t bn_CURVE_B; /* curve constant 3 (Montgomery) */
 static fr_t FR_ROOT32;   /* w_{2^32} = 5^((r-1)/2^32) (Montgomery) */
+static bnr_t BNR_ROOT28; /* BN254: w_{2^28} = 5^((r-1)/2^28) (Montgomery) */
 
 static void tko_init(void) {
     if (fr_ready && fq_ready) return;
@@ -204,6 +205,17 @@ static void tko_init(void) {
             memset(&three, 0, sizeof three);
             three.l[0] = 3;
             bnq_to_mont(&bn_CURVE_B, &three);
+            {
+                bnr_t five_b;
+                memset(&five_b, 0, sizeof five_b);
+                five_b.l[0] = 5;
+                bnr_to_mont(&five_b, &five_b);
+                u64 eb[4];
+                for (int i = 0; i < 4; i++) eb[i] = BNR_MOD[i];
+                eb[0] -= 1; /* r - 1, then >> 28 */
+                for (int i = 0; i < 4; i++) eb[i] = (eb[i] >> 28) | (i < 3 ? eb[i + 1] << 36 : 0);
+                bnr_pow(&BNR_ROOT28, &five_b, eb, 4);
+            }
             /* root of unity before publishing fr_ready */
             memcpy(fr_P.l, FR_MOD, sizeof fr_P.l);
             fr_init(FR_MOD);
@@ -378,139 +390,27 @@ static int log2_exact(size_t n) {
     while (((size_t)1 << l) < n) l++;
     return l;
 }
-static void fr_root_of_unity(int logn, fr_t *w) { /* w_{2^logn} */
-    *w = FR_ROOT32;
-    for (int i = logn; i < 32; i++) fr_sqr(w, w);
-}
-int tko_get_root_of_unity(uint64_t max_size, uint8_t *out) {
-    tko_init();
-    int l = 0;
-    while (l < 32 && ((u64)1 << l) < max_size) l++;
-    if (((u64)1 << l) < max_size) return -1;
-    fr_t w;
-    fr_root_of_unity(l, &w);
-    fr_store(out, &w);
-    return 0;
-}
+#define FS(x) fr_##x
+#define TKN(x) tko_##x
+#define NTT_ROOT FR_ROOT32
+#define NTT_TWO_ADICITY 32
+#include "tk_ntt.inc"
+#undef FS
+#undef TKN
+#undef NTT_ROOT
+#undef NTT_TWO_ADICITY
 
-/* in-place iterative radix-2 DIT on Montgomery values; tw[i] = w^i, i < n/2 */
-static void fr_ntt_inplace(fr_t *a, size_t n, int logn, const fr_t *tw) {
-    for (size_t i = 0, j = 0; i < n; i++) {
-        if (i < j) {
-            fr_t t = a[i];
-            a[i] = a[j];
-            a[j] = t;
-        }
-        size_t bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-    }
-    for (int s = 1; s <= logn; s++) {
-        size_t m = (size_t)1 << s, h = m >> 1, step = n / m;
-        for (size_t k = 0; k < n; k += m)
-            for (size_t j = 0; j < h; j++) {
-                fr_t t, u = a[k + j];
-                fr_mul(&t, &a[k + j + h], &tw[j * step]);
-                fr_add(&a[k + j], &u, &t);
-                fr_sub(&a[k + j + h], &u, &t);
-            }
-    }
-}
-
-int tko_ntt(const uint8_t *in, size_t n, size_t batch, int columns_batch, int inverse,
-            const uint8_t *coset_gen, uint8_t *out) {
-    tko_init();
-    int logn = log2_exact(n);
-    if (logn < 0 || logn > 32) return -1;
-    fr_t w, g, ginv, ninv;
-    fr_root_of_unity(logn, &w);
-    if (inverse) fr_inv(&w, &w);
-    int has_coset = 0;
-    if (coset_gen) {
-        fr_load(&g, coset_gen);
-        has_coset = !fr_eq(&g, &fr_R1);
-        fr_inv(&ginv, &g);
-    }
-    {
-        fr_t nn;
-        memset(&nn, 0, sizeof nn);
-        nn.l[0] = (u64)n;
-        fr_to_mont(&nn, &nn);
-        fr_inv(&ninv, &nn);
-    }
-    size_t half = n > 1 ? n / 2 : 1;
-    fr_t *tw = (fr_t *)malloc(sizeof(fr_t) * half);
-    fr_t *cs = has_coset ? (fr_t *)malloc(sizeof(fr_t) * n) : NULL; /* g^j or (g^-j)/n */
-    if (!tw || (has_coset && !cs)) return -2;
-    tw[0] = fr_R1;
-    for (size_t i = 1; i < half; i++) fr_mul(&tw[i], &tw[i - 1], &w);
-    if (has_coset) {
-        cs[0] = fr_R1;
-        for (size_t i = 1; i < n; i++) fr_mul(&cs[i], &cs[i - 1], inverse ? &ginv : &g);
-    }
-    size_t estride = columns_batch ? batch : 1, bstride = columns_batch ? 1 : n;
-#pragma omp parallel
-    {
-        fr_t *buf = (fr_t *)malloc(sizeof(fr_t) * n);
-#pragma omp for schedule(static)
-        for (size_t b = 0; b < batch; b++) {
-            for (size_t j = 0; j < n; j++) {
-                fr_load(&buf[j], in + 32 * (b * bstride + j * estride));
-                if (has_coset && !inverse) fr_mul(&buf[j], &buf[j], &cs[j]);
-            }
-            fr_ntt_inplace(buf, n, logn, tw);
-            for (size_t j = 0; j < n; j++) {
-                if (inverse) {
-                    fr_mul(&buf[j], &buf[j], &ninv);
-                    if (has_coset) fr_mul(&buf[j], &buf[j], &cs[j]);
-                }
-                fr_store(out + 32 * (b * bstride + j * estride), &buf[j]);
-            }
-        }
-        free(buf);
-    }
-    free(tw);
-    free(cs);
-    return 0;
-}
-
-int tko_bintt(const uint8_t *in, size_t x_size, size_t y_size, int inverse, const uint8_t *coset_x,
-              const uint8_t *coset_y, uint8_t *out) {
-    /* libs/src/bivariate_polynomial/mod.rs:1449-1476 */
-    if (x_size == 1) return tko_ntt(in, y_size, 1, 0, inverse, coset_y, out);
-    if (y_size == 1) return tko_ntt(in, x_size, 1, 0, inverse, coset_x, out);
-    uint8_t *tmp = (uint8_t *)malloc(32 * x_size * y_size);
-    if (!tmp) return -2;
-    int rc = tko_ntt(in, y_size, x_size, 0, inverse, coset_y, tmp);
-    if (!rc) rc = tko_ntt(tmp, x_size, y_size, 1, inverse, coset_x, out);
-    free(tmp);
-    return rc;
-}
-
-int tko_dft_naive(const uint8_t *in, size_t n, uint8_t *out) {
-    tko_init();
-    int logn = log2_exact(n);
-    if (logn < 0) return -1;
-    fr_t w;
-    fr_root_of_unity(logn, &w);
-    fr_t *x = (fr_t *)malloc(sizeof(fr_t) * n);
-    for (size_t j = 0; j < n; j++) fr_load(&x[j], in + 32 * j);
-    for (size_t k = 0; k < n; k++) {
-        fr_t wk, acc, cur = fr_R1;
-        u64 e = k;
-        fr_pow(&wk, &w, &e, 1);
-        memset(&acc, 0, sizeof acc);
-        for (size_t j = 0; j < n; j++) {
-            fr_t t;
-            fr_mul(&t, &x[j], &cur);
-            fr_add(&acc, &acc, &t);
-            fr_mul(&cur, &cur, &wk);
-        }
-        fr_store(out + 32 * k, &acc);
-    }
-    free(x);
-    return 0;
-}
+/* BN254 scalar field: two-adicity 28, root 5^((r-1)/2^28) (5 is the smallest quadratic non-residue; the generator both
+ * arkworks and ffjavascript use for this field).  No counterpart in the reference. */
+#define FS(x) bnr_##x
+#define TKN(x) tko_bn254_##x
+#define NTT_ROOT BNR_ROOT28
+#define NTT_TWO_ADICITY 28
+#include "tk_ntt.inc"
+#undef FS
+#undef TKN
+#undef NTT_ROOT
+#undef NTT_TWO_ADICITY
 
 /* ------------------------------------------------------------------------------------------
  * G1 groups: the curve-generic code lives in tk_g1.inc and is instantiated per curve.

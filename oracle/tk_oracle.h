@@ -101,6 +101,12 @@ void tko_bn254_fq_sub(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n
 void tko_bn254_fq_mul(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
 void tko_bn254_fq_inv(const uint8_t *a, uint8_t *out, size_t n);
 void tko_bn254_fr_random(uint64_t seed, size_t first, size_t n, uint8_t *out);
+/* NTT over the BN254 scalar field: same definitions as tko_ntt / tko_bintt / tko_dft_naive; w_{2^28} = 5^((r-1)/2^28) */
+int tko_bn254_get_root_of_unity(uint64_t max_size, uint8_t *out);
+int tko_bn254_ntt(const uint8_t *in, size_t n, size_t batch, int columns_batch, int inverse, const uint8_t *coset_gen, uint8_t *out);
+int tko_bn254_bintt(const uint8_t *in, size_t x_size, size_t y_size, int inverse, const uint8_t *coset_x, const uint8_t *coset_y,
+                    uint8_t *out);
+int tko_bn254_dft_naive(const uint8_t *in, size_t n, uint8_t *out);
 void tko_bn254_g1_generator(uint8_t *out64);
 int  tko_bn254_g1_on_curve(const uint8_t *p64);
 void tko_bn254_g1_add(const uint8_t *p64, const uint8_t *q64, uint8_t *out64);
