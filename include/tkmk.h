@@ -248,6 +248,17 @@ tkmk_error bn254_msm_precompute_bases(const tkmk_bn254_g1_affine *bases, int msm
                                       tkmk_bn254_g1_affine *output_bases);
 tkmk_error tkmk_bn254_msm_multi(const tkmk_bn254_msm_job *jobs, int n_jobs, const tkmk_msm_config *cfg,
                                 tkmk_bn254_g1_projective *results);
+/* BN254 scalar-field NTT: the twins of bls12_381_get_root_of_unity / _ntt_init_domain / _ntt_release_domain / _ntt and
+ * tkmk_bintt (declared below with their semantics); own process-global domain; two-adicity 28,
+ * w_{2^28} = 5^((r-1)/2^28).  No reference call site (BASELINE.json configs[0] names the transform). */
+tkmk_error bn254_get_root_of_unity(uint64_t max_size, tkmk_bn254_fr *rou_out);
+tkmk_error bn254_ntt_init_domain(const tkmk_bn254_fr *primitive_root, const tkmk_ntt_init_domain_config *cfg);
+tkmk_error bn254_ntt_release_domain(void);
+tkmk_error bn254_ntt(const tkmk_bn254_fr *input, int size, tkmk_ntt_dir dir, const tkmk_ntt_config *cfg,   /* cfg->coset_gen: 8 limbs */
+                     tkmk_bn254_fr *output);
+tkmk_error tkmk_bn254_bintt(const tkmk_bn254_fr *input, size_t x_size, size_t y_size, tkmk_ntt_dir dir,
+                            const tkmk_bn254_fr *coset_x, const tkmk_bn254_fr *coset_y, bool on_device, tkmk_stream stream,
+                            tkmk_bn254_fr *output);
 /* input generation twins of tkmk_fr_random_device / tkmk_g1_batch_scalar_mul_device (below) */
 tkmk_error tkmk_bn254_fr_random_device(uint64_t seed, uint64_t first, uint64_t n, tkmk_bn254_fr *out_dev, tkmk_stream s);
 tkmk_error tkmk_bn254_g1_batch_scalar_mul_device(const tkmk_bn254_fr *scalars_dev, const tkmk_bn254_g1_affine *base_host,

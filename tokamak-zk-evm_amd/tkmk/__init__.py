@@ -82,7 +82,8 @@ SYMBOLS = [
     "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
     "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
     "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
-    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm", "bls12_381_msm_precompute_bases", "bn254_msm_precompute_bases", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "tkmk_bn254_fr_random_device",
+    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_msm_default_config", "bls12_381_msm", "bls12_381_msm_precompute_bases", "bn254_msm_precompute_bases", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "bn254_get_root_of_unity", "bn254_ntt_init_domain", "bn254_ntt_release_domain",
+    "bn254_ntt", "tkmk_bn254_bintt", "tkmk_bn254_fr_random_device",
     "tkmk_bn254_g1_batch_scalar_mul_device",
     "tkmk_ntt_default_config", "bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain",
     "bls12_381_ntt", "tkmk_bintt", "tkmk_vecops_default_config", "bls12_381_vector_add", "bls12_381_vector_sub",
@@ -194,37 +195,46 @@ def available_memory():
 
 
 # ---- NTT (reference: libs/src/bivariate_polynomial/mod.rs:33-55, 1422-1478) ----
-def get_root_of_unity(max_size):
+# curve -> (get_root_of_unity, init_domain, release_domain, ntt, bintt) symbols
+_NTT_SYMS = {
+    "bls12_381": ("bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain", "bls12_381_ntt", "tkmk_bintt"),
+    "bn254": ("bn254_get_root_of_unity", "bn254_ntt_init_domain", "bn254_ntt_release_domain", "bn254_ntt", "tkmk_bn254_bintt"),
+}
+
+
+def get_root_of_unity(max_size, curve="bls12_381"):
+    sym = _NTT_SYMS[curve][0]
     out = np.empty(32, np.uint8)
-    _check(lib().bls12_381_get_root_of_unity(ctypes.c_uint64(max_size), _p(out)), "bls12_381_get_root_of_unity")
+    _check(getattr(lib(), sym)(ctypes.c_uint64(max_size), _p(out)), sym)
     return out
 
 
-_domain_size = None
+_domain_size = {}
 
 
-def init_ntt_domain_for_size(size):
-    """grow-only global domain, like init_ntt_domain_for_size (bivariate_polynomial/mod.rs:33-55)"""
-    global _domain_size
+def init_ntt_domain_for_size(size, curve="bls12_381"):
+    """grow-only global domain (one per scalar field), like init_ntt_domain_for_size (bivariate_polynomial/mod.rs:33-55)"""
     if size <= 0 or size & (size - 1):
         raise ValueError("NTT domain size must be a non-zero power of two")
-    if _domain_size is not None and _domain_size >= size:
+    have = _domain_size.get(curve)
+    if have is not None and have >= size:
         return
-    if _domain_size is not None:
-        release_ntt_domain()
-    root = get_root_of_unity(size)
+    if have is not None:
+        release_ntt_domain(curve)
+    root = get_root_of_unity(size, curve)
     cfg = NTTInitDomainConfig(None, False, None)
-    _check(lib().bls12_381_ntt_init_domain(_p(root), ctypes.byref(cfg)), "bls12_381_ntt_init_domain")
-    _domain_size = size
+    sym = _NTT_SYMS[curve][1]
+    _check(getattr(lib(), sym)(_p(root), ctypes.byref(cfg)), sym)
+    _domain_size[curve] = size
 
 
-def release_ntt_domain():
-    global _domain_size
-    _check(lib().bls12_381_ntt_release_domain(), "bls12_381_ntt_release_domain")
-    _domain_size = None
+def release_ntt_domain(curve="bls12_381"):
+    sym = _NTT_SYMS[curve][2]
+    _check(getattr(lib(), sym)(), sym)
+    _domain_size.pop(curve, None)
 
 
-def ntt(a, n, batch=1, columns_batch=False, inverse=False, coset_gen=None, out=None, stream=None):
+def ntt(a, n, batch=1, columns_batch=False, inverse=False, coset_gen=None, out=None, stream=None, curve="bls12_381"):
     cfg = lib().tkmk_ntt_default_config()
     cfg.batch_size = batch
     cfg.columns_batch = columns_batch
@@ -234,16 +244,18 @@ def ntt(a, n, batch=1, columns_batch=False, inverse=False, coset_gen=None, out=N
     out = _out_like(a, 32 * n * batch, out)
     cfg.are_inputs_on_device = _on_dev(a)
     cfg.are_outputs_on_device = _on_dev(out)
-    _check(lib().bls12_381_ntt(_p(a), int(n), 1 if inverse else 0, ctypes.byref(cfg), _p(out)), "bls12_381_ntt")
+    sym = _NTT_SYMS[curve][3]
+    _check(getattr(lib(), sym)(_p(a), int(n), 1 if inverse else 0, ctypes.byref(cfg), _p(out)), sym)
     return out
 
 
-def bintt(a, x_size, y_size, inverse=False, coset_x=None, coset_y=None, out=None, stream=None):
+def bintt(a, x_size, y_size, inverse=False, coset_x=None, coset_y=None, out=None, stream=None, curve="bls12_381"):
     out = _out_like(a, 32 * x_size * y_size, out)
     if _on_dev(a) != _on_dev(out):
         raise ValueError("tkmk_bintt takes both buffers on the same side")
-    _check(lib().tkmk_bintt(_p(a), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size), 1 if inverse else 0, _p(coset_x),
-                            _p(coset_y), _on_dev(a), ctypes.c_void_p(stream), _p(out)), "tkmk_bintt")
+    sym = _NTT_SYMS[curve][4]
+    _check(getattr(lib(), sym)(_p(a), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size), 1 if inverse else 0, _p(coset_x),
+                               _p(coset_y), _on_dev(a), ctypes.c_void_p(stream), _p(out)), sym)
     return out
 
 
