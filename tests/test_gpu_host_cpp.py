@@ -101,3 +101,110 @@ def test_cpp_host_mirror_against_oracle(gpu, oracle, tmp_path):
     assert (many[:96] == oracle.g1_scalar_mul(val, g)).all() and not many[96:192].any()
     assert (many[192:] == oracle.g1_scalar_mul(valb, g)).all()
     assert struct.unpack("<I", rec[99])[0] == 7          # the three misuse cases raised tkmk::Error
+
+
+def test_cpp_protocol_glue(gpu, oracle, tmp_path):
+    """tokamak-zk-evm_amd/host/tkmk_protocol.hpp (Keccak transcript, Solidity formatting, TKCRS001 reader, binding commitments,
+    preprocess round) through tests/host_cpp/protocol_driver.cpp: Keccak known answers, and every other output equal to the
+    Python mirrors (tkmk/transcript.py, proofio.py, crs.py, binding.py, preprocess.py), which are themselves checked against
+    the oracle in their own tests."""
+    import random
+    from tkmk import binding, crs, proofio
+    from tkmk.preprocess import Preprocess
+    from tkmk.sigma import Sigma1
+    from tkmk.transcript import TranscriptManager
+    drv = os.path.join(HERE, "host_cpp", "protocol_driver")
+    pkg = os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd")
+    src = drv + ".cpp"
+    hdrs = [os.path.join(pkg, "host", h) for h in ("tkmk_host.hpp", "tkmk_protocol.hpp")]
+    if not os.path.exists(drv) or os.path.getmtime(drv) < max(os.path.getmtime(p) for p in [src] + hdrs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(pkg, "host"), src, "-o", drv, "-L" + pkg, "-ltkmk_hip",
+                        "-Wl,-rpath," + pkg], check=True)
+    pins = json.load(open(os.path.join(HERE, "golden", "pins.json")))
+    R = oracle.R_MOD
+    rnd = random.Random(21)
+    tx, ty = int(pins["tau_x"], 16), int(pins["tau_y"], 16)
+    g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
+    sp = {"l": 6, "l_free": 4, "l_user": 3, "l_user_out": 1, "l_D": 14, "m_D": 22, "n": 8, "s_max": 4, "s_D": 2}
+    m_i, s_max = sp["l_D"] - sp["l"], sp["s_max"]
+    rs_x, rs_y = max(2 * sp["n"], 2 * m_i), 2 * s_max
+
+    def pts(scalars):
+        return gpu.g1_batch_scalar_mul_device(gpu.DeviceBuffer.from_host(oracle.to_bytes(scalars, 32)), g, len(scalars)).to_host()
+
+    rand = lambda k: [rnd.randrange(1, R) for _ in range(k)]   # noqa: E731
+    sections = {"g1": pts([1, tx, ty, 5, 7, 11]), "g2": bytes(10 * 192),
+                "xy_powers": pts([pow(tx, i, R) * pow(ty, j, R) % R for i in range(rs_x) for j in range(rs_y)]),
+                "gamma_inv_o_inst": pts(rand(sp["l"])), "eta_inv_li_o_inter_alpha4_kj": pts(rand(m_i * s_max)),
+                "delta_inv_li_o_prv": pts(rand((sp["m_D"] - sp["l_D"]) * s_max)), "delta_inv_alphak_xh_tx": pts(rand(9)),
+                "delta_inv_alpha4_xj_tx": pts(rand(2)), "delta_inv_alphak_yi_ty": pts(rand(12))}
+    payload = crs.build_payload(sections)
+    names = ["bufferPubOut", "bufferPubIn", "bufferBlockIn", "bufferEVMIn", "ADD"]
+    infos = [
+        {"id": 0, "name": names[0], "Nwires": 4, "Out_idx": [1, 2], "In_idx": [3, 1], "flattenMap": [6, 0, 1, 7]},
+        {"id": 1, "name": names[1], "Nwires": 4, "Out_idx": [1, 1], "In_idx": [2, 2], "flattenMap": [6, 8, 2, 3]},
+        {"id": 2, "name": names[2], "Nwires": 3, "Out_idx": [1, 1], "In_idx": [2, 1], "flattenMap": [6, 9, 4]},
+        {"id": 3, "name": names[4], "Nwires": 7, "Out_idx": [1, 1], "In_idx": [2, 2], "flattenMap": [6, 11, 12, 13, 14, 15, 16]},
+    ]
+    name_code = {n: i for i, n in enumerate(names)}
+    pls = []
+    for sid in (0, 1, 2, 3):
+        vals = [rnd.randrange(R) for _ in range(infos[sid]["Nwires"])]
+        vals[0] = 1
+        pls.append({"subcircuitId": sid, "variables": ["0x%x" % v for v in vals]})
+    a_fn = [rnd.randrange(R) for _ in range(sp["l"] - sp["l_free"])]
+    perm = [{"row": 1, "col": 2, "X": 5, "Y": 0}, {"row": 5, "col": 0, "X": 1, "Y": 2}, {"row": 7, "col": 3, "X": 7, "Y": 3}]
+    inp, outp = tmp_path / "pin.bin", tmp_path / "pout.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<10I", sp["l"], sp["l_free"], sp["l_D"], sp["m_D"], sp["n"], s_max, len(perm), len(a_fn), rs_x, rs_y))
+        for p in perm:
+            f.write(struct.pack("<4I", p["row"], p["col"], p["X"], p["Y"]))
+        f.write(oracle.to_bytes(a_fn, 32).tobytes())
+        f.write(struct.pack("<Q", len(payload)))
+        f.write(payload)
+        f.write(struct.pack("<I", len(infos)))
+        for e in infos:
+            f.write(struct.pack("<6I", name_code[e["name"]], e["Nwires"], *e["Out_idx"], *e["In_idx"]))
+            f.write(struct.pack("<%dI" % e["Nwires"], *e["flattenMap"]))
+        f.write(struct.pack("<I", len(pls)))
+        for pl in pls:
+            f.write(struct.pack("<2I", pl["subcircuitId"], len(pl["variables"])))
+            f.write(oracle.to_bytes([int(v, 16) for v in pl["variables"]], 32).tobytes())
+    gpu.release_scratch()
+    subprocess.run([drv, str(inp), str(outp)], check=True, timeout=300)
+    rec = _records(str(outp))
+    # Keccak-256 known answers
+    assert rec[1].hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert rec[2].hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    from tkmk.transcript import keccak256
+    assert rec[3] == keccak256(b"a" * 300)
+    # CRS payload sections
+    sec = crs.parse_payload(payload)
+    assert list(struct.unpack("<9Q", rec[10])) == [sec[n].size for n in crs.SECTION_NAMES]
+    assert rec[11] == bytes(sec["gamma_inv_o_inst"])
+    # preprocess round == Python mirror (which is checked against the commit identity in test_gpu_preprocess.py)
+    sigma1, tables = crs.load_sigma1(sec, sp)
+    instance = {"a_pub_user": [], "a_pub_block": [], "a_pub_function": ["0x%x" % a for a in a_fn]}
+    py = Preprocess.gen(sigma1, tables["gamma_inv_o_inst"], perm, instance, sp)
+    assert rec[20] == bytes(py.s0) and rec[21] == bytes(py.s1) and rec[22] == bytes(py.O_pub_fix)
+    assert json.loads(rec[23].decode()) == py.convert_format_for_solidity_verifier()
+    assert struct.unpack("<I", rec[24])[0] == 1
+    # binding commitments == Python mirror
+    o_free = binding.encode_O_pub_free(tables["gamma_inv_o_inst"], pls, infos, sp)
+    o_mid = binding.encode_O_mid_no_zk(tables["eta_inv_li_o_inter_alpha4_kj"], pls, infos, sp)
+    o_prv = binding.encode_O_prv_no_zk(tables["delta_inv_li_o_prv"], pls, infos, sp)
+    assert rec[30] == bytes(o_free) and rec[31] == bytes(o_mid) and rec[32] == bytes(o_prv)
+    # transcript == Python mirror
+    tm = TranscriptManager()
+    tm.add_proof0(py.s0, py.s1, py.O_pub_fix, o_free, o_mid, o_prv)
+    th = tm.get_thetas()
+    assert rec[40] == oracle.to_bytes(th, 32).tobytes()
+    tm.add_proof1(o_mid)
+    k0 = tm.get_kappa0()
+    assert rec[41] == k0.to_bytes(32, "little")
+    tm.add_proof2(o_prv, py.s0)
+    chi, zeta = tm.get_chi_zeta()
+    assert rec[42] == chi.to_bytes(32, "little") and rec[43] == zeta.to_bytes(32, "little")
+    tm.add_proof3(th[0], th[1], th[2], k0)
+    assert rec[44] == tm.get_kappa1().to_bytes(32, "little")
+    assert struct.unpack("<I", rec[99])[0] == 7
