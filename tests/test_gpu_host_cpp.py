@@ -208,3 +208,67 @@ def test_cpp_protocol_glue(gpu, oracle, tmp_path):
     tm.add_proof3(th[0], th[1], th[2], k0)
     assert rec[44] == tm.get_kappa1().to_bytes(32, "little")
     assert struct.unpack("<I", rec[99])[0] == 7
+
+
+def test_cpp_witness_side(gpu, oracle, tmp_path):
+    """tokamak-zk-evm_amd/host/tkmk_witness.hpp (iden3 .r1cs reader, read_R1CS_gen_uvwXY, gen_bXY, gen_a_free_X) through
+    tests/host_cpp/witness_driver.cpp on the committed .r1cs data fixtures: header fields and the prime equal the Python
+    reader's, u / v / w / b / a_free polynomials equal the Python mirrors' (checked against the oracle in test_gpu_poly.py)."""
+    import random
+    from tkmk import r1cs, witness
+    drv = os.path.join(HERE, "host_cpp", "witness_driver")
+    pkg = os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd")
+    src = drv + ".cpp"
+    hdrs = [os.path.join(pkg, "host", h) for h in ("tkmk_host.hpp", "tkmk_protocol.hpp", "tkmk_witness.hpp")]
+    if not os.path.exists(drv) or os.path.getmtime(drv) < max(os.path.getmtime(p) for p in [src] + hdrs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(pkg, "host"), src, "-o", drv, "-L" + pkg, "-ltkmk_hip",
+                        "-Wl,-rpath," + pkg], check=True)
+    qap = os.path.join(HERE, "golden", "qap")
+    all_infos = {e["id"]: e for e in json.load(open(os.path.join(qap, "subcircuitInfo.json")))}
+    sp = dict(json.load(open(os.path.join(qap, "setupParams.json"))), n=64, s_max=8)
+    ids = [1, 2, 12]                                            # the committed fixtures
+    infos = [all_infos[i] for i in ids]                          # driver-side subcircuit ids are positions in this list
+    rnd = random.Random(9)
+    R = oracle.R_MOD
+    order = [0, 2, 1, 0, 2]
+    pls_cpp = [(k, [rnd.randrange(R) for _ in range(infos[k]["Nwires"])]) for k in order]
+    pls_cpp[1][1][0] = 1
+    placements = [{"subcircuitId": ids[k], "variables": ["0x%x" % v for v in vals]} for k, vals in pls_cpp]
+    l_free, l_user = sp["l_free"], sp["l_user"]
+    a_user = [rnd.randrange(R) for _ in range(l_user)]
+    a_block = [rnd.randrange(R) for _ in range(l_free - l_user)]
+    inp, outp = tmp_path / "win.bin", tmp_path / "wout.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<7I", sp["l"], l_free, l_user, sp["l_D"], sp["m_D"], sp["n"], sp["s_max"]))
+        f.write(struct.pack("<I", len(infos)))
+        for e in infos:
+            f.write(struct.pack("<7I", e["id"], e["Nwires"], e["Nconsts"], *e["Out_idx"], *e["In_idx"]))
+            f.write(struct.pack("<%dI" % e["Nwires"], *e["flattenMap"]))
+        f.write(struct.pack("<I", len(pls_cpp)))
+        for k, vals in pls_cpp:
+            f.write(struct.pack("<2I", k, len(vals)))
+            f.write(oracle.to_bytes(vals, 32).tobytes())
+        for vec in (a_user, a_block):
+            f.write(struct.pack("<I", len(vec)))
+            f.write(oracle.to_bytes(vec, 32).tobytes())
+    gpu.release_scratch()
+    subprocess.run([drv, str(inp), str(outp), os.path.join(qap, "r1cs")], check=True, timeout=300)
+    rec = _records(str(outp))
+    for k, e in enumerate(infos):
+        b = r1cs.R1csBinary.read(os.path.join(qap, "r1cs", "subcircuit%d.r1cs" % e["id"]))
+        assert struct.unpack("<3I", rec[100 + k]) == (b.n_wires, b.n_constraints, b.field_size)
+        assert int.from_bytes(rec[200 + k], "little") == b.prime() == R
+        s = r1cs.SubcircuitR1CS.from_r1cs_sparse_only(os.path.join(qap, "r1cs", "subcircuit%d.r1cs" % e["id"]), sp, e)
+        assert struct.unpack("<3I", rec[300 + k]) == tuple(int(s.csr[m][1].size) for m in range(3))
+    gpu.init_ntt_domain_for_size(1 << 16)
+    u, v, w = r1cs.read_R1CS_gen_uvwXY(qap, placements, list(all_infos.values()), sp)
+    for tag, poly in ((10, u), (12, v), (14, w)):
+        xs, ys, _, _, co = _poly(rec, tag)
+        assert (xs, ys) == (sp["n"], sp["s_max"]) and (co == poly.copy_coeffs()).all()
+    bpy = witness.gen_bXY(placements, list(all_infos.values()), sp)
+    xs, ys, _, _, co = _poly(rec, 20)
+    assert (xs, ys) == (bpy.x_size, bpy.y_size) and (co == bpy.copy_coeffs()).all()
+    apy = witness.gen_a_free_X({"a_pub_user": ["0x%x" % x for x in a_user], "a_pub_block": ["0x%x" % x for x in a_block]}, sp)
+    xs, ys, _, _, co = _poly(rec, 22)
+    assert (xs, ys) == (apy.x_size, apy.y_size) and (co == apy.copy_coeffs()).all()
+    assert struct.unpack("<I", rec[99])[0] == 7
