@@ -101,6 +101,18 @@ def test_preprocess_cli_files_in_files_out(gpu, oracle, tmp_path):
     subprocess.run([sys.executable, "-m", "tkmk.cli", "preprocess", "--crs", str(tmp_path / "crs"), "--synthesizer-stat", str(tmp_path / "synth"),
                     "--output", str(tmp_path / "out"), "--subcircuit-library", str(tmp_path / "lib")], check=True, env=env, timeout=300)
     got = proofio.recover_preprocess(json.load(open(tmp_path / "out" / "preprocess.json")))
+    # the native binary (tokamak-zk-evm_amd/host/preprocess_main.cpp) with the same flags writes the same file
+    native = os.path.join(root, "tokamak-zk-evm_amd", "bin", "preprocess")
+    if os.path.exists(native):
+        (tmp_path / "out2").mkdir()
+        subprocess.run([native, "--crs", str(tmp_path / "crs"), "--synthesizer-stat", str(tmp_path / "synth"), "--output", str(tmp_path / "out2"),
+                        "--subcircuit-library", str(tmp_path / "lib")], check=True, timeout=300)
+        assert json.load(open(tmp_path / "out2" / "preprocess.json")) == json.load(open(tmp_path / "out" / "preprocess.json"))
+        r2 = subprocess.run([native, "--crs", str(tmp_path / "lib"), "--synthesizer-stat", str(tmp_path / "synth"), "--output", str(tmp_path / "out2"),
+                             "--subcircuit-library", str(tmp_path / "lib")], capture_output=True, timeout=300)
+        assert r2.returncode != 0 and b"No reference string is found" in r2.stderr
+    else:
+        pytest.fail("native preprocess binary is not built (run __graft_entry__.build())")
     dot = sum(a * k for a, k in zip(a_fn, ks[sp["l_free"]:])) % R
     assert (got["O_pub_fix"] == oracle.g1_scalar_mul(oracle.to_bytes([dot], 32), g)).all()
     wx = oracle.to_ints(oracle.root_of_unity(m_i), 32)[0]
