@@ -28,6 +28,12 @@ if PKG not in sys.path:
 def tkmk():
     """The product: ctypes binding over tokamak-zk-evm_amd/libtkmk_hip.so (C ABI in include/tkmk.h)."""
     import tkmk as t
+    if not os.path.exists(t.LIB_PATH):      # normally built beforehand by __graft_entry__.build(); same recipe if it was not
+        import shutil
+        if shutil.which("hipcc") is None:
+            pytest.fail("libtkmk_hip.so is not built and hipcc is not available")
+        import __graft_entry__
+        __graft_entry__.build()
     t.lib()
     return t
 
