@@ -134,7 +134,7 @@ def test_div_by_vanishing_opt(P, gpu, oracle, xs, ys, c, d):
         P.from_coeffs(oracle.fr_random(1, 64), 8, 8).div_by_vanishing_opt(3, 4)
 
 
-@pytest.mark.parametrize("xs,ys", [(1, 1), (1, 8), (8, 1), (2, 2), (64, 32), (4096, 256)])
+@pytest.mark.parametrize("xs,ys", [(1, 1), (1, 8), (8, 1), (2, 2), (64, 32), (4096, 256), (128, 1024), (16384, 4), (8192, 16), (32, 512)])
 def test_div_by_ruffini(P, gpu, oracle, xs, ys):
     m = oracle.fr_random(400 + xs + ys, xs * ys)
     x, y = oracle.fr_random(41, 1), oracle.fr_random(42, 1)

@@ -171,16 +171,26 @@ __global__ __launch_bounds__(256) void k_ruffini_local(const fr_t *__restrict__ 
     for (uint32_t k = hi; k-- > lo;) h = Fr::add(Fr::canon(tk_load(p + (uint64_t)k * ys + j)), Fr::mul(h, xm));
     tk_store(H + (uint64_t)sgm * ys + j, h);
 }
-// carry[s][j] = B at the first row above segment s;  xLm = x^L (Montgomery)
+// carry[s][j] = B at the first row above segment s = sum_{u > s} H[u][j] * (x^L)^(u - s - 1).  One workgroup per column j,
+// one lane per segment (S <= 256): geometric suffix scan in LDS, log2(S) product steps instead of a serial walk over the
+// segments (which, with only y_size lanes alive, was most of the division's run time).  xLm = x^L (Montgomery)
 __global__ __launch_bounds__(256) void k_ruffini_carry(const fr_t *__restrict__ H, uint32_t S, uint32_t ys, fr_t xLm,
                                                       fr_t *__restrict__ carry) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ys) return;
-    fr_t run = Fr::zero();
-    for (uint32_t sgm = S; sgm-- > 0;) {
-        tk_store(carry + (uint64_t)sgm * ys + j, run);
-        run = Fr::add(tk_load(H + (uint64_t)sgm * ys + j), Fr::mul(run, xLm));
+    __shared__ fr_t sh[256];
+    const uint32_t j = blockIdx.x, t = threadIdx.x;
+    fr_t v = t < S ? tk_load(H + (uint64_t)t * ys + j) : Fr::zero();
+    sh[t] = v;
+    fr_t pw = xLm;
+    for (uint32_t st = 1; st < 256; st <<= 1) {
+        __syncthreads();
+        fr_t o = t + st < 256 ? sh[t + st] : Fr::zero();
+        __syncthreads();
+        v = Fr::add(v, Fr::mul(o, pw));   // plain + plain * mont
+        sh[t] = v;
+        pw = Fr::sqr(pw);
     }
+    __syncthreads();
+    if (t < S) tk_store(carry + (uint64_t)t * ys + j, t + 1 < 256 ? sh[t + 1] : Fr::zero());
 }
 __global__ __launch_bounds__(256) void k_ruffini_apply(const fr_t *__restrict__ p, const fr_t *__restrict__ carry, uint32_t xs, uint32_t ys,
                                                       fr_t xm, uint32_t L, fr_t *__restrict__ qx, fr_t *__restrict__ rx) {
@@ -195,22 +205,35 @@ __global__ __launch_bounds__(256) void k_ruffini_apply(const fr_t *__restrict__ 
         else tk_store(rx + j, b);
     }
 }
-// single lane: univariate division of r (length n) by (Y - y); out: q (length n, top = 0), rem
-__global__ void k_ruffini_y(const fr_t *__restrict__ r, uint32_t n, fr_t ym, fr_t *__restrict__ q, fr_t *__restrict__ rem) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    if (n < 2) {
-        tk_store(q, Fr::zero());
-        tk_store(rem, tk_load(r));
-        return;
+// univariate division of r (length n) by (Y - y): b_k = r[k] + y b_{k+1}, b_n = 0; q[k-1] = b_k (k >= 1), q[n-1] = 0, rem = b_0.
+// One workgroup: every lane takes a run of Ls coefficients (local Horner), the runs are chained by a geometric suffix
+// scan in LDS, then every lane replays its run with the incoming carry.  (A single lane walking all n coefficients was
+// a 512-step dependent chain of field products on an otherwise idle GPU.)
+__global__ __launch_bounds__(256) void k_ruffini_y(const fr_t *__restrict__ r, uint32_t n, fr_t ym, fr_t *__restrict__ q, fr_t *__restrict__ rem) {
+    __shared__ fr_t sh[256];
+    const uint32_t t = threadIdx.x;
+    const uint32_t Ls = (n + 255) / 256;
+    const uint32_t lo = t * Ls < n ? t * Ls : n, hi = lo + Ls < n ? lo + Ls : n;
+    fr_t h = Fr::zero();
+    for (uint32_t k = hi; k-- > lo;) h = Fr::add(Fr::canon(tk_load(r + k)), Fr::mul(h, ym));
+    sh[t] = h;
+    fr_t pw = Fr::pow_u64(ym, Ls), v = h;
+    for (uint32_t st = 1; st < 256; st <<= 1) {
+        __syncthreads();
+        fr_t o = t + st < 256 ? sh[t + st] : Fr::zero();
+        __syncthreads();
+        v = Fr::add(v, Fr::mul(o, pw));
+        sh[t] = v;
+        pw = Fr::sqr(pw);
     }
-    fr_t b = tk_load(r + n - 1);
-    tk_store(q + n - 1, Fr::zero());
-    tk_store(q + n - 2, b);
-    for (uint32_t i = n - 2; i >= 1; i--) {
-        b = Fr::add(tk_load(r + i), Fr::mul(b, ym));
-        tk_store(q + i - 1, b);
+    __syncthreads();
+    fr_t b = t + 1 < 256 ? sh[t + 1] : Fr::zero();   // value of the recurrence just above this lane's run
+    if (t == 0) tk_store(q + n - 1, Fr::zero());
+    for (uint32_t k = hi; k-- > lo;) {
+        b = Fr::add(Fr::canon(tk_load(r + k)), Fr::mul(b, ym));
+        if (k >= 1) tk_store(q + k - 1, b);
+        else tk_store(rem, b);
     }
-    tk_store(rem, Fr::add(tk_load(r), Fr::mul(b, ym)));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -401,18 +424,21 @@ TK_API tkmk_error tkmk_poly_div_by_ruffini(const tkmk_fr *p_dev, uint32_t x_size
         TK_HIP(hipMemsetAsync(q_x_dev, 0, (size_t)y_size * sizeof(fr_t), s));
         TK_HIP(hipMemcpyAsync(rx.p, p_dev, (size_t)y_size * sizeof(fr_t), hipMemcpyDeviceToDevice, s));
     } else {
-        const uint32_t L = x_size >= 128 ? 64 : x_size, S = (x_size + L - 1) / L;
+        // S <= 256 segments (one lane each in k_ruffini_carry) of L rows: 32-row runs up to 8192 rows, longer above
+        uint32_t L = x_size >= 64 ? 32 : x_size;
+        while ((x_size + L - 1) / L > 256) L *= 2;
+        const uint32_t S = (x_size + L - 1) / L;
         tk_scratch H, carry;
         TK_TRY(H.alloc((size_t)S * y_size * sizeof(fr_t), s));
         TK_TRY(carry.alloc((size_t)S * y_size * sizeof(fr_t), s));
         dim3 grid(tk_div_up(y_size, 256), S);
         hipLaunchKernelGGL(k_ruffini_local, grid, 256, 0, s, (const fr_t *)p_dev, x_size, y_size, xm, L, H.as<fr_t>());
-        hipLaunchKernelGGL(k_ruffini_carry, tk_div_up(y_size, 256), 256, 0, s, (const fr_t *)H.p, S, y_size, Fr::pow_u64(xm, L),
+        hipLaunchKernelGGL(k_ruffini_carry, y_size, 256, 0, s, (const fr_t *)H.p, S, y_size, Fr::pow_u64(xm, L),
                            carry.as<fr_t>());
         hipLaunchKernelGGL(k_ruffini_apply, grid, 256, 0, s, (const fr_t *)p_dev, (const fr_t *)carry.p, x_size, y_size, xm, L,
                            (fr_t *)q_x_dev, rx.as<fr_t>());
     }
-    hipLaunchKernelGGL(k_ruffini_y, 1, 64, 0, s, (const fr_t *)rx.p, y_size, Fr::to_mont(fr_in(y)), (fr_t *)q_y_dev, rem.as<fr_t>());
+    hipLaunchKernelGGL(k_ruffini_y, 1, 256, 0, s, (const fr_t *)rx.p, y_size, Fr::to_mont(fr_in(y)), (fr_t *)q_y_dev, rem.as<fr_t>());
     TK_HIP(hipGetLastError());
     TK_HIP(hipMemcpyAsync(r_host, rem.p, sizeof(fr_t), hipMemcpyDeviceToHost, s));
     TK_HIP(hipStreamSynchronize(s));
