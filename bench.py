@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--no-bn254", action="store_true", help="skip the secondary BN254 G1 MSM measurement (BASELINE.json configs[1] as worded)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --dist-backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal only: initialise the process group and run the partial-result exchange even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,7 +65,7 @@ def main():
     torch.cuda.set_device(dev)
     tkmk.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -91,6 +93,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.force_dist and world == 1:   # one-rank rehearsal of the exchange msm_sharded performs for N > 1
+        part = tkmk.msm(scalars, bases)
+        assert (sharding.combine_partials(tkmk, sharding.gather_partials(dist, part, comm_device)) == part).all()
     tkmk.profile_enable(True)
     tkmk.profile_reset()
     barrier()
