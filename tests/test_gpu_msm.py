@@ -293,3 +293,32 @@ def test_msm_precomputed_bases_large_identity(gpu, oracle):
     kv, sv = oracle.to_ints(k.to_host(), 32), oracle.to_ints(sd.to_host(), 32)
     dot = sum(a * b for a, b in zip(kv, sv)) % oracle.R_MOD
     assert (got == oracle.g1_scalar_mul(oracle.to_bytes([dot], 32), g.copy())).all()
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_msm_montgomery_form_inputs(gpu, oracle, curve):
+    # MSMConfig::are_scalars_montgomery_form / are_points_montgomery_form (ICICLE: x * 2^(32 limbs) mod modulus): the same
+    # MSM with either or both operands handed over in Montgomery form, also through the precompute entry
+    o = oracle if curve == "bls12_381" else oracle.bn254
+    fq_bytes = 48 if curve == "bls12_381" else 32
+    aff = 2 * fq_bytes
+    n = 500
+    s = o.fr_random(801, n)
+    p = o.g1_random_bases(802, n)
+    p[aff * 3:aff * 4] = 0                                                   # infinity stays (0, 0) in either form
+    want = o.g1_msm(s, p)
+    R_MOD, P_MOD = o.R_MOD, o.P_MOD
+    sm = oracle.to_bytes([(x << 256) % R_MOD for x in oracle.to_ints(s, 32)], 32)
+    pm = oracle.to_bytes([(x << (8 * fq_bytes)) % P_MOD for x in oracle.to_ints(p, fq_bytes)], fq_bytes)
+
+    def run(sc, pt, **kw):
+        return gpu.projective_to_affine_bytes(gpu.msm(sc, pt, curve=curve, **kw), curve=curve)
+
+    assert (run(sm, p, scalars_montgomery=True) == want).all()
+    assert (run(s, pm, points_montgomery=True) == want).all()
+    assert (run(sm, pm, scalars_montgomery=True, points_montgomery=True) == want).all()
+    table = gpu.msm_precompute_bases(pm, n, 4, curve=curve, points_montgomery=True)   # Montgomery bases into the precompute table
+    assert (run(sm, table, msm_size=n, precompute_factor=4, scalars_montgomery=True) == want).all()
+    one = oracle.to_bytes([(1 << 256) % R_MOD], 32)                              # Montgomery 1: [1]P through the size-1 path
+    got1 = run(one, pm[:aff].copy(), msm_size=1, scalars_montgomery=True, points_montgomery=True)
+    assert (got1 == p[:aff]).all()

@@ -361,13 +361,14 @@ def msm_windows(n, c=0, bitsize=0, curve="bls12_381"):
     return bits // c + 1
 
 
-def msm_precompute_bases(bases, n, factor, c=0, bitsize=0, curve="bls12_381"):
+def msm_precompute_bases(bases, n, factor, c=0, bitsize=0, curve="bls12_381", points_montgomery=False):
     """-> DeviceBuffer with the n * min(factor, windows) expanded points (converted form) for msm(..., precompute_factor=factor)"""
     sym, aff = _CURVES[curve][5], _CURVES[curve][4]
     cfg = lib().tkmk_msm_default_config()
     cfg.precompute_factor = factor
     cfg.c, cfg.bitsize = c, bitsize
     cfg.are_points_on_device = _on_dev(bases)
+    cfg.are_points_montgomery_form = points_montgomery
     cfg.are_results_on_device = True
     f = min(factor, msm_windows(n, c, bitsize, curve))
     out = DeviceBuffer(aff * n * f)
@@ -376,7 +377,7 @@ def msm_precompute_bases(bases, n, factor, c=0, bitsize=0, curve="bls12_381"):
 
 
 def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize=0, stream=None, curve="bls12_381",
-        precompute_factor=1):
+        precompute_factor=1, scalars_montgomery=False, points_montgomery=False):
     """returns `batch` projective results (144 B each; 96 B for bn254) on the host"""
     sym, aff = _CURVES[curve][0], _CURVES[curve][4]
     cfg = lib().tkmk_msm_default_config()
@@ -389,6 +390,8 @@ def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize
     cfg.bitsize = bitsize
     cfg.stream_handle = stream
     cfg.precompute_factor = precompute_factor
+    cfg.are_scalars_montgomery_form = scalars_montgomery
+    cfg.are_points_montgomery_form = points_montgomery
     out = np.empty(aff // 2 * 3 * batch, np.uint8)
     _check(getattr(lib(), sym)(_p(scalars), _p(bases), int(n), ctypes.byref(cfg), _p(out)), sym)
     return out
