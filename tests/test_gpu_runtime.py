@@ -1,0 +1,84 @@
+"""gpu tier: the device-runtime part of the C ABI (include/tkmk.h: streams, async copies, device results, the allocation
+cache) as the reference uses it through icicle_runtime (IcicleStream, DeviceVec, `are_results_on_device`, `is_async` in
+setup/mpc-setup/src/lib.rs:91-122)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_streams_async_copies_and_device_results(gpu, oracle):
+    lib = gpu.lib()
+    st = ctypes.c_void_p()
+    gpu._check(lib.tkmk_stream_create(ctypes.byref(st)), "tkmk_stream_create")
+    try:
+        n = 3000
+        s = oracle.fr_random(1, n)
+        p = oracle.g1_random_bases(2, n)
+        ds, dp = gpu.DeviceBuffer(s.size), gpu.DeviceBuffer(p.size)
+        gpu._check(lib.tkmk_memcpy_h2d_async(gpu._p(ds), gpu._p(s), ctypes.c_size_t(s.size), st), "h2d_async")
+        gpu._check(lib.tkmk_memcpy_h2d_async(gpu._p(dp), gpu._p(p), ctypes.c_size_t(p.size), st), "h2d_async")
+        # MSM on the user's stream with the result left on the device, then an async copy back on the same stream
+        cfg = lib.tkmk_msm_default_config()
+        cfg.stream_handle = st
+        cfg.are_scalars_on_device = cfg.are_points_on_device = cfg.are_results_on_device = True
+        dres = gpu.DeviceBuffer(144)
+        gpu._check(lib.bls12_381_msm(gpu._p(ds), gpu._p(dp), n, ctypes.byref(cfg), gpu._p(dres)), "bls12_381_msm")
+        res = np.empty(144, np.uint8)
+        gpu._check(lib.tkmk_memcpy_d2h_async(gpu._p(res), gpu._p(dres), ctypes.c_size_t(144), st), "d2h_async")
+        gpu._check(lib.tkmk_stream_synchronize(st), "tkmk_stream_synchronize")
+        assert (gpu.projective_to_affine_bytes(res) == oracle.g1_msm(s, p)).all()
+        # NTT on the stream, asynchronous (device in / out), then a vector op on the same stream consuming it
+        gpu.init_ntt_domain_for_size(1 << 12)
+        x = oracle.fr_random(3, 1 << 12)
+        dx = gpu.DeviceBuffer(x.size)
+        gpu._check(lib.tkmk_memcpy_h2d_async(gpu._p(dx), gpu._p(x), ctypes.c_size_t(x.size), st), "h2d_async")
+        ncfg = lib.tkmk_ntt_default_config()
+        ncfg.stream_handle = st
+        ncfg.are_inputs_on_device = ncfg.are_outputs_on_device = True
+        ncfg.is_async = True
+        dy = gpu.DeviceBuffer(x.size)
+        gpu._check(lib.bls12_381_ntt(gpu._p(dx), 1 << 12, 0, ctypes.byref(ncfg), gpu._p(dy)), "bls12_381_ntt")
+        vcfg = lib.tkmk_vecops_default_config()
+        vcfg.stream_handle = st
+        vcfg.is_a_on_device = vcfg.is_b_on_device = vcfg.is_result_on_device = True
+        vcfg.is_async = True
+        dz = gpu.DeviceBuffer(x.size)
+        gpu._check(lib.bls12_381_vector_mul(gpu._p(dy), gpu._p(dy), ctypes.c_uint64(1 << 12), ctypes.byref(vcfg), gpu._p(dz)), "vector_mul")
+        gpu._check(lib.tkmk_stream_synchronize(st), "tkmk_stream_synchronize")
+        ev = oracle.ntt(x, 1 << 12)
+        assert (dz.to_host() == oracle.fr_mul(ev, ev)).all()
+    finally:
+        gpu._check(lib.tkmk_stream_destroy(st), "tkmk_stream_destroy")
+
+
+def test_strided_copy_and_allocation_cache(gpu, oracle):
+    lib = gpu.lib()
+    rows, width, spitch, dpitch = 37, 96 * 5, 96 * 9, 96 * 6
+    src = np.arange(rows * spitch, dtype=np.uint32).astype(np.uint8)
+    d_src = gpu.DeviceBuffer.from_host(src)
+    d_dst = gpu.DeviceBuffer(rows * dpitch)
+    gpu._check(lib.tkmk_memset(gpu._p(d_dst), 0xAB, ctypes.c_size_t(rows * dpitch)), "tkmk_memset")
+    gpu._check(lib.tkmk_memcpy_2d_d2d(gpu._p(d_dst), ctypes.c_size_t(dpitch), gpu._p(d_src), ctypes.c_size_t(spitch), ctypes.c_size_t(width),
+                                      ctypes.c_size_t(rows)), "tkmk_memcpy_2d_d2d")
+    got = d_dst.to_host().reshape(rows, dpitch)
+    assert (got[:, :width] == src.reshape(rows, spitch)[:, :width]).all() and (got[:, width:] == 0xAB).all()
+    # freed blocks are handed out again (same size class) and arrive clean of pending work; release returns them
+    total, free0 = gpu.available_memory()
+    a = gpu.DeviceBuffer(64 << 20)
+    ptr = a.ptr
+    gpu._check(lib.tkmk_memset(gpu._p(a), 0x5A, ctypes.c_size_t(64 << 20)), "tkmk_memset")
+    a.free()
+    b = gpu.DeviceBuffer(64 << 20)
+    assert b.ptr == ptr                                       # reused from the cache
+    assert (b.to_host(4096) == 0x5A).all()                    # ordinary memory: the earlier fill is still there, nothing stale or torn
+    b.free()
+    _, free1 = gpu.available_memory()
+    assert free1 >= free0 - (1 << 20)                         # cached bytes count as available
+    gpu.release_scratch()
+    c = gpu.DeviceBuffer(1 << 20)
+    assert c.to_host(16).size == 16
+    with pytest.raises(gpu.TkmkError):
+        gpu.DeviceBuffer(1 << 50)                             # absurd size: OUT_OF_MEMORY / ALLOCATION_FAILED, not a crash
