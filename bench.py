@@ -242,8 +242,22 @@ def _ntt_secondary(tkmk):
                 fn()
             tkmk.synchronize()
             dt = (time.perf_counter() - t0) / reps
+            # per-pass kernel times from HIP events on the launch stream (a separate, profiled repetition)
+            tkmk.profile_enable(True)
+            tkmk.profile_reset()
+            fn()
+            tkmk.profile_enable(False)
+            passes = []
+            for k in range(8):
+                ms, cnt = tkmk.profile_get("ntt.pass%d" % k)
+                if cnt:
+                    passes.append(ms / cnt)
+            moved = 64 * elems * len(passes)                   # every pass reads and writes each element once
             res[name] = {"ms": dt * 1e3, "elements_per_s": elems / dt, "algorithmic_GBps": 64 * elems / dt / 1e9,
-                         "hbm_frac": 64 * elems / dt / 1e9 / HBM_PEAK_GBS}
+                         "hbm_frac": 64 * elems / dt / 1e9 / HBM_PEAK_GBS, "passes_ms": [round(x, 4) for x in passes],
+                         "moved_GBps": (moved / (sum(passes) * 1e-3) / 1e9) if passes else None,
+                         "moved_hbm_frac": (moved / (sum(passes) * 1e-3) / 1e9 / HBM_PEAK_GBS) if passes else None,
+                         "bound": "integer VALU (Fr products): see DESIGN.md section 4"}
             a.free()
             o.free()
     except Exception as e:  # secondary figure: never fail the headline line
