@@ -1,0 +1,402 @@
+"""Test infrastructure: CPU restatement of the reference prover "in the exponent", for parity tests of tkmk/prove.py.
+
+Follows packages/backend/prove/src/lib.rs (init :675-1206, prove0 :1446-1782, prove1 :1784-1956, prove2 :1958-2270,
+prove3 :2272-2354, prove4 :2356-3206), using the ORIGINAL expressions the reference quotes in its comments where its code
+has been refactored (W, B, Q_CX / Q_CY, LHS_zk1 / LHS_zk2), so the product's transcription of the refactored code is checked
+against the un-refactored algebra.  Polynomials are Python big-int matrices with schoolbook products and naive
+interpolation — no NTT, no device code, nothing from the product.  The two divisions whose quotient split is a property of
+the reference's algorithm (div_by_vanishing_opt, div_by_ruffini) come from the oracle's statement-for-statement restatements
+(oracle/tk_oracle.c, checked by tests/test_oracle_poly.py).  Every commitment is kept as its discrete logarithm: with the
+fixed-tau CRS of setup/trusted-setup/src/main.rs:68-80, encode_poly(P) = [P(tau_x, tau_y)]G (:236-246), and the binding
+commitments are dot products with the (synthetic) table scalars.  That also lets the verifier's pairing equations
+(verify-rust/src/lib.rs:154-196, 225-246, 291-317) be checked as scalar equations (`verify_arith`, `verify_copy`).
+"""
+import os
+import sys
+
+import numpy as np
+
+import oracle
+
+_PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tokamak-zk-evm_amd")
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+from tkmk.transcript import TranscriptManager  # noqa: E402   (host-only Keccak transcript, pinned in tests/test_transcript.py)
+
+R = oracle.R_MOD
+
+
+def inv(a):
+    return pow(a % R, R - 2, R)
+
+
+class P:
+    """dense bivariate polynomial, c[i][j] = coefficient of X^i Y^j (object array of Python ints)"""
+
+    def __init__(self, c):
+        self.c = np.array(c, dtype=object) % R
+        if self.c.ndim != 2:
+            raise ValueError("need a matrix")
+
+    @classmethod
+    def const(cls, v):
+        return cls([[v % R]])
+
+    @classmethod
+    def x_poly(cls, coeffs):
+        return cls([[v] for v in coeffs])
+
+    @classmethod
+    def y_poly(cls, coeffs):
+        return cls([list(coeffs)])
+
+    @classmethod
+    def from_bytes(cls, buf, xs, ys):
+        return cls(np.array(oracle.to_ints(buf, 32), dtype=object).reshape(xs, ys))
+
+    def padded(self, xs, ys):
+        out = np.zeros((xs, ys), dtype=object)
+        a, b = self.c.shape
+        assert not self.c[xs:, :].any() and not self.c[:, ys:].any(), "padded(): would drop non-zero coefficients"
+        out[:min(a, xs), :min(b, ys)] = self.c[:xs, :ys]
+        return out
+
+    def to_bytes(self, xs, ys):
+        return oracle.to_bytes([int(v) for v in self.padded(xs, ys).reshape(-1)], 32)
+
+    def _bin(self, o, sign):
+        o = o if isinstance(o, P) else P.const(o)
+        xs, ys = max(self.c.shape[0], o.c.shape[0]), max(self.c.shape[1], o.c.shape[1])
+        return P((self.padded(xs, ys) + sign * o.padded(xs, ys)) % R)
+
+    def __add__(self, o):
+        return self._bin(o, 1)
+
+    def __sub__(self, o):
+        return self._bin(o, -1)
+
+    def __mul__(self, o):
+        if not isinstance(o, P):
+            return P(self.c * (o % R) % R)
+        a, b = self.c.shape
+        out = np.zeros((a + o.c.shape[0] - 1, b + o.c.shape[1] - 1), dtype=object)
+        for i in range(a):
+            for j in range(b):
+                if self.c[i, j]:
+                    out[i:i + o.c.shape[0], j:j + o.c.shape[1]] += self.c[i, j] * o.c
+        return P(out % R)
+
+    __rmul__ = __mul__
+
+    def eval(self, x, y):
+        acc = 0
+        for row in self.c[::-1]:
+            r = 0
+            for v in row[::-1]:
+                r = (r * y + v) % R
+            acc = (acc * x + r) % R
+        return acc
+
+    def scaled(self, fx, fy):
+        """coefficient (i, j) times fx^i fy^j: P(fx X, fy Y)"""
+        px = [pow(fx, i, R) for i in range(self.c.shape[0])]
+        py = [pow(fy, j, R) for j in range(self.c.shape[1])]
+        return P(self.c * np.array(px, dtype=object)[:, None] * np.array(py, dtype=object)[None, :] % R)
+
+    def degree(self):
+        nz = np.argwhere(self.c != 0)
+        return (-1, -1) if nz.size == 0 else (int(nz[:, 0].max()), int(nz[:, 1].max()))
+
+
+def interpolate(evals, xs, ys):
+    """from_rou_evals: evals[i][j] = p(wx^i, wy^j) -> coefficients, by the naive inverse DFT on each axis"""
+    wx = oracle.to_ints(oracle.root_of_unity(xs), 32)[0]
+    wy = oracle.to_ints(oracle.root_of_unity(ys), 32)[0]
+    e = np.array(evals, dtype=object).reshape(xs, ys)
+
+    def idft(mat, w, n):           # along axis 0
+        wi, ni = inv(w), inv(n)
+        m = np.array([[pow(wi, i * k, R) for k in range(n)] for i in range(n)], dtype=object)
+        return m.dot(mat) % R * ni % R
+
+    c = idft(e, wx, xs)
+    c = idft(c.T, wy, ys).T
+    return P(c)
+
+
+def vanishing(size, x_axis):
+    c = [R - 1] + [0] * (size - 1) + [1]
+    return P.x_poly(c) if x_axis else P.y_poly(c)
+
+
+def _pow2(v):
+    return 1 if v <= 1 else 1 << (v - 1).bit_length()
+
+
+def div_by_vanishing(p, c, d):
+    """DensePolynomialExt::div_by_vanishing_opt (libs/src/bivariate_polynomial/mod.rs:2284-2410) via the oracle's restatement"""
+    xd, yd = p.degree()
+    xs, ys = _pow2(xd + 1), _pow2(yd + 1)
+    assert xd >= c and yd >= d
+    xs2, ys2 = (xs // c) * c, (ys // d) * d
+    qx, qy = oracle.poly_div_by_vanishing_opt(p.to_bytes(xs2, ys2), xs2, ys2, c, d)
+    return P.from_bytes(qx, xs2, ys2), P.from_bytes(qy, c, ys2)
+
+
+def div_by_ruffini(p, x, y):
+    """div_by_ruffini (mod.rs:2412-2477) via the oracle's restatement -> (q_x, q_y, remainder)"""
+    xs, ys = _pow2(p.c.shape[0]), _pow2(p.c.shape[1])
+    qx, qy, r = oracle.poly_div_by_ruffini(p.to_bytes(xs, ys), xs, ys, oracle.to_bytes([x % R], 32), oracle.to_bytes([y % R], 32))
+    return P.from_bytes(qx, xs, ys), P.from_bytes(qy, 1, ys), oracle.to_ints(r, 32)[0]
+
+
+def hex_fr(h):
+    return int(h, 16) % R
+
+
+class RefProver:
+    """crs = {"tau_x", "tau_y", "delta", "eta", "gamma_inv_o_inst": [...], "eta_inv_li_o_inter_alpha4_kj": [[..s_max..] x m_i],
+    "delta_inv_li_o_prv": [[...]], "delta_inv_alphak_xh_tx": 3x3, "delta_inv_alpha4_xj_tx": 2, "delta_inv_alphak_yi_ty": 4x3}:
+    discrete logarithms of the CRS entries (libs/src/group_structures/mod.rs:313-551 for the names)"""
+
+    def __init__(self, inst, crs, mixer):
+        self.sp, self.crs, self.mx = inst["setup_params"], crs, mixer
+        sp = self.sp
+        self.n, self.s_max, self.l, self.l_D = sp["n"], sp["s_max"], sp["l"], sp["l_D"]
+        self.m_i = self.l_D - self.l
+        self.infos, self.pv = inst["infos"], inst["placement_variables"]
+        self.wx = oracle.to_ints(oracle.root_of_unity(self.m_i), 32)[0]
+        self.wy = oracle.to_ints(oracle.root_of_unity(self.s_max), 32)[0]
+        n, s_max, m_i = self.n, self.s_max, self.m_i
+        # gen_bXY (libs/src/polynomial_structures/mod.rs:132-162)
+        b = np.zeros((m_i, s_max), dtype=object)
+        for i, pl in enumerate(self.pv):
+            fm = self.infos[pl["subcircuitId"]]["flattenMap"]
+            for g, val in zip(fm, pl["variables"]):
+                if self.l <= g < self.l_D:
+                    b[g - self.l, i] = hex_fr(val)
+        self.b = interpolate(b, m_i, s_max)
+        # read_R1CS_gen_uvwXY (libs/src/iotools/mod.rs:1287-1523): column i = (A w_i, B w_i, C w_i) of placement i's subcircuit
+        uvw = [np.zeros((n, s_max), dtype=object) for _ in range(3)]
+        for i, pl in enumerate(self.pv):
+            sub = inst["subs"][pl["subcircuitId"]]
+            w = [hex_fr(v) for v in pl["variables"]]
+            for row, abc in enumerate(sub.rows):
+                for m in range(3):
+                    uvw[m][row, i] = sum(c * w[k] for k, c in abc[m]) % R
+        self.u, self.v, self.w = (interpolate(e, n, s_max) for e in uvw)
+        self.uvw_evals = uvw
+        # Permutation::to_poly (libs/src/iotools/mod.rs:419-455)
+        s0 = np.array([[pow(self.wx, r, R)] * s_max for r in range(m_i)], dtype=object)
+        s1 = np.array([[pow(self.wy, c, R) for c in range(s_max)] for _ in range(m_i)], dtype=object)
+        for e in inst["permutation"]:
+            s0[e["row"], e["col"]] = pow(self.wx, e["X"], R)
+            s1[e["row"], e["col"]] = pow(self.wy, e["Y"], R)
+        self.s0, self.s1 = interpolate(s0, m_i, s_max), interpolate(s1, m_i, s_max)
+        ins = inst["instance"]
+        a = [hex_fr(ins["a_pub_user"][i]) for i in range(sp["l_user"])] + [hex_fr(ins["a_pub_block"][i]) for i in range(sp["l_free"] - sp["l_user"])]
+        self.a_free = interpolate([[v] for v in a], sp["l_free"], 1)
+        self.t_n, self.t_mi, self.t_smax = vanishing(n, True), vanishing(m_i, True), vanishing(s_max, False)
+
+    def commit(self, p):
+        return p.eval(self.crs["tau_x"], self.crs["tau_y"])
+
+    # ---- init: binding (lib.rs:1083-1167; libs/src/group_structures/mod.rs:184-300)
+    def binding(self):
+        crs, mx, l, l_D, m_D = self.crs, self.mx, self.l, self.l_D, self.sp["m_D"]
+        o_pub = o_mid = o_prv = 0
+        for i, pl in enumerate(self.pv):
+            info = self.infos[pl["subcircuitId"]]
+            vals = [hex_fr(v) for v in pl["variables"]]
+            key = {"bufferPubOut": "Out_idx", "bufferPubIn": "In_idx", "bufferBlockIn": "In_idx"}.get(info["name"])
+            if key:
+                for j in range(info[key][0], info[key][0] + info[key][1]):
+                    o_pub += vals[j] * crs["gamma_inv_o_inst"][info["flattenMap"][j]]
+            for j, g in enumerate(info["flattenMap"]):
+                if l <= g < l_D:
+                    o_mid += vals[j] * crs["eta_inv_li_o_inter_alpha4_kj"][g - l][i]
+                elif l_D <= g < m_D:
+                    o_prv += vals[j] * crs["delta_inv_li_o_prv"][g - l_D][i]
+        xh, xj, yi = crs["delta_inv_alphak_xh_tx"], crs["delta_inv_alpha4_xj_tx"], crs["delta_inv_alphak_yi_ty"]
+        O_mid = o_mid + crs["delta"] * mx["rO_mid"]
+        O_prv = (o_prv - crs["eta"] * mx["rO_mid"] + xh[0][0] * mx["rU_X"] + xh[1][0] * mx["rV_X"]
+                 + sum(xh[2][k] * mx["rW_X"][k] for k in range(3)) + sum(xj[k] * mx["rB_X"][k] for k in range(2))
+                 + yi[0][0] * mx["rU_Y"] + yi[1][0] * mx["rV_Y"] + sum(yi[2][k] * mx["rW_Y"][k] for k in range(3))
+                 + sum(yi[3][k] * mx["rB_Y"][k] for k in range(2)))
+        return {"A_free": self.commit(self.a_free), "O_pub_free": o_pub % R, "O_mid": O_mid % R, "O_prv": O_prv % R}
+
+    def r1cs_satisfied(self):
+        u, v, w = self.uvw_evals
+        return bool(((u * v - w) % R == 0).all())
+
+    def fg(self, th):
+        f = self.b + self.s0 * th[0] + self.s1 * th[1] + th[2]
+        g = self.b + P.x_poly([0, th[0]]) + P.y_poly([0, th[1]]) + th[2]
+        return f, g
+
+    def prove0(self):
+        mx, n, s_max, m_i = self.mx, self.n, self.s_max, self.m_i
+        p0 = self.u * self.v - self.w
+        self.q0, self.q1 = div_by_vanishing(p0, n, s_max)
+        rW_X, rW_Y = P.x_poly(mx["rW_X"]), P.y_poly(mx["rW_Y"])
+        self.U = self.u + self.t_n * mx["rU_X"] + self.t_smax * mx["rU_Y"]
+        self.V = self.v + self.t_n * mx["rV_X"] + self.t_smax * mx["rV_Y"]
+        self.W = self.w + rW_X * self.t_n + rW_Y * self.t_smax                         # original expression (lib.rs:1633-1634)
+        Q_AX = (self.q0 + self.v * mx["rU_X"] + self.u * mx["rV_X"] - rW_X + self.t_n * (mx["rU_X"] * mx["rV_X"])
+                + self.t_smax * (mx["rU_Y"] * mx["rV_X"]))
+        Q_AY = (self.q1 + self.v * mx["rU_Y"] + self.u * mx["rV_Y"] - rW_Y + self.t_n * (mx["rU_X"] * mx["rV_Y"])
+                + self.t_smax * (mx["rU_Y"] * mx["rV_Y"]))
+        self.B = self.b + P.x_poly(mx["rB_X"]) * self.t_mi + P.y_poly(mx["rB_Y"]) * self.t_smax     # lib.rs:1744-1745
+        self.Q_AX, self.Q_AY = Q_AX, Q_AY
+        return {k: self.commit(p) for k, p in (("U", self.U), ("V", self.V), ("W", self.W), ("Q_AX", Q_AX), ("Q_AY", Q_AY), ("B", self.B))}
+
+    def prove1(self, th):
+        mx, m_i, s_max = self.mx, self.m_i, self.s_max
+        f, g = self.fg(th)
+        fe = [[f.eval(pow(self.wx, i, R), pow(self.wy, j, R)) for j in range(s_max)] for i in range(m_i)]
+        ge = [[g.eval(pow(self.wx, i, R), pow(self.wy, j, R)) for j in range(s_max)] for i in range(m_i)]
+        # lib.rs:1858-1866 : walk the grid column by column (transposed order) from the last cell backwards
+        order = [(i, j) for j in range(s_max) for i in range(m_i)]
+        r = {order[-1]: 1}
+        for k in range(len(order) - 2, -1, -1):
+            ni, nj = order[k + 1]
+            r[order[k]] = r[order[k + 1]] * ge[ni][nj] % R * inv(fe[ni][nj]) % R
+        self.r = interpolate([[r[(i, j)] for j in range(s_max)] for i in range(m_i)], m_i, s_max)
+        self.R = self.r + self.t_mi * mx["rR_X"] + self.t_smax * mx["rR_Y"]
+        return {"R": self.commit(self.R)}
+
+    def prove2(self, th, k0):
+        mx, m_i, s_max = self.mx, self.m_i, self.s_max
+        wxi, wyi = inv(self.wx), inv(self.wy)
+        r = self.r
+        r_wx = r.scaled(wxi, 1)
+        r_wxy = r_wx.scaled(1, wyi)
+        f, g = self.fg(th)
+        K = interpolate([[0]] * (m_i - 1) + [[1]], m_i, 1)
+        L = interpolate([[0] * (s_max - 1) + [1]], 1, s_max)
+        K0 = interpolate([[1]] + [[0]] * (m_i - 1), m_i, 1)
+        KL = K * L
+        Xm1 = P.x_poly([R - 1, 1])
+        p1 = (r - 1) * KL
+        p2 = Xm1 * (r * g - r_wx * f)
+        p3 = K0 * (r * g - r_wxy * f)
+        p_comb = p1 + p2 * k0 + p3 * (k0 * k0 % R)
+        self.q2, self.q3 = div_by_vanishing(p_comb, m_i, s_max)
+        r_D1, r_D2, g_D = r - r_wx, r - r_wxy, g - f
+        rB_X, rB_Y = P.x_poly(mx["rB_X"]), P.y_poly(mx["rB_Y"])
+        # original expressions (lib.rs:2190-2194, 2234-2238)
+        Q_CX = (self.q2 + KL * mx["rR_X"] + (Xm1 * rB_X * r_D1 + Xm1 * g_D * mx["rR_X"]) * k0
+                + (K0 * rB_X * r_D2 + K0 * g_D * mx["rR_X"]) * (k0 * k0 % R))
+        Q_CY = (self.q3 + KL * mx["rR_Y"] + (Xm1 * rB_Y * r_D1 + Xm1 * g_D * mx["rR_Y"]) * k0
+                + (K0 * rB_Y * r_D2 + K0 * g_D * mx["rR_Y"]) * (k0 * k0 % R))
+        self.KL, self.K0, self.r_wx, self.r_wxy, self.p_comb = KL, K0, r_wx, r_wxy, p_comb
+        return {"Q_CX": self.commit(Q_CX), "Q_CY": self.commit(Q_CY)}
+
+    def prove3(self, chi, zeta):
+        wxi, wyi = inv(self.wx), inv(self.wy)
+        R_wx = self.R.scaled(wxi, 1)
+        return {"V_eval": self.V.eval(chi, zeta), "R_eval": self.R.eval(chi, zeta), "R_omegaX_eval": R_wx.eval(chi, zeta),
+                "R_omegaX_omegaY_eval": R_wx.scaled(1, wyi).eval(chi, zeta)}
+
+    def prove4(self, p3, th, k0, chi, zeta, k1):
+        mx, m_i, s_max, n = self.mx, self.m_i, self.s_max, self.n
+        wxi, wyi = inv(self.wx), inv(self.wy)
+        t_n_e, t_mi_e, t_s_e = (pow(chi, n, R) - 1) % R, (pow(chi, m_i, R) - 1) % R, (pow(zeta, s_max, R) - 1) % R
+        v_e = self.v.eval(chi, zeta)
+        rW_X, rW_Y = P.x_poly(mx["rW_X"]), P.y_poly(mx["rW_Y"])
+        # lib.rs:2457-2486 with the original zero-knowledge term of :2480-2481
+        pA = ((self.V - p3["V_eval"]) * k1 + self.u * v_e - self.w - self.q0 * t_n_e - self.q1 * t_s_e
+              + self.t_n * (v_e * mx["rU_X"]) + self.t_smax * (v_e * mx["rU_Y"]) - self.v * (mx["rU_X"] * t_n_e + mx["rU_Y"] * t_s_e)
+              + rW_X * (P.const(t_n_e) - self.t_n) + rW_Y * (P.const(t_s_e) - self.t_smax))
+        Pi_AX, Pi_AY, rem_A = div_by_ruffini(pA, chi, zeta)
+        M_X, M_Y, rem_M = div_by_ruffini(self.R - p3["R_omegaX_eval"], wxi * chi, zeta)
+        N_X, N_Y, rem_N = div_by_ruffini(self.R - p3["R_omegaX_omegaY_eval"], wxi * chi, wyi * zeta)
+        r, r_wx, r_wxy = self.r, self.r_wx, self.r_wxy
+        f, g = self.fg(th)
+        K0_e = self.K0.eval(chi, zeta)
+        r_e, r_wx_e, r_wxy_e = r.eval(chi, zeta), r_wx.eval(chi, zeta), r_wxy.eval(chi, zeta)
+        pC = (self.KL * (r_e - 1) + (g * r_e - f * r_wx_e) * (k0 * (chi - 1)) + (g * r_e - f * r_wxy_e) * (k0 * k0 % R * K0_e)
+              - self.q2 * t_mi_e - self.q3 * t_s_e)
+        r_D1, r_D2 = r - r_wx, r - r_wxy
+        term_B_zk = P.x_poly(mx["rB_X"]) * self.t_mi + P.y_poly(mx["rB_Y"]) * self.t_smax
+        term9 = P.x_poly(mx["rB_X"]) * t_mi_e + P.y_poly(mx["rB_Y"]) * t_s_e
+        term10 = (g - f) * (mx["rR_X"] * t_mi_e + mx["rR_Y"] * t_s_e)
+        one_minus_X, chi_minus_X = P.x_poly([1, R - 1]), P.x_poly([chi, R - 1])
+        # original expressions (lib.rs:3002-3004, 3029-3031) plus the term_B_zk parts of the poly_comb! calls
+        zk1 = term_B_zk * ((chi - 1) * r_D1.eval(chi, zeta)) + one_minus_X * (r_D1 * term9) + chi_minus_X * term10
+        zk2 = term_B_zk * (K0_e * r_D2.eval(chi, zeta)) + (self.K0 * r_D2) * (term9 * (R - 1)) + term10 * (P.const(K0_e) - self.K0)
+        k1_2 = k1 * k1 % R
+        lhs_copy = pC * k1_2 + zk1 * (k1_2 * k0) + zk2 * (k1_2 * k0 % R * k0) + (self.R - p3["R_eval"]) * (k1_2 * k1)
+        Pi_CX, Pi_CY, rem_C = div_by_ruffini(lhs_copy, chi, zeta)
+        A_e = self.a_free.eval(chi, zeta)
+        pi_B, _, rem_B = div_by_ruffini(self.a_free - A_e, chi, zeta)
+        self.remainders = {"Pi_A": rem_A, "M": rem_M, "N": rem_N, "Pi_C": rem_C, "Pi_B": rem_B}
+        c = self.commit
+        Pi_B = c(pi_B) * pow(k1, 4, R) % R
+        t = {"Pi_CX": c(Pi_CX), "Pi_CY": c(Pi_CY), "Pi_AX": c(Pi_AX), "Pi_AY": c(Pi_AY), "Pi_B": Pi_B, "M_X": c(M_X), "M_Y": c(M_Y),
+             "N_X": c(N_X), "N_Y": c(N_Y)}
+        proof4 = {"Pi_X": (t["Pi_AX"] + t["Pi_CX"] + Pi_B) % R, "Pi_Y": (t["Pi_AY"] + t["Pi_CY"]) % R, "M_X": t["M_X"], "M_Y": t["M_Y"],
+                  "N_X": t["N_X"], "N_Y": t["N_Y"]}
+        return proof4, t
+
+
+def g1_of(dlog, g):
+    """[dlog]G as the 96-byte affine record ((0,0) for infinity)"""
+    return oracle.g1_scalar_mul(oracle.to_bytes([dlog % R], 32), g)
+
+
+def run(inst, crs, mixer, g):
+    """all five rounds with the Fiat-Shamir challenges drawn from the commitments' POINTS (as the product must) ->
+    (dlogs of the 19 proof points, 4 scalars, challenges, proof4_test dlogs, RefProver)"""
+    rp = RefProver(inst, crs, mixer)
+    binding = rp.binding()
+    m = TranscriptManager()
+    pt = lambda d: np.asarray(g1_of(d, g))                                            # noqa: E731
+    p0 = rp.prove0()
+    m.add_proof0(*(pt(p0[k]) for k in ("U", "V", "W", "Q_AX", "Q_AY", "B")))
+    th = m.get_thetas()
+    p1 = rp.prove1(th)
+    m.add_proof1(pt(p1["R"]))
+    k0 = m.get_kappa0()
+    p2 = rp.prove2(th, k0)
+    m.add_proof2(pt(p2["Q_CX"]), pt(p2["Q_CY"]))
+    chi, zeta = m.get_chi_zeta()
+    p3 = rp.prove3(chi, zeta)
+    m.add_proof3(p3["V_eval"], p3["R_eval"], p3["R_omegaX_eval"], p3["R_omegaX_omegaY_eval"])
+    k1 = m.get_kappa1()
+    p4, p4t = rp.prove4(p3, th, k0, chi, zeta, k1)
+    dlogs = dict(binding)
+    for part in (p0, p1, p2, p4):
+        dlogs.update(part)
+    return dlogs, p3, {"thetas": th, "kappa0": k0, "chi": chi, "zeta": zeta, "kappa1": k1}, p4t, rp
+
+
+# ---- the verifier's equations, in the exponent (verify-rust/src/lib.rs) ----
+def verify_arith(d, s, ch, p4t, crs, sp):
+    """:154-165, 244-246, 291-303:  e(LHS_A + AUX_A, H) = e(Pi_AX, [x]H) e(Pi_AY, [y]H)"""
+    chi, zeta, k1 = ch["chi"], ch["zeta"], ch["kappa1"]
+    t_n_e, t_s_e = pow(chi, sp["n"], R) - 1, pow(zeta, sp["s_max"], R) - 1
+    lhs = d["U"] * s["V_eval"] - d["W"] + (d["V"] - s["V_eval"]) * k1 - d["Q_AX"] * t_n_e - d["Q_AY"] * t_s_e
+    aux = p4t["Pi_AX"] * chi + p4t["Pi_AY"] * zeta
+    return (lhs + aux - p4t["Pi_AX"] * crs["tau_x"] - p4t["Pi_AY"] * crs["tau_y"]) % R == 0
+
+
+def verify_copy(d, s, ch, p4t, crs, sp, s0_commit, s1_commit, kl_commit, kappa2):
+    """:167-196, 225-242, 305-317"""
+    th, k0, chi, zeta, k1 = ch["thetas"], ch["kappa0"], ch["chi"], ch["zeta"], ch["kappa1"]
+    m_i, s_max = sp["l_D"] - sp["l"], sp["s_max"]
+    wxi = inv(oracle.to_ints(oracle.root_of_unity(m_i), 32)[0])
+    wyi = inv(oracle.to_ints(oracle.root_of_unity(s_max), 32)[0])
+    t_mi_e, t_s_e = (pow(chi, m_i, R) - 1) % R, (pow(zeta, s_max, R) - 1) % R
+    k0_e = 1 if chi == 1 else t_mi_e * inv(m_i) * inv(chi - 1) % R                    # eval_lagrange_k0 (:135-148)
+    F = d["B"] + s0_commit * th[0] + s1_commit * th[1] + th[2]
+    G = d["B"] + crs["tau_x"] * th[0] + crs["tau_y"] * th[1] + th[2]
+    term1 = (kl_commit * (s["R_eval"] - 1) + (G * s["R_eval"] - F * s["R_omegaX_eval"]) * (k0 * (chi - 1))
+             + (G * s["R_eval"] - F * s["R_omegaX_omegaY_eval"]) * (k0 * k0 * k0_e) - d["Q_CX"] * t_mi_e - d["Q_CY"] * t_s_e)
+    lhs = (term1 * k1 ** 2 + (d["R"] - s["R_eval"]) * k1 ** 3 + (d["R"] - s["R_omegaX_eval"]) * kappa2
+           + (d["R"] - s["R_omegaX_omegaY_eval"]) * kappa2 ** 2)
+    aux = (p4t["Pi_CX"] * chi + p4t["Pi_CY"] * zeta + p4t["M_X"] * (kappa2 * wxi * chi) + p4t["M_Y"] * (kappa2 * zeta)
+           + p4t["N_X"] * (kappa2 ** 2 * wxi * chi) + p4t["N_Y"] * (kappa2 ** 2 * wyi * zeta))
+    aux_x = p4t["Pi_CX"] + p4t["M_X"] * kappa2 + p4t["N_X"] * kappa2 ** 2
+    aux_y = p4t["Pi_CY"] + p4t["M_Y"] * kappa2 + p4t["N_Y"] * kappa2 ** 2
+    return (lhs + aux - aux_x * crs["tau_x"] - aux_y * crs["tau_y"]) % R == 0

@@ -1,0 +1,156 @@
+"""Test infrastructure: a synthetic subcircuit library + synthesizer output with the file formats `prove` reads.
+
+The reference ships no witness / proof fixtures (and its witness calculators are prebuilt wasm, which is never run here),
+so satisfying inputs are manufactured: random arithmetic subcircuits written as iden3 `.r1cs` v1 files (the format of
+packages/frontend/qap-compiler/subcircuits/library/r1cs/*.r1cs, reader packages/backend/libs/src/iotools/mod.rs:505-650),
+witnesses by forward evaluation, placements chained through copy constraints (permutation.json entries {row, col, X, Y}:
+libs/src/iotools/mod.rs:408-455), setupParams.json / subcircuitInfo.json / placementVariables.json / instance.json with
+the field names of libs/src/iotools/mod.rs:166-177,366-372,399-406,458-469.
+
+Layout of one subcircuit's local wires: [0] = the constant 1, then outputs, then inputs, then private wires
+(Out_idx = [1, n_out], In_idx = [1 + n_out, n_in]).  Global wire ranges: [0, l) public, [l, l_D) interface, [l_D, m_D) private.
+"""
+import json
+import os
+import struct
+
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+def write_r1cs(path, n_wires, rows):
+    """rows: list of (A, B, C), each a list of (wire, coeff int)"""
+    cons = bytearray()
+    for abc in rows:
+        for lc in abc:
+            cons += struct.pack("<I", len(lc))
+            for wire, coeff in lc:
+                cons += struct.pack("<I", wire) + (coeff % R).to_bytes(32, "little")
+    header = struct.pack("<I", 32) + R.to_bytes(32, "little") + struct.pack("<IIIIQI", n_wires, 0, 0, 0, n_wires, len(rows))
+    labels = b"".join(struct.pack("<Q", i) for i in range(n_wires))
+    with open(path, "wb") as f:
+        f.write(b"r1cs" + struct.pack("<II", 1, 3))
+        for stype, body in ((1, header), (2, bytes(cons)), (3, labels)):
+            f.write(struct.pack("<IQ", stype, len(body)) + body)
+
+
+class Subcircuit:
+    def __init__(self, sid, name, n_out, n_in, n_prv):
+        self.id, self.name, self.n_out, self.n_in, self.n_prv = sid, name, n_out, n_in, n_prv
+        self.n_wires = 1 + n_out + n_in + n_prv
+        self.rows = []          # (A, B, C)
+        self.order = []         # (target wire, A, B, lin): target = (A.w)(B.w) + lin.w, in evaluation order
+        self.flatten_map = None
+
+    def outs(self):
+        return range(1, 1 + self.n_out)
+
+    def ins(self):
+        return range(1 + self.n_out, 1 + self.n_out + self.n_in)
+
+    def prvs(self):
+        return range(1 + self.n_out + self.n_in, self.n_wires)
+
+    def define(self, target, A, B, lin):
+        self.order.append((target, A, B, lin))
+        self.rows.append((A, B, [(target, 1)] + [(w, -c) for w, c in lin]))
+
+    def witness(self, inputs):
+        w = [0] * self.n_wires
+        w[0] = 1
+        for wire, v in zip(self.ins(), inputs):
+            w[wire] = v % R
+        dot = lambda lc: sum(c * w[k] for k, c in lc) % R                             # noqa: E731
+        for target, A, B, lin in self.order:
+            w[target] = (dot(A) * dot(B) + dot(lin)) % R
+        return w
+
+
+def buffer_pub_in(sid, k):
+    """the shape of the library's bufferPubIn: out_i * 1 = in_i"""
+    s = Subcircuit(sid, "bufferPubIn", k, k, 0)
+    for o, i in zip(s.outs(), s.ins()):
+        s.define(o, [(i, 1)], [(0, 1)], [])
+    return s
+
+
+def random_gates(sid, rnd, n_out, n_in, n_prv, fan=3):
+    s = Subcircuit(sid, "synthGate%d" % sid, n_out, n_in, n_prv)
+    known = [0] + list(s.ins())
+    lc = lambda: [(w, rnd.randrange(1, R)) for w in rnd.sample(known, min(fan, len(known)))]   # noqa: E731
+    for t in list(s.prvs()) + list(s.outs()):
+        s.define(t, lc(), lc(), lc() if rnd.random() < 0.5 else [])
+        known.append(t)
+    return s
+
+
+def build(out_dir, rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub=2, used_placements=None, l_free=4, l_extra=4):
+    """writes <out_dir>/qap/{setupParams.json, subcircuitInfo.json, r1cs/subcircuit{id}.r1cs} and
+    <out_dir>/synth/{placementVariables.json, instance.json, permutation.json}; returns a dict describing the instance"""
+    qap, synth = os.path.join(out_dir, "qap"), os.path.join(out_dir, "synth")
+    os.makedirs(os.path.join(qap, "r1cs"), exist_ok=True)
+    os.makedirs(synth, exist_ok=True)
+    subs = [buffer_pub_in(0, k_pub)] + [random_gates(1 + g, rnd, n_out, n_in, n_prv) for g in range(n_gate_kinds)]
+    l_user = k_pub
+    assert l_user <= l_free
+    l = l_free + l_extra
+    # interface wires: constant + outputs + inputs of every subcircuit (the public buffer's inputs are public wires)
+    need_iface = sum(1 + s.n_out + (0 if s.id == 0 else s.n_in) for s in subs)
+    m_i = 1 << (need_iface - 1).bit_length()
+    l_D = l + m_i
+    nxt_iface, nxt_prv = l, l_D
+    for s in subs:
+        fm = [0] * s.n_wires
+        fm[0] = nxt_iface
+        nxt_iface += 1
+        for w in s.outs():
+            fm[w] = nxt_iface
+            nxt_iface += 1
+        for j, w in enumerate(s.ins()):
+            if s.id == 0:
+                fm[w] = j                              # public user inputs: global indices [0, l_user)
+            else:
+                fm[w] = nxt_iface
+                nxt_iface += 1
+        for w in s.prvs():
+            fm[w] = nxt_prv
+            nxt_prv += 1
+        s.flatten_map = fm
+    m_D = nxt_prv
+    n = 1 << (max(len(s.rows) for s in subs) - 1).bit_length()
+    sp = {"l_free": l_free, "l_user_out": 0, "l_user": l_user, "l": l, "l_D": l_D, "m_D": m_D, "n": n, "s_D": len(subs), "s_max": s_max}
+    infos = [{"id": s.id, "name": s.name, "Nwires": s.n_wires, "Nconsts": len(s.rows), "Out_idx": [1, s.n_out],
+              "In_idx": [1 + s.n_out, s.n_in], "flattenMap": s.flatten_map} for s in subs]
+    for s in subs:
+        write_r1cs(os.path.join(qap, "r1cs", "subcircuit%d.r1cs" % s.id), s.n_wires, s.rows)
+    json.dump(sp, open(os.path.join(qap, "setupParams.json"), "w"))
+    json.dump(infos, open(os.path.join(qap, "subcircuitInfo.json"), "w"))
+
+    # placements: 0 = the public buffer, then gates fed by earlier outputs; every feed is a copy constraint
+    used = s_max if used_placements is None else used_placements
+    pub_vals = [rnd.randrange(R) for _ in range(k_pub)]
+    placements = [(subs[0], subs[0].witness(pub_vals))]
+    produced = [(0, w) for w in subs[0].outs()]       # (placement, local wire) whose value may be consumed
+    consumers = {}                                    # source (placement, wire) -> [(placement, wire), ...]
+    for p in range(1, used):
+        s = subs[1 + rnd.randrange(n_gate_kinds)]
+        srcs = [rnd.choice(produced) for _ in s.ins()]
+        w = s.witness([placements[sp_][1][sw] for sp_, sw in srcs])
+        placements.append((s, w))
+        for src, dst in zip(srcs, s.ins()):
+            consumers.setdefault(src, []).append((p, dst))
+        produced += [(p, o) for o in s.outs()]
+    cell = lambda pl, wire: (placements[pl][0].flatten_map[wire] - l, pl)              # noqa: E731   (row, col)
+    perm = []
+    for src, dsts in consumers.items():
+        cyc = [cell(*src)] + [cell(*d) for d in dsts]
+        for a, b in zip(cyc, cyc[1:] + cyc[:1]):
+            perm.append({"row": a[0], "col": a[1], "X": b[0], "Y": b[1]})
+    hx = lambda v: "0x%x" % v                                                        # noqa: E731
+    pv = [{"subcircuitId": s.id, "variables": [hx(v) for v in w]} for s, w in placements]
+    instance = {"a_pub_user": [hx(v) for v in pub_vals], "a_pub_block": [hx(rnd.randrange(R)) for _ in range(l_free - l_user)],
+                "a_pub_function": [hx(rnd.randrange(R)) for _ in range(l - l_free)]}
+    json.dump(pv, open(os.path.join(synth, "placementVariables.json"), "w"))
+    json.dump(instance, open(os.path.join(synth, "instance.json"), "w"))
+    json.dump(perm, open(os.path.join(synth, "permutation.json"), "w"))
+    return {"qap": qap, "synth": synth, "setup_params": sp, "infos": infos, "subs": subs, "placements": placements,
+            "placement_variables": pv, "instance": instance, "permutation": perm, "m_i": m_i}

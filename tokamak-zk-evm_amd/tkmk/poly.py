@@ -167,6 +167,30 @@ class DensePolynomialExt:
     def scalar_mul(self, scalar):
         return DensePolynomialExt.from_coeffs(tkmk.scalar_mul(tkmk.DeviceBuffer.from_host(scalar), self.poly), self.x_size, self.y_size)
 
+    def mul_scalar(self, scalar):
+        """&poly * &scalar / &scalar * &poly (mod.rs:766-966): a clone when the scalar is one"""
+        s = np.ascontiguousarray(scalar)
+        if s[0] == 1 and not s[1:].any():
+            return self.clone()
+        return self.scalar_mul(s)
+
+    def _const_term(self, scalar, sub):
+        # mod.rs:1042-1116, 1189-1262: only coefficient (0, 0) changes; here a 32-byte device op on the clone
+        out = self.clone()
+        s = tkmk.DeviceBuffer.from_host(np.ascontiguousarray(scalar))
+        head = tkmk.DeviceBuffer(32)
+        lib = tkmk.lib()
+        tkmk._check(lib.tkmk_memcpy_d2d(tkmk._p(head), tkmk._p(out.poly), ctypes.c_size_t(32)), "tkmk_memcpy_d2d")
+        (tkmk.vec_sub if sub else tkmk.vec_add)(head, s, out=head)
+        tkmk._check(lib.tkmk_memcpy_d2d(tkmk._p(out.poly), tkmk._p(head), ctypes.c_size_t(32)), "tkmk_memcpy_d2d")
+        return out
+
+    def add_scalar(self, scalar):
+        return self._const_term(scalar, False)
+
+    def sub_scalar(self, scalar):
+        return self._const_term(scalar, True)
+
     def __neg__(self):
         zero = tkmk.DeviceBuffer.from_host(np.zeros(32, np.uint8))
         return DensePolynomialExt.from_coeffs(tkmk.scalar_sub(zero, self.poly), self.x_size, self.y_size)
