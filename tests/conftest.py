@@ -22,6 +22,9 @@ def oracle():
 PKG = os.path.join(ROOT, "tokamak-zk-evm_amd")
 if PKG not in sys.path:
     sys.path.insert(0, PKG)
+TOOLS = os.path.join(ROOT, "tools")                # tools/synth_circuit.py: synthetic circuits in the reference's file formats
+if TOOLS not in sys.path:
+    sys.path.insert(0, TOOLS)
 
 
 @pytest.fixture(scope="session")

@@ -153,23 +153,30 @@ class Prover:
     # ------------------------------------------------------------------ init (lib.rs:675-1206)
     @classmethod
     def init(cls, qap_path, synthesizer_path, setup_path, mixer=None, testing_mode=False, sigma=None, rng=None):
-        """-> (Prover, binding dict).  `sigma` = (Sigma1, tables) skips reading <setup_path>/combined_sigma.tkcrs (tests and
-        the bench stage the CRS in HBM directly); `mixer` fixes the blinding scalars (ScalarCfg::generate_random in the reference)"""
+        """-> (Prover, binding dict).  `sigma` = (Sigma1, tables, singles) skips reading <setup_path>/combined_sigma.tkcrs (tests
+        and the bench stage the CRS in HBM directly); `mixer` fixes the blinding scalars (ScalarCfg::generate_random in the reference)"""
+        t0 = time.perf_counter()
+        load = lambda d, name: json.load(open(os.path.join(d, name)))                 # noqa: E731
+        inputs = {"setup_params": load(qap_path, "setupParams.json"), "subcircuit_infos": load(qap_path, "subcircuitInfo.json"),
+                  "placement_variables": load(synthesizer_path, "placementVariables.json"),
+                  "permutation": load(synthesizer_path, "permutation.json"), "instance": load(synthesizer_path, "instance.json")}
+        return cls.init_from(inputs, qap_path, setup_path, mixer=mixer, testing_mode=testing_mode, sigma=sigma, rng=rng, _t0=t0)
+
+    @classmethod
+    def init_from(cls, inputs, qap_path, setup_path=None, mixer=None, testing_mode=False, sigma=None, rng=None, _t0=None):
+        """Prover::init after the JSON files are parsed: `inputs` holds the five parsed documents (the bench hands them over
+        in memory; a production-shape placementVariables.json is hundreds of MB of hex text)"""
         from tkmk import crs
         self = cls()
         self.testing_mode = testing_mode
-        t0 = time.perf_counter()
-        with open(os.path.join(qap_path, "setupParams.json")) as f:
-            sp = json.load(f)
+        t0 = time.perf_counter() if _t0 is None else _t0
+        sp = inputs["setup_params"]
         self.setup_params = sp
         m_i = validate_setup_shape(sp)
         n, s_max = sp["n"], sp["s_max"]
         self.m_i = m_i
         tkmk.init_ntt_domain_for_size(4 * max(m_i, n) * 2 * s_max)          # prover_verifier_ntt_domain_size (libs/src/utils/mod.rs:51-58)
-        with open(os.path.join(qap_path, "subcircuitInfo.json")) as f:
-            subcircuit_infos = json.load(f)
-        with open(os.path.join(synthesizer_path, "placementVariables.json")) as f:
-            placement_variables = json.load(f)
+        subcircuit_infos, placement_variables = inputs["subcircuit_infos"], inputs["placement_variables"]
         self.timing["init.load"] = time.perf_counter() - t0
 
         t1 = time.perf_counter()
@@ -178,10 +185,7 @@ class Prover:
         self.rXY = DensePolynomialExt.zero()
         self.q = {}
         self.cache = {}
-        with open(os.path.join(synthesizer_path, "permutation.json")) as f:
-            permutation_raw = json.load(f)
-        with open(os.path.join(synthesizer_path, "instance.json")) as f:
-            instance = json.load(f)
+        permutation_raw, instance = inputs["permutation"], inputs["instance"]
         self.a_free_X = gen_a_free_X(instance, sp)
         self.t_n = _vanishing(n, True)
         self.t_mi = _vanishing(m_i, True)

@@ -1,0 +1,123 @@
+"""Full `prove` (init + prove0..prove4, tkmk/prove.py) on a synthetic circuit of the production shape, timed on one MI355X.
+
+Shapes: --s-max 256 is the reference's production shape (n = 4096, m_I = 4096, s_max = 256: 2^20 constraint slots;
+reference walls 45.70 s CPU / 21.08 s CUDA with 166 placements); --s-max 1024 is BASELINE.json configs[3]'s
+"2^22-constraint circuit" (SURVEY.md §8d cfg 4).  The circuit comes from tools/synth_circuit.py (random satisfying
+subcircuits, iden3 .r1cs files on disk, synthesizer documents handed over in memory); the CRS is the fixed-tau recipe
+(xy_powers[i * 2 s_max + j] = [tau_x^i tau_y^j]G built on the device), the binding tables are random multiples of G.
+--check runs the reference's testing-mode assertions (R1CS satisfaction, Lemma 3, quotient identities, zero remainders)
+at full size and compares three commitments with [P(tau_x, tau_y)]G.
+
+Prints one JSON line: seconds per stage (best of --repeat), constraint slots/s and real R1CS rows/s over init + rounds."""
+import argparse
+import json
+import os
+import random
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tokamak-zk-evm_amd"), os.path.join(ROOT, "tools")]
+
+PINS = json.load(open(os.path.join(ROOT, "tests", "golden", "pins.json")))       # the fixed tau / G of setup/trusted-setup/src/main.rs:68-80
+TAU_X, TAU_Y = int(PINS["tau_x"], 16), int(PINS["tau_y"], 16)
+
+
+def stage_crs(tkmk, sp, seed):
+    from tkmk.prove import fr
+    from tkmk.sigma import Sigma1
+    pins = PINS
+    g = np.frombuffer(int(pins["fixed_tau_g1_x"], 16).to_bytes(48, "little") + int(pins["fixed_tau_g1_y"], 16).to_bytes(48, "little"), np.uint8).copy()
+    m_i, s_max = sp["l_D"] - sp["l"], sp["s_max"]
+    rs_x, rs_y = max(2 * sp["n"], 2 * m_i), 2 * s_max
+    lib = tkmk.lib()
+    one = np.zeros(32, np.uint8)
+    one[0] = 1
+    ones = tkmk.DeviceBuffer.from_host(np.tile(one, rs_x * rs_y))
+    mon = tkmk.DeviceBuffer(32 * rs_x * rs_y)          # mon[i][j] = tau_x^i tau_y^j
+    tkmk._check(lib.tkmk_poly_scale_coeffs(tkmk._p(ones), rs_x, rs_y, tkmk._p(fr(TAU_X)), tkmk._p(fr(TAU_Y)), tkmk._p(mon), None),
+                "tkmk_poly_scale_coeffs")
+    sigma1 = Sigma1(tkmk.g1_batch_scalar_mul_device(mon, g, rs_x * rs_y), rs_x, rs_y)
+
+    def rand_pts(k, first):
+        return tkmk.g1_batch_scalar_mul_device(tkmk.fr_random_device(seed, k, first=first), g, k)
+
+    sizes = {"gamma_inv_o_inst": sp["l"], "eta_inv_li_o_inter_alpha4_kj": m_i * s_max, "delta_inv_li_o_prv": (sp["m_D"] - sp["l_D"]) * s_max,
+             "delta_inv_alphak_xh_tx": 9, "delta_inv_alpha4_xj_tx": 2, "delta_inv_alphak_yi_ty": 12}
+    tables, first = {}, 0
+    for name, k in sizes.items():
+        tables[name] = rand_pts(k, first)
+        first += k
+    two = rand_pts(2, first).to_host()
+    singles = {"delta": two[:96].copy(), "eta": two[96:].copy()}
+    return (sigma1, tables, singles), g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--s-max", type=int, default=256)
+    ap.add_argument("--placements", type=int, default=None, help="used placements (default: all s_max; the reference's run has 166)")
+    ap.add_argument("--pool", type=int, default=24, help="distinct gate witnesses")
+    ap.add_argument("--n-prv", type=int, default=3000)
+    ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--seed", type=int, default=0x746F6B616D616B04)
+    args = ap.parse_args()
+    import synth_circuit
+    import tkmk
+    from tkmk.prove import Prover, fr, random_mixer, run_rounds
+    tkmk.set_device(0)
+    t = time.perf_counter()
+    inst = synth_circuit.generate(random.Random(args.seed), s_max=args.s_max, n_gate_kinds=13, n_out=100, n_in=200, n_prv=args.n_prv, k_pub=85,
+                                  l_free=128, l_extra=600, n=4096, m_i=4096, pool=args.pool, used_placements=args.placements)
+    tmp = tempfile.mkdtemp(prefix="tkmk_prove_bench_")
+    synth_circuit.write(inst, tmp, synth_files=False)
+    sp = inst["setup_params"]
+    gen_s = time.perf_counter() - t
+    t = time.perf_counter()
+    sigma, g = stage_crs(tkmk, sp, args.seed)
+    tkmk.synchronize()
+    crs_s = time.perf_counter() - t
+    inputs = {"setup_params": sp, "subcircuit_infos": inst["infos"], "placement_variables": inst["placement_variables"],
+              "permutation": inst["permutation"], "instance": inst["instance"]}
+    slots = sp["n"] * sp["s_max"]
+    best, runs = None, []
+    for rep in range(args.repeat):
+        tkmk.synchronize()
+        t0 = time.perf_counter()
+        prover, binding = Prover.init_from(inputs, inst["qap"], mixer=random_mixer(random.Random(rep)), testing_mode=args.check, sigma=sigma)
+        tkmk.synchronize()
+        init_s = time.perf_counter() - t0
+        points, scalars, challenges, _, times = run_rounds(prover, binding)
+        total = time.perf_counter() - t0
+        rec = dict({k: round(v, 4) for k, v in prover.timing.items()}, **{k: round(v, 4) for k, v in times.items()})
+        rec["init"] = round(init_s, 4)
+        rec["rounds"] = round(sum(times.values()), 4)
+        rec["total"] = round(total, 4)
+        runs.append(rec)
+        if best is None or rec["total"] < best["total"]:
+            best = rec
+        if args.check and rep == 0:
+            # commit identity on three of the proof's polynomials: [P(tau_x, tau_y)]G through a 1-point MSM
+            for name, poly in (("B", prover.bXY + prover.cache["term_b_zk"]), ("R", None), ("A_free", prover.a_free_X)):
+                if poly is None:
+                    mx = prover.mixer
+                    poly = prover.rXY + (prover.t_mi.mul_scalar(fr(mx["rR_X"])) + prover.t_smax.mul_scalar(fr(mx["rR_Y"])))
+                want = tkmk.projective_to_affine_bytes(tkmk.msm(poly.eval(fr(TAU_X), fr(TAU_Y)), g))
+                assert (np.asarray(points[name]) == np.asarray(want)).all(), "commit identity fails for " + name
+        del prover
+    out = {"workload": "prove: synthetic circuit n=%d m_I=%d s_max=%d, %d placements, %d real R1CS rows" % (
+        sp["n"], sp["l_D"] - sp["l"], sp["s_max"], len(inst["placement_variables"]), inst["r1cs_rows"]),
+        "setup_params": sp, "constraint_slots": slots, "r1cs_rows": inst["r1cs_rows"], "seconds": best, "runs": runs,
+        "constraint_slots_per_s": round(slots / best["total"]), "r1cs_rows_per_s": round(inst["r1cs_rows"] / best["total"]),
+        "constraint_slots_per_s_rounds_only": round(slots / best["rounds"]),
+        "generate_s": round(gen_s, 2), "stage_crs_s": round(crs_s, 2), "checked": bool(args.check),
+        "reference_wall_s": {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md)"}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,4 @@
-"""Test infrastructure: a synthetic subcircuit library + synthesizer output with the file formats `prove` reads.
+"""Test / bench infrastructure (not product code): a synthetic subcircuit library + synthesizer output with the file formats `prove` reads.
 
 The reference ships no witness / proof fixtures (and its witness calculators are prebuilt wasm, which is never run here),
 so satisfying inputs are manufactured: random arithmetic subcircuits written as iden3 `.r1cs` v1 files (the format of
@@ -83,19 +83,21 @@ def random_gates(sid, rnd, n_out, n_in, n_prv, fan=3):
     return s
 
 
-def build(out_dir, rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub=2, used_placements=None, l_free=4, l_extra=4):
-    """writes <out_dir>/qap/{setupParams.json, subcircuitInfo.json, r1cs/subcircuit{id}.r1cs} and
-    <out_dir>/synth/{placementVariables.json, instance.json, permutation.json}; returns a dict describing the instance"""
-    qap, synth = os.path.join(out_dir, "qap"), os.path.join(out_dir, "synth")
-    os.makedirs(os.path.join(qap, "r1cs"), exist_ok=True)
-    os.makedirs(synth, exist_ok=True)
+def generate(rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub=2, used_placements=None, l_free=4, l_extra=4, n=None,
+             m_i=None, pool=None):
+    """-> the instance in memory (setup params, subcircuit infos, placements with witnesses, permutation, instance).
+    pool=K (production shapes): only K distinct gate witnesses are computed — every placement past the first K re-uses one
+    of them together with its input wiring, so generation stays at K forward evaluations however many placements there are;
+    the copy constraints (one cycle per consumed source wire) and R1CS satisfaction hold exactly as in the unpooled case."""
     subs = [buffer_pub_in(0, k_pub)] + [random_gates(1 + g, rnd, n_out, n_in, n_prv) for g in range(n_gate_kinds)]
     l_user = k_pub
     assert l_user <= l_free
     l = l_free + l_extra
     # interface wires: constant + outputs + inputs of every subcircuit (the public buffer's inputs are public wires)
     need_iface = sum(1 + s.n_out + (0 if s.id == 0 else s.n_in) for s in subs)
-    m_i = 1 << (need_iface - 1).bit_length()
+    if m_i is None:
+        m_i = 1 << (need_iface - 1).bit_length()
+    assert need_iface <= m_i and m_i & (m_i - 1) == 0
     l_D = l + m_i
     nxt_iface, nxt_prv = l, l_D
     for s in subs:
@@ -116,41 +118,69 @@ def build(out_dir, rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub
             nxt_prv += 1
         s.flatten_map = fm
     m_D = nxt_prv
-    n = 1 << (max(len(s.rows) for s in subs) - 1).bit_length()
+    n_min = 1 << (max(len(s.rows) for s in subs) - 1).bit_length()
+    n = n_min if n is None else n
+    assert n >= n_min
     sp = {"l_free": l_free, "l_user_out": 0, "l_user": l_user, "l": l, "l_D": l_D, "m_D": m_D, "n": n, "s_D": len(subs), "s_max": s_max}
     infos = [{"id": s.id, "name": s.name, "Nwires": s.n_wires, "Nconsts": len(s.rows), "Out_idx": [1, s.n_out],
               "In_idx": [1 + s.n_out, s.n_in], "flattenMap": s.flatten_map} for s in subs]
-    for s in subs:
-        write_r1cs(os.path.join(qap, "r1cs", "subcircuit%d.r1cs" % s.id), s.n_wires, s.rows)
-    json.dump(sp, open(os.path.join(qap, "setupParams.json"), "w"))
-    json.dump(infos, open(os.path.join(qap, "subcircuitInfo.json"), "w"))
 
     # placements: 0 = the public buffer, then gates fed by earlier outputs; every feed is a copy constraint
     used = s_max if used_placements is None else used_placements
+    hx = lambda v: "0x%x" % v                                                        # noqa: E731
     pub_vals = [rnd.randrange(R) for _ in range(k_pub)]
     placements = [(subs[0], subs[0].witness(pub_vals))]
+    hexes = [[hx(v) for v in placements[0][1]]]
+    sources = [None]                                  # per placement: the (placement, wire) feeding each input
     produced = [(0, w) for w in subs[0].outs()]       # (placement, local wire) whose value may be consumed
     consumers = {}                                    # source (placement, wire) -> [(placement, wire), ...]
     for p in range(1, used):
-        s = subs[1 + rnd.randrange(n_gate_kinds)]
-        srcs = [rnd.choice(produced) for _ in s.ins()]
-        w = s.witness([placements[sp_][1][sw] for sp_, sw in srcs])
+        if pool is not None and p > pool:
+            q = 1 + rnd.randrange(pool)               # same subcircuit, same sources, same witness as placement q
+            s, w, srcs = placements[q][0], placements[q][1], sources[q]
+            hexes.append(hexes[q])
+        else:
+            s = subs[1 + rnd.randrange(n_gate_kinds)]
+            srcs = [rnd.choice(produced) for _ in s.ins()]
+            w = s.witness([placements[sp_][1][sw] for sp_, sw in srcs])
+            hexes.append([hx(v) for v in w])
+            produced += [(p, o) for o in s.outs()]
         placements.append((s, w))
+        sources.append(srcs)
         for src, dst in zip(srcs, s.ins()):
             consumers.setdefault(src, []).append((p, dst))
-        produced += [(p, o) for o in s.outs()]
     cell = lambda pl, wire: (placements[pl][0].flatten_map[wire] - l, pl)              # noqa: E731   (row, col)
     perm = []
     for src, dsts in consumers.items():
         cyc = [cell(*src)] + [cell(*d) for d in dsts]
         for a, b in zip(cyc, cyc[1:] + cyc[:1]):
             perm.append({"row": a[0], "col": a[1], "X": b[0], "Y": b[1]})
-    hx = lambda v: "0x%x" % v                                                        # noqa: E731
-    pv = [{"subcircuitId": s.id, "variables": [hx(v) for v in w]} for s, w in placements]
+    pv = [{"subcircuitId": s.id, "variables": h} for (s, _), h in zip(placements, hexes)]
     instance = {"a_pub_user": [hx(v) for v in pub_vals], "a_pub_block": [hx(rnd.randrange(R)) for _ in range(l_free - l_user)],
                 "a_pub_function": [hx(rnd.randrange(R)) for _ in range(l - l_free)]}
-    json.dump(pv, open(os.path.join(synth, "placementVariables.json"), "w"))
-    json.dump(instance, open(os.path.join(synth, "instance.json"), "w"))
-    json.dump(perm, open(os.path.join(synth, "permutation.json"), "w"))
-    return {"qap": qap, "synth": synth, "setup_params": sp, "infos": infos, "subs": subs, "placements": placements,
-            "placement_variables": pv, "instance": instance, "permutation": perm, "m_i": m_i}
+    return {"setup_params": sp, "infos": infos, "subs": subs, "placements": placements, "placement_variables": pv,
+            "instance": instance, "permutation": perm, "m_i": m_i,
+            "r1cs_rows": sum(len(s.rows) for s, _ in placements)}
+
+
+def write(inst, out_dir, synth_files=True):
+    """<out_dir>/qap/{setupParams.json, subcircuitInfo.json, r1cs/subcircuit{id}.r1cs} and, unless synth_files is False,
+    <out_dir>/synth/{placementVariables.json, instance.json, permutation.json}"""
+    qap, synth = os.path.join(out_dir, "qap"), os.path.join(out_dir, "synth")
+    os.makedirs(os.path.join(qap, "r1cs"), exist_ok=True)
+    for s in inst["subs"]:
+        write_r1cs(os.path.join(qap, "r1cs", "subcircuit%d.r1cs" % s.id), s.n_wires, s.rows)
+    json.dump(inst["setup_params"], open(os.path.join(qap, "setupParams.json"), "w"))
+    json.dump(inst["infos"], open(os.path.join(qap, "subcircuitInfo.json"), "w"))
+    inst["qap"] = qap
+    if synth_files:
+        os.makedirs(synth, exist_ok=True)
+        json.dump(inst["placement_variables"], open(os.path.join(synth, "placementVariables.json"), "w"))
+        json.dump(inst["instance"], open(os.path.join(synth, "instance.json"), "w"))
+        json.dump(inst["permutation"], open(os.path.join(synth, "permutation.json"), "w"))
+        inst["synth"] = synth
+    return inst
+
+
+def build(out_dir, rnd, **shape):
+    return write(generate(rnd, **shape), out_dir)
