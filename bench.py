@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true", help="skip the secondary NTT measurements (BASELINE.json configs[2], _biNTT)")
     ap.add_argument("--no-bn254", action="store_true", help="skip the secondary BN254 G1 MSM measurement (BASELINE.json configs[1] as worded)")
+    ap.add_argument("--no-prove", action="store_true",
+                    help="skip the full-prove measurements (BASELINE.json configs[3] and the reference's production shape)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
@@ -157,7 +159,7 @@ def main():
                               "frac": n * ADDS_PER_POINT * MADS_PER_BUCKET_ADD / (kernel_ms * 1e-3) / MAD_PEAK_PER_S},
         }
         if world > 1:      # the CPU baseline and the secondary figures are N = 1 material; keep the scaling runs lean
-            args.no_cpu_baseline = args.no_bn254 = args.no_ntt = True
+            args.no_cpu_baseline = args.no_bn254 = args.no_ntt = args.no_prove = True
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(tkmk, args.cpu_sample_logn)
         if not args.no_bn254 or not args.no_ntt:
@@ -167,6 +169,8 @@ def main():
             out["bn254_msm"] = _bn254_secondary(tkmk, args.logn)
         if not args.no_ntt:
             out["ntt"] = _ntt_secondary(tkmk)
+        if not args.no_prove:
+            out["prove"] = _prove_secondary(tkmk)
         out["result_x_lo"] = int.from_bytes(bytes(result[:8]), "little")
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -263,6 +267,26 @@ def _ntt_secondary(tkmk):
     except Exception as e:  # secondary figure: never fail the headline line
         res["error"] = str(e)
     return res
+
+
+def _prove_secondary(tkmk):
+    """BASELINE.json's "constraints/sec (prove step)": the whole prover (tkmk/prove.py: init + prove0..prove4, every
+    polynomial and commitment on the device) on synthetic satisfying circuits (tools/synth_circuit.py, fixed-tau CRS), at
+    the reference's production shape with its placement count (2^20 constraint slots; reference walls 45.70 s CPU / 21.08 s
+    CUDA on other hardware) and at configs[3]'s 2^22 slots (s_max = 1024, every placement used).
+    constraints_per_s = constraint slots / (init + rounds) wall, host glue included."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import prove_bench
+    out = {}
+    for key, kw in (("production_2p20", dict(s_max=256, placements=166, repeat=3)), ("configs3_2p22", dict(s_max=1024, repeat=2))):
+        r = prove_bench.run(**kw)
+        out[key] = {"workload": r["workload"], "constraints_per_s": r["constraint_slots_per_s"], "r1cs_rows_per_s": r["r1cs_rows_per_s"],
+                    "wall_s": r["seconds"]["total"], "init_s": r["seconds"]["init"], "rounds_s": r["seconds"]["rounds"],
+                    "per_round_s": {k: r["seconds"][k] for k in ("prove0", "prove1", "prove2", "prove3", "prove4")},
+                    "constraint_slots": r["constraint_slots"], "r1cs_rows": r["r1cs_rows"]}
+        tkmk.release_scratch()
+    out["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md §1)"}
+    return out
 
 
 def _usable_cpus(omp_threads):

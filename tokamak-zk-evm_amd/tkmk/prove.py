@@ -24,7 +24,7 @@ import tkmk
 from tkmk import binding as _binding
 from tkmk import proofio
 from tkmk.poly import DensePolynomialExt, PolyExpr
-from tkmk.r1cs import R_MOD, read_R1CS_gen_uvwXY
+from tkmk.r1cs import R_MOD, PlacementValues, read_R1CS_gen_uvwXY
 from tkmk.transcript import TranscriptManager
 from tkmk.witness import gen_a_free_X, gen_bXY, permutation_to_poly
 
@@ -180,8 +180,9 @@ class Prover:
         self.timing["init.load"] = time.perf_counter() - t0
 
         t1 = time.perf_counter()
-        self.bXY = gen_bXY(placement_variables, subcircuit_infos, sp)
-        self.uXY, self.vXY, self.wXY = read_R1CS_gen_uvwXY(qap_path, placement_variables, subcircuit_infos, sp)
+        values = PlacementValues(placement_variables)                          # every hex string parsed once
+        self.bXY = gen_bXY(placement_variables, subcircuit_infos, sp, values)
+        self.uXY, self.vXY, self.wXY = read_R1CS_gen_uvwXY(qap_path, placement_variables, subcircuit_infos, sp, values)
         self.rXY = DensePolynomialExt.zero()
         self.q = {}
         self.cache = {}
@@ -211,10 +212,10 @@ class Prover:
         t2 = time.perf_counter()
         host = lambda name: tables[name].to_host().reshape(-1, 96) if isinstance(tables[name], tkmk.DeviceBuffer) else np.asarray(tables[name], np.uint8).reshape(-1, 96)   # noqa: E731
         A_free = sigma1.encode_poly(self.a_free_X)
-        O_pub_free = _binding.encode_O_pub_free(tables["gamma_inv_o_inst"], placement_variables, subcircuit_infos, sp)
-        O_mid_core = _binding.encode_O_mid_no_zk(tables["eta_inv_li_o_inter_alpha4_kj"], placement_variables, subcircuit_infos, sp)
+        O_pub_free = _binding.encode_O_pub_free(tables["gamma_inv_o_inst"], placement_variables, subcircuit_infos, sp, values)
+        O_mid_core = _binding.encode_O_mid_no_zk(tables["eta_inv_li_o_inter_alpha4_kj"], placement_variables, subcircuit_infos, sp, values)
         O_mid = g1_lincomb([(1, O_mid_core), (mx["rO_mid"], singles["delta"])])
-        O_prv_core = _binding.encode_O_prv_no_zk(tables["delta_inv_li_o_prv"], placement_variables, subcircuit_infos, sp)
+        O_prv_core = _binding.encode_O_prv_no_zk(tables["delta_inv_li_o_prv"], placement_variables, subcircuit_infos, sp, values)
         xh, xj, yi = host("delta_inv_alphak_xh_tx"), host("delta_inv_alpha4_xj_tx"), host("delta_inv_alphak_yi_ty")
         O_prv = g1_lincomb([                                                  # lib.rs:1146-1160
             (1, O_prv_core), (R - mx["rO_mid"], singles["eta"]),

@@ -113,6 +113,88 @@ class R1csBinary:
             raise R1csError("R1CS constraints section has %d trailing bytes" % max(0, end - off))
 
 
+    def csr(self):
+        """A, B, C as CSR triples (row_ptr u32, wire u32, coeff bytes), coefficients reduced mod r: the same walk and the same
+        errors as scan_constraints, with each linear combination read as one numpy record array"""
+        data, off = self.data, self.constraints_offset
+        end = self.constraints_offset + self.constraints_size
+        fs = self.field_size
+        if fs != 32:
+            return self._csr_slow()
+        rec = np.dtype([("w", "<u4"), ("c", np.uint8, (32,))])
+        ptr = [[0] for _ in range(3)]
+        parts = [[] for _ in range(3)]
+        unpack = struct.unpack_from
+        n = len(data)
+        for _ in range(self.n_constraints):
+            for m in range(3):
+                if off + 4 > n:
+                    raise R1csError("unexpected end of R1CS file")
+                cnt = unpack("<I", data, off)[0]
+                off += 4
+                if off + cnt * 36 > n:
+                    raise R1csError("unexpected end of R1CS file")
+                if cnt:
+                    parts[m].append(np.frombuffer(data, rec, cnt, off))
+                    off += cnt * 36
+                ptr[m].append(ptr[m][-1] + cnt)
+        if off != end:
+            raise R1csError("R1CS constraints section has %d trailing bytes" % max(0, end - off))
+        out = []
+        for m in range(3):
+            a = np.concatenate(parts[m]) if parts[m] else np.zeros(0, rec)
+            if a.size and int(a["w"].max()) >= self.n_wires:
+                raise R1csError("R1CS wire index %d exceeds nWires %d" % (int(a["w"].max()), self.n_wires))
+            coeff = _reduce_le32(np.ascontiguousarray(a["c"]).reshape(-1, 32)).reshape(-1)
+            out.append((np.array(ptr[m], np.uint32), np.ascontiguousarray(a["w"]), coeff))
+        return out
+
+    def _csr_slow(self):
+        rows = [[[] for _ in range(self.n_constraints)] for _ in range(3)]
+        for m, wire, coeff, row in self.scan_constraints():
+            rows[m][row].append((wire, int.from_bytes(coeff, "little") % R_MOD))
+        csr = []
+        for m in range(3):
+            ptr, wires, coeffs = [0], [], []
+            for r in rows[m]:
+                for wire, v in r:
+                    wires.append(wire)
+                    coeffs.append(v)
+                ptr.append(len(wires))
+            cb = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in coeffs), np.uint8).copy() if coeffs else np.zeros(0, np.uint8)
+            csr.append((np.array(ptr, np.uint32), np.array(wires, np.uint32), cb))
+        return csr
+
+
+def _reduce_le32(rows):
+    """(N, 32) little-endian values -> the same reduced mod r (ScalarField::from_bytes_le); only the rare rows >= r are touched"""
+    if rows.shape[0] == 0:
+        return rows
+    limbs = np.ascontiguousarray(rows).view("<u8").reshape(-1, 4)
+    r4 = [(R_MOD >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+    gt = np.zeros(limbs.shape[0], bool)
+    eq = np.ones(limbs.shape[0], bool)
+    for k in (3, 2, 1, 0):
+        gt |= eq & (limbs[:, k] > r4[k])
+        eq &= limbs[:, k] == r4[k]
+    for i in np.nonzero(gt | eq)[0]:
+        rows[i] = np.frombuffer((int.from_bytes(rows[i].tobytes(), "little") % R_MOD).to_bytes(32, "little"), np.uint8)
+    return rows
+
+
+def hex_list_to_fr32(hexes):
+    """[HexString, ...] -> (N, 32) uint8 little-endian Fr records, each ScalarField::from_hex (mod.rs:126-146) of its entry;
+    one bytes.fromhex over the whole list instead of one big-int conversion per element"""
+    try:
+        txt = "".join((h[2:] if h[:2] in ("0x", "0X") else h).rjust(64, "0") for h in hexes)
+        if len(txt) != 64 * len(hexes):
+            raise ValueError
+        be = np.frombuffer(bytes.fromhex(txt), np.uint8).reshape(-1, 32)
+    except ValueError:                                   # an entry longer than 256 bits (or odd text): element-wise route
+        return np.frombuffer(b"".join(hex_to_fr(h).to_bytes(32, "little") for h in hexes), np.uint8).reshape(-1, 32).copy()
+    return _reduce_le32(np.ascontiguousarray(be[:, ::-1]))
+
+
 class SubcircuitR1CS:
     """sparse rows of A, B, C as CSR (row_ptr, wire, coeff) — from_r1cs_sparse_only (mod.rs:685-760)"""
 
@@ -129,21 +211,7 @@ class SubcircuitR1CS:
             raise R1csError("R1CS nConstraints mismatch for subcircuit %d: binary=%d, info=%d" % (info["id"], b.n_constraints, info["Nconsts"]))
         if setup_params["n"] < info["Nconsts"]:
             raise R1csError("n is smaller than the actual number of constraints.")
-        rows = [[[] for _ in range(b.n_constraints)] for _ in range(3)]
-        for m, wire, coeff, row in b.scan_constraints():
-            v = int.from_bytes(coeff, "little") % R_MOD          # ScalarField::from_bytes_le
-            rows[m][row].append((wire, v))
-        csr = []
-        for m in range(3):
-            ptr, wires, coeffs = [0], [], []
-            for r in rows[m]:
-                for wire, v in r:
-                    wires.append(wire)
-                    coeffs.append(v)
-                ptr.append(len(wires))
-            cb = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in coeffs), np.uint8).copy() if coeffs else np.zeros(0, np.uint8)
-            csr.append((np.array(ptr, np.uint32), np.array(wires, np.uint32), cb))
-        return cls(b.n_wires, b.n_constraints, csr)
+        return cls(b.n_wires, b.n_constraints, b.csr())
 
     def active_wires(self, m):
         return sorted(set(int(w) for w in self.csr[m][1]))
@@ -165,9 +233,22 @@ def hex_to_fr(h):
     return (int(h, 16) if h else 0) % R_MOD
 
 
-def read_R1CS_gen_uvwXY(qap_path, placement_variables, subcircuit_infos, setup_params):
+class PlacementValues:
+    """the `variables` of every placement parsed once into (Nwires, 32) little-endian Fr records; gen_bXY, the u/v/w
+    evaluation and the three binding commitments all read the same hex strings (the reference parses them in each:
+    libs/src/polynomial_structures/mod.rs:150, libs/src/iotools/mod.rs:1373, libs/src/group_structures/mod.rs:213,285)"""
+
+    def __init__(self, placement_variables):
+        self.rows = [hex_list_to_fr32(pl["variables"]) for pl in placement_variables]
+
+    def __getitem__(self, i):
+        return self.rows[i]
+
+
+def read_R1CS_gen_uvwXY(qap_path, placement_variables, subcircuit_infos, setup_params, values=None):
     """placement_variables: list of {"subcircuitId": id, "variables": [hex, ...]} (synthesizer output);
     returns (uXY, vXY, wXY) as device-resident DensePolynomialExt of size n x s_max"""
+    values = PlacementValues(placement_variables) if values is None else values
     n, s_max = setup_params["n"], setup_params["s_max"]
     if len(placement_variables) > s_max:
         raise ValueError("placement_variables length exceeds s_max.")
@@ -182,8 +263,7 @@ def read_R1CS_gen_uvwXY(qap_path, placement_variables, subcircuit_infos, setup_p
     lib = tkmk.lib()
     for sid, slots in by_id.items():
         r1cs = SubcircuitR1CS.from_r1cs_sparse_only(os.path.join(qap_path, "r1cs", "subcircuit%d.r1cs" % sid), setup_params, infos[sid])
-        var = np.frombuffer(b"".join(hex_to_fr(h).to_bytes(32, "little") for i in slots for h in placement_variables[i]["variables"]),
-                            np.uint8).copy()
+        var = np.concatenate([values[i] for i in slots]).reshape(-1)
         if var.size != 32 * len(slots) * r1cs.n_wires:
             raise ValueError("placement variable count does not match nWires of subcircuit %d" % sid)
         d_var = tkmk.DeviceBuffer.from_host(var)

@@ -14,18 +14,24 @@ def _fr_bytes(vals):
     return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), np.uint8).copy()
 
 
-def gen_bXY(placement_variables, subcircuit_infos, setup_params):
+def gen_bXY(placement_variables, subcircuit_infos, setup_params, values=None):
+    from tkmk.r1cs import PlacementValues
     l, l_d, s_max = setup_params["l"], setup_params["l_D"], setup_params["s_max"]
     m_i = l_d - l
     infos = {e["id"]: e for e in subcircuit_infos}
+    values = PlacementValues(placement_variables) if values is None else values
     w = np.zeros((m_i * s_max, 32), np.uint8)
+    sel = {}                                             # per subcircuit: local wires on the interface range and their rows
     for i, pl in enumerate(placement_variables):
-        flat = infos[pl["subcircuitId"]]["flattenMap"]
-        if len(pl["variables"]) != len(flat):
+        sid = pl["subcircuitId"]
+        if sid not in sel:
+            fm = np.asarray(infos[sid]["flattenMap"], np.int64)
+            loc = np.nonzero((fm >= l) & (fm < l_d))[0]
+            sel[sid] = (len(fm), loc, (fm[loc] - l) * s_max)
+        n_wires, loc, rows = sel[sid]
+        if len(pl["variables"]) != n_wires:
             raise ValueError("Corrupted placement variables.")
-        for g, val in zip(flat, pl["variables"]):
-            if l <= g < l_d and val != "0x0":
-                w[(g - l) * s_max + i] = np.frombuffer(hex_to_fr(val).to_bytes(32, "little"), np.uint8)
+        w[rows + i] = values[i][loc]                     # a "0x0" entry is a zero record either way (mod.rs:150-152)
     return DensePolynomialExt.from_rou_evals(w.reshape(-1), m_i, s_max)
 
 
@@ -49,7 +55,10 @@ def permutation_to_poly(perm_raw, m_i, s_max):
     yb = _fr_bytes(yp).reshape(s_max, 32)
     s0 = np.repeat(xb[:, None, :], s_max, axis=1).copy()        # s0[row][col] = wx^row
     s1 = np.repeat(yb[None, :, :], m_i, axis=0).copy()          # s1[row][col] = wy^col
-    for p in perm_raw:
-        s0[p["row"], p["col"]] = xb[p["X"]]
-        s1[p["row"], p["col"]] = yb[p["Y"]]
+    if perm_raw:                                          # one scatter for all entries (mod.rs:440-449 loops over them)
+        k = len(perm_raw)
+        col = lambda key: np.fromiter((p[key] for p in perm_raw), np.int64, k)          # noqa: E731
+        rows, cols = col("row"), col("col")
+        s0[rows, cols] = xb[col("X")]
+        s1[rows, cols] = yb[col("Y")]
     return (DensePolynomialExt.from_rou_evals(s0.reshape(-1), m_i, s_max), DensePolynomialExt.from_rou_evals(s1.reshape(-1), m_i, s_max))

@@ -56,39 +56,29 @@ def stage_crs(tkmk, sp, seed):
     return (sigma1, tables, singles), g
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--s-max", type=int, default=256)
-    ap.add_argument("--placements", type=int, default=None, help="used placements (default: all s_max; the reference's run has 166)")
-    ap.add_argument("--pool", type=int, default=24, help="distinct gate witnesses")
-    ap.add_argument("--n-prv", type=int, default=3000)
-    ap.add_argument("--repeat", type=int, default=3)
-    ap.add_argument("--check", action="store_true")
-    ap.add_argument("--seed", type=int, default=0x746F6B616D616B04)
-    args = ap.parse_args()
+def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, seed=0x746F6B616D616B04):
     import synth_circuit
     import tkmk
     from tkmk.prove import Prover, fr, random_mixer, run_rounds
-    tkmk.set_device(0)
     t = time.perf_counter()
-    inst = synth_circuit.generate(random.Random(args.seed), s_max=args.s_max, n_gate_kinds=13, n_out=100, n_in=200, n_prv=args.n_prv, k_pub=85,
-                                  l_free=128, l_extra=600, n=4096, m_i=4096, pool=args.pool, used_placements=args.placements)
+    inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=13, n_out=100, n_in=200, n_prv=n_prv, k_pub=85,
+                                  l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements)
     tmp = tempfile.mkdtemp(prefix="tkmk_prove_bench_")
     synth_circuit.write(inst, tmp, synth_files=False)
     sp = inst["setup_params"]
     gen_s = time.perf_counter() - t
     t = time.perf_counter()
-    sigma, g = stage_crs(tkmk, sp, args.seed)
+    sigma, g = stage_crs(tkmk, sp, seed)
     tkmk.synchronize()
     crs_s = time.perf_counter() - t
     inputs = {"setup_params": sp, "subcircuit_infos": inst["infos"], "placement_variables": inst["placement_variables"],
               "permutation": inst["permutation"], "instance": inst["instance"]}
     slots = sp["n"] * sp["s_max"]
     best, runs = None, []
-    for rep in range(args.repeat):
+    for rep in range(repeat):
         tkmk.synchronize()
         t0 = time.perf_counter()
-        prover, binding = Prover.init_from(inputs, inst["qap"], mixer=random_mixer(random.Random(rep)), testing_mode=args.check, sigma=sigma)
+        prover, binding = Prover.init_from(inputs, inst["qap"], mixer=random_mixer(random.Random(rep)), testing_mode=check, sigma=sigma)
         tkmk.synchronize()
         init_s = time.perf_counter() - t0
         points, scalars, challenges, _, times = run_rounds(prover, binding)
@@ -100,7 +90,7 @@ def main():
         runs.append(rec)
         if best is None or rec["total"] < best["total"]:
             best = rec
-        if args.check and rep == 0:
+        if check and rep == 0:
             # commit identity on three of the proof's polynomials: [P(tau_x, tau_y)]G through a 1-point MSM
             for name, poly in (("B", prover.bXY + prover.cache["term_b_zk"]), ("R", None), ("A_free", prover.a_free_X)):
                 if poly is None:
@@ -109,13 +99,29 @@ def main():
                 want = tkmk.projective_to_affine_bytes(tkmk.msm(poly.eval(fr(TAU_X), fr(TAU_Y)), g))
                 assert (np.asarray(points[name]) == np.asarray(want)).all(), "commit identity fails for " + name
         del prover
-    out = {"workload": "prove: synthetic circuit n=%d m_I=%d s_max=%d, %d placements, %d real R1CS rows" % (
+    del sigma
+    return {"workload": "prove (init + prove0..4): synthetic circuit n=%d m_I=%d s_max=%d, %d placements, %d real R1CS rows" % (
         sp["n"], sp["l_D"] - sp["l"], sp["s_max"], len(inst["placement_variables"]), inst["r1cs_rows"]),
         "setup_params": sp, "constraint_slots": slots, "r1cs_rows": inst["r1cs_rows"], "seconds": best, "runs": runs,
         "constraint_slots_per_s": round(slots / best["total"]), "r1cs_rows_per_s": round(inst["r1cs_rows"] / best["total"]),
         "constraint_slots_per_s_rounds_only": round(slots / best["rounds"]),
-        "generate_s": round(gen_s, 2), "stage_crs_s": round(crs_s, 2), "checked": bool(args.check),
-        "reference_wall_s": {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md)"}}
+        "generate_s": round(gen_s, 2), "stage_crs_s": round(crs_s, 2), "checked": bool(check)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--s-max", type=int, default=256)
+    ap.add_argument("--placements", type=int, default=None, help="used placements (default: all s_max; the reference's run has 166)")
+    ap.add_argument("--pool", type=int, default=24, help="distinct gate witnesses")
+    ap.add_argument("--n-prv", type=int, default=3000)
+    ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--seed", type=int, default=0x746F6B616D616B04)
+    args = ap.parse_args()
+    import tkmk
+    tkmk.set_device(0)
+    out = run(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.check, args.seed)
+    out["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md)"}
     print(json.dumps(out))
 
 
