@@ -87,6 +87,9 @@ tkmk_error tkmk_release_scratch(void);
 const char *tkmk_error_string(tkmk_error e);
 /* 1 if libtkmk_hip.so was built with gfx950 code objects (always, for this library) */
 int tkmk_is_hip_build(void);
+/* host-only: Keccak-256 (original 0x01 padding), the hash of the Fiat-Shamir transcript — replaces the tiny_keccak calls of
+ * RollingKeccakTranscript::update / get_challenge_raw (prove/src/lib.rs:3247-3394); no device is touched */
+tkmk_error tkmk_keccak256(const uint8_t *data, size_t len, uint8_t out[32]);
 
 /* ---------------------------------------------------------------------------------------------
  * MSM — replaces icicle_core::msm::msm<G1> (extern "C" bls12_381_msm in ICICLE v3) as called at

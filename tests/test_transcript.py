@@ -14,6 +14,17 @@ from tkmk import proofio  # noqa: E402
 from tkmk.transcript import RollingKeccakTranscript, TranscriptManager, keccak256  # noqa: E402
 
 
+def test_native_keccak_equals_python_permutation():
+    """tkmk_keccak256 (csrc/hostutil.hip, host-only) against the pure-Python sponge on every block-boundary length"""
+    import random
+    from tkmk.transcript import keccak256_py
+    rnd = random.Random(7)
+    for n in list(range(0, 140)) + [271, 272, 273, 1000]:
+        data = bytes(rnd.randrange(256) for _ in range(n))
+        assert keccak256(data) == keccak256_py(data), n
+    assert keccak256_py(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+
+
 def test_keccak256_known_answers():
     assert keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
     assert keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"

@@ -44,6 +44,14 @@ def _coeffs(vals, x_size, y_size):
     return DensePolynomialExt.from_coeffs(np.concatenate([fr(v) for v in vals]), x_size, y_size)
 
 
+def _sparse(entries, x_size, y_size):
+    """coefficient vector of x_size * y_size zeros with a few {index: value} entries"""
+    buf = np.zeros((x_size * y_size, 32), np.uint8)
+    for i, v in entries.items():
+        buf[i] = fr(v)
+    return DensePolynomialExt.from_coeffs(buf.reshape(-1), x_size, y_size)
+
+
 def poly_comb(*terms):
     """poly_comb! (lib.rs:30-38): sum of c_i * p_i"""
     acc = None
@@ -55,24 +63,24 @@ def poly_comb(*terms):
 
 def low_degree_x_times_vanishing(coeffs, exponent):
     """lib.rs:48-57: (sum c_i X^i) * (X^exponent - 1)"""
-    assert exponent > 0
+    assert exponent > 0 and len(coeffs) <= exponent
     x_size = 1 << (exponent + len(coeffs) - 1).bit_length()
-    out = [0] * x_size
+    entries = {}
     for i, c in enumerate(coeffs):
-        out[i] = (out[i] - c) % R
-        out[i + exponent] = (out[i + exponent] + c) % R
-    return _coeffs(out, x_size, 1)
+        entries[i] = (R - c) % R
+        entries[i + exponent] = c % R
+    return _sparse(entries, x_size, 1)
 
 
 def low_degree_y_times_vanishing(coeffs, exponent):
     """lib.rs:59-68"""
-    assert exponent > 0
+    assert exponent > 0 and len(coeffs) <= exponent
     y_size = 1 << (exponent + len(coeffs) - 1).bit_length()
-    out = [0] * y_size
+    entries = {}
     for i, c in enumerate(coeffs):
-        out[i] = (out[i] - c) % R
-        out[i + exponent] = (out[i + exponent] + c) % R
-    return _coeffs(out, 1, y_size)
+        entries[i] = (R - c) % R
+        entries[i + exponent] = c % R
+    return _sparse(entries, 1, y_size)
 
 
 def mul_by_x_minus_one(poly):
@@ -108,9 +116,7 @@ def mul_by_term9(poly, rB_X, rB_Y, t_mi_eval, t_smax_eval):
 
 def _vanishing(size, x_axis):
     """t(X) = X^size - 1 on 2*size coefficients (lib.rs:849-894)"""
-    c = [0] * (2 * size)
-    c[0], c[size] = R - 1, 1
-    return _coeffs(c, 2 * size, 1) if x_axis else _coeffs(c, 1, 2 * size)
+    return _sparse({0: R - 1, size: 1}, 2 * size, 1) if x_axis else _sparse({0: R - 1, size: 1}, 1, 2 * size)
 
 
 def _unit_evals(size, index, x_axis):
@@ -126,6 +132,16 @@ def g1_lincomb(terms):
     sc = np.concatenate([fr(s) for s, _ in terms])
     pts = np.concatenate([np.asarray(p, np.uint8).reshape(96) for _, p in terms])
     return tkmk.projective_to_affine_bytes(tkmk.msm(sc, pts))
+
+
+def g1_lincombs(rows):
+    """several equally long linear combinations in ONE batched MSM call (independent bases per row) -> [96-byte affine, ...]"""
+    k = len(rows[0])
+    assert all(len(r) == k for r in rows)
+    sc = np.concatenate([fr(s) for r in rows for s, _ in r])
+    pts = np.concatenate([np.asarray(p, np.uint8).reshape(96) for r in rows for _, p in r])
+    res = tkmk.projective_to_affine_bytes(tkmk.msm(sc, pts, msm_size=k, batch=len(rows), shared_points=False))
+    return [np.array(res[96 * i:96 * (i + 1)]) for i in range(len(rows))]
 
 
 def random_mixer(rng=None):
@@ -448,9 +464,9 @@ class Prover:
         Pi_AX, Pi_AY, M_X, M_Y, N_X, N_Y, Pi_CX, Pi_CY, Pi_B0 = self.sigma1.encode_polys(
             [Pi_AX_XY, Pi_AY_XY, M_X_XY, M_Y_XY, N_X_XY, N_Y_XY, Pi_CX_XY, Pi_CY_XY, pi_B_XY])
         k1_4 = k1_2 * k1_2 % R
-        Pi_B = g1_lincomb([(k1_4, Pi_B0)])
-        Pi_X = g1_lincomb([(1, Pi_AX), (1, Pi_CX), (k1_4, Pi_B0)])                   # lib.rs:3183-3184
-        Pi_Y = g1_lincomb([(1, Pi_AY), (1, Pi_CY)])
+        Pi_B, Pi_X, Pi_Y = g1_lincombs([[(k1_4, Pi_B0), (0, Pi_B0), (0, Pi_B0)],     # encode(pi_B) * kappa1^4 (lib.rs:3180)
+                                        [(1, Pi_AX), (1, Pi_CX), (k1_4, Pi_B0)],      # lib.rs:3183-3184
+                                        [(1, Pi_AY), (1, Pi_CY), (0, Pi_AY)]])
         proof4 = {"Pi_X": Pi_X, "Pi_Y": Pi_Y, "M_X": M_X, "M_Y": M_Y, "N_X": N_X, "N_Y": N_Y}
         proof4_test = {"Pi_CX": Pi_CX, "Pi_CY": Pi_CY, "Pi_AX": Pi_AX, "Pi_AY": Pi_AY, "Pi_B": Pi_B, "M_X": M_X, "M_Y": M_Y, "N_X": N_X, "N_Y": N_Y}
         return proof4, proof4_test

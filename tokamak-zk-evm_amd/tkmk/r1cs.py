@@ -10,6 +10,7 @@ import ctypes
 import json
 import os
 import struct
+from itertools import repeat as _repeat
 
 import numpy as np
 
@@ -121,9 +122,9 @@ class R1csBinary:
         fs = self.field_size
         if fs != 32:
             return self._csr_slow()
-        rec = np.dtype([("w", "<u4"), ("c", np.uint8, (32,))])
-        ptr = [[0] for _ in range(3)]
-        parts = [[] for _ in range(3)]
+        # pass 1 (sequential by format): the count word of every linear combination -> its start offset and length
+        starts = [[] for _ in range(3)]
+        counts = [[] for _ in range(3)]
         unpack = struct.unpack_from
         n = len(data)
         for _ in range(self.n_constraints):
@@ -132,21 +133,28 @@ class R1csBinary:
                     raise R1csError("unexpected end of R1CS file")
                 cnt = unpack("<I", data, off)[0]
                 off += 4
-                if off + cnt * 36 > n:
+                starts[m].append(off)
+                counts[m].append(cnt)
+                off += cnt * 36
+                if off > n:
                     raise R1csError("unexpected end of R1CS file")
-                if cnt:
-                    parts[m].append(np.frombuffer(data, rec, cnt, off))
-                    off += cnt * 36
-                ptr[m].append(ptr[m][-1] + cnt)
         if off != end:
             raise R1csError("R1CS constraints section has %d trailing bytes" % max(0, end - off))
+        # pass 2: all (wire, coefficient) records of one matrix in a single gather
+        raw = np.frombuffer(data, np.uint8)
         out = []
         for m in range(3):
-            a = np.concatenate(parts[m]) if parts[m] else np.zeros(0, rec)
-            if a.size and int(a["w"].max()) >= self.n_wires:
-                raise R1csError("R1CS wire index %d exceeds nWires %d" % (int(a["w"].max()), self.n_wires))
-            coeff = _reduce_le32(np.ascontiguousarray(a["c"]).reshape(-1, 32)).reshape(-1)
-            out.append((np.array(ptr[m], np.uint32), np.ascontiguousarray(a["w"]), coeff))
+            cnt = np.asarray(counts[m], np.int64)
+            ptr = np.zeros(cnt.size + 1, np.int64)
+            np.cumsum(cnt, out=ptr[1:])
+            total = int(ptr[-1])
+            entry = np.repeat(np.asarray(starts[m], np.int64), cnt) + 36 * (np.arange(total) - np.repeat(ptr[:-1], cnt))
+            rec = raw[entry[:, None] + np.arange(36)] if total else np.zeros((0, 36), np.uint8)
+            wires = np.ascontiguousarray(rec[:, :4]).view("<u4").reshape(-1)
+            if total and int(wires.max()) >= self.n_wires:
+                raise R1csError("R1CS wire index %d exceeds nWires %d" % (int(wires.max()), self.n_wires))
+            coeff = _reduce_le32(np.ascontiguousarray(rec[:, 4:])).reshape(-1)
+            out.append((ptr.astype(np.uint32), wires.astype(np.uint32), coeff))
         return out
 
     def _csr_slow(self):
@@ -186,11 +194,15 @@ def hex_list_to_fr32(hexes):
     """[HexString, ...] -> (N, 32) uint8 little-endian Fr records, each ScalarField::from_hex (mod.rs:126-146) of its entry;
     one bytes.fromhex over the whole list instead of one big-int conversion per element"""
     try:
-        txt = "".join((h[2:] if h[:2] in ("0x", "0X") else h).rjust(64, "0") for h in hexes)
-        if len(txt) != 64 * len(hexes):
+        # right-align every entry in 66 characters with C-level map/join; the 'x' of a "0x" prefix becomes one more zero digit
+        txt = "".join(map(str.rjust, hexes, _repeat(66), _repeat("0"))).replace("x", "0").replace("X", "0")
+        if len(txt) != 66 * len(hexes):
             raise ValueError
-        be = np.frombuffer(bytes.fromhex(txt), np.uint8).reshape(-1, 32)
-    except ValueError:                                   # an entry longer than 256 bits (or odd text): element-wise route
+        be = np.frombuffer(bytes.fromhex(txt), np.uint8).reshape(-1, 33)
+        if be[:, 0].any():                                # more than 256 bits of digits
+            raise ValueError
+        be = be[:, 1:]
+    except (ValueError, TypeError):                      # an entry longer than 256 bits (or odd text): element-wise route
         return np.frombuffer(b"".join(hex_to_fr(h).to_bytes(32, "little") for h in hexes), np.uint8).reshape(-1, 32).copy()
     return _reduce_le32(np.ascontiguousarray(be[:, ::-1]))
 

@@ -56,7 +56,7 @@ def stage_crs(tkmk, sp, seed):
     return (sigma1, tables, singles), g
 
 
-def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, seed=0x746F6B616D616B04):
+def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, seed=0x746F6B616D616B04, profile_host=False):
     import synth_circuit
     import tkmk
     from tkmk.prove import Prover, fr, random_mixer, run_rounds
@@ -99,6 +99,16 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
                 want = tkmk.projective_to_affine_bytes(tkmk.msm(poly.eval(fr(TAU_X), fr(TAU_Y)), g))
                 assert (np.asarray(points[name]) == np.asarray(want)).all(), "commit identity fails for " + name
         del prover
+    if profile_host:                                       # where the host side of one more prove spends its time (stderr)
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        prover, binding = Prover.init_from(inputs, inst["qap"], mixer=random_mixer(random.Random(0)), sigma=sigma)
+        run_rounds(prover, binding)
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+        del prover
     del sigma
     return {"workload": "prove (init + prove0..4): synthetic circuit n=%d m_I=%d s_max=%d, %d placements, %d real R1CS rows" % (
         sp["n"], sp["l_D"] - sp["l"], sp["s_max"], len(inst["placement_variables"]), inst["r1cs_rows"]),
@@ -116,11 +126,12 @@ def main():
     ap.add_argument("--n-prv", type=int, default=3000)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--profile-host", action="store_true", help="cProfile of one more init + rounds, printed to stderr")
     ap.add_argument("--seed", type=int, default=0x746F6B616D616B04)
     args = ap.parse_args()
     import tkmk
     tkmk.set_device(0)
-    out = run(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.check, args.seed)
+    out = run(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.check, args.seed, args.profile_host)
     out["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md)"}
     print(json.dumps(out))
 
