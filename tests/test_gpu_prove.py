@@ -131,6 +131,65 @@ def test_testing_mode_rejects_bad_witness_and_bad_copy(gpu, oracle, tmp_path):
     json.dump(good, open(pv_path, "w"))
 
 
+def _stage_crs_file(gpu, oracle, sp, rnd, crs_dir):
+    from tkmk import crs as crsmod
+    (sigma1, tables, singles), crs, g = stage_crs(gpu, oracle, sp, rnd)
+    zero_g1 = np.zeros(96, np.uint8)
+    g_aff = np.frombuffer(bytes(g), np.uint8)
+    sections = {"g1": np.concatenate([g_aff, zero_g1, zero_g1, singles["delta"], singles["eta"], zero_g1]),
+                "xy_powers": sigma1.xy_powers.to_host(), "g2": np.zeros(10 * 192, np.uint8)}
+    sections.update({k: v.to_host() for k, v in tables.items()})
+    os.makedirs(crs_dir, exist_ok=True)
+    with open(os.path.join(crs_dir, "combined_sigma.tkcrs"), "wb") as f:
+        f.write(crsmod.build_payload(sections))
+    return (sigma1, tables, singles), crs, g
+
+
+@pytest.mark.parametrize("seed,shape", [(41, dict(s_max=8, n_gate_kinds=2)), (42, dict(s_max=4, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=3))])
+def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
+    """tokamak-zk-evm_amd/bin/prove (host/prove_main.cpp over host/tkmk_prover.hpp, the C++ host side) writes the same proof.json as
+    the Python prover for the same blinding scalars, and both equal the exponent restatement"""
+    import subprocess
+    import prove_ref
+    import synth_circuit
+    from tkmk import proofio
+    from tkmk.prove import Prover, run_rounds
+    binary = os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd", "bin", "prove")
+    assert os.path.exists(binary), "bin/prove is not built (run __graft_entry__.build())"
+    rnd = random.Random(seed)
+    inst = synth_circuit.build(str(tmp_path), rnd, **shape)
+    sp = inst["setup_params"]
+    crs_dir, out_dir = str(tmp_path / "crs"), str(tmp_path / "out")
+    sigma, crs, g = _stage_crs_file(gpu, oracle, sp, rnd, crs_dir)
+    os.makedirs(out_dir)
+    mixer = seeded_mixer(seed)
+    hx = lambda v: [hx(e) for e in v] if isinstance(v, list) else "0x%x" % v          # noqa: E731
+    mixer_path = str(tmp_path / "mixer.json")
+    json.dump({k: hx(v) for k, v in mixer.items()}, open(mixer_path, "w"))
+    cmd = [binary, "--crs", crs_dir, "--synthesizer-stat", inst["synth"], "--output", out_dir, "--subcircuit-library", inst["qap"]]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TKMK_PROVE_MIXER=mixer_path))
+    assert r.returncode == 0, r.stderr
+    native_points, native_scalars = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
+
+    prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, sigma=sigma)
+    points, scalars, _, _, _ = run_rounds(prover, binding)
+    assert native_scalars == scalars
+    for name in proofio.PROOF_POINT_ORDER:
+        assert (np.asarray(native_points[name]) == np.asarray(points[name])).all(), name
+    dlogs, ref_scalars, _, _, _ = prove_ref.run(inst, crs, mixer, g)
+    assert native_scalars == ref_scalars
+    for name in proofio.PROOF_POINT_ORDER:
+        assert (np.asarray(native_points[name]) == np.asarray(prove_ref.g1_of(dlogs[name], g))).all(), name
+    # fresh blinding without the hook; missing CRS -> the reference's message and a non-zero exit
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr
+    p2, _ = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
+    assert (np.asarray(p2["A_free"]) == np.asarray(points["A_free"])).all() and not (np.asarray(p2["U"]) == np.asarray(points["U"])).all()
+    os.remove(os.path.join(crs_dir, "combined_sigma.tkcrs"))
+    r3 = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r3.returncode != 0 and "No reference string is found" in r3.stderr
+
+
 def test_prove_cli_files_in_files_out(gpu, oracle, tmp_path):
     """process-level surface of `prove` (prove/src/main.rs:8-25): directories in, proof.json out; CRS staged as TKCRS001"""
     import subprocess

@@ -1,0 +1,517 @@
+// tkmk_prover.hpp — the prover over the C++ host side: work-alike of Prover::init / prove0 .. prove4 and of the round loop of main
+// (packages/backend/prove/src/lib.rs:675-1206, 1446-3206; packages/backend/prove/src/main.rs:27-97), with the reference's
+// structure names (Mixer, Binding, Proof0..Proof4, Proof4Test).  Same design as tkmk/prove.py, which it matches byte for byte
+// (tests/test_gpu_prove.py::test_native_prove_binary): every polynomial stays in HBM from init to the last commitment, the
+// independent commitments of one round are ONE tkmk_msm_multi call (6 / 2 / 9), prove1's running product is a device scan,
+// prove2's p_comb is one pass of the fused expression evaluator.
+#pragma once
+#include <array>
+#include <chrono>
+#include <functional>
+#include <initializer_list>
+#include <map>
+#include <memory>
+#include <random>
+
+#include "tkmk_fr.hpp"
+#include "tkmk_protocol.hpp"
+#include "tkmk_witness.hpp"
+
+namespace tkmk {
+
+struct Mixer {   // lib.rs:251-263
+    ScalarField rU_X, rU_Y, rV_X, rV_Y;
+    std::array<ScalarField, 4> rW_X, rW_Y;   // 3 random values resized to 4 with a zero (lib.rs:1045-1060)
+    std::array<ScalarField, 2> rB_X, rB_Y;
+    ScalarField rR_X, rR_Y, rO_mid;
+    static Mixer random() {
+        std::random_device rd;
+        auto draw = [&]() {
+            uint8_t b[32];
+            for (int i = 0; i < 32; i += 4) {
+                uint32_t w = rd();
+                std::memcpy(b + i, &w, 4);
+            }
+            return fr_from_le_bytes_mod_r(b, 32);
+        };
+        Mixer m;
+        m.rU_X = draw(), m.rU_Y = draw(), m.rV_X = draw(), m.rV_Y = draw();
+        m.rW_X = {draw(), draw(), draw(), ScalarField{}};
+        m.rW_Y = {draw(), draw(), draw(), ScalarField{}};
+        m.rB_X = {draw(), draw()};
+        m.rB_Y = {draw(), draw()};
+        m.rO_mid = draw(), m.rR_X = draw(), m.rR_Y = draw();
+        return m;
+    }
+};
+struct Binding {
+    G1Affine A_free, O_pub_free, O_mid, O_prv;
+};
+struct Proof0 {
+    G1Affine U, V, W, Q_AX, Q_AY, B;
+};
+struct Proof1 {
+    G1Affine R;
+};
+struct Proof2 {
+    G1Affine Q_CX, Q_CY;
+};
+struct Proof3 {
+    ScalarField V_eval, R_eval, R_omegaX_eval, R_omegaX_omegaY_eval;
+};
+struct Proof4 {
+    G1Affine Pi_X, Pi_Y, M_X, M_Y, N_X, N_Y;
+};
+struct Proof4Test {
+    G1Affine Pi_CX, Pi_CY, Pi_AX, Pi_AY, Pi_B, M_X, M_Y, N_X, N_Y;
+};
+struct Proof {
+    Binding binding;
+    Proof0 proof0;
+    Proof1 proof1;
+    Proof2 proof2;
+    Proof3 proof3;
+    Proof4 proof4;
+    // convert_format_for_solidity_verifier (lib.rs:452-513)
+    FormattedEntries convert_format_for_solidity_verifier() const {
+        FormattedEntries f;
+        for (const G1Affine *p : {&proof0.U, &proof0.V, &proof0.W, &binding.O_mid, &binding.O_prv, &proof0.Q_AX, &proof0.Q_AY, &proof2.Q_CX,
+                                  &proof2.Q_CY, &proof4.Pi_X, &proof4.Pi_Y, &proof0.B, &proof1.R, &proof4.M_Y, &proof4.M_X, &proof4.N_Y,
+                                  &proof4.N_X, &binding.O_pub_free, &binding.A_free})
+            split_push(f, *p);
+        for (const ScalarField *s : {&proof3.R_eval, &proof3.R_omegaX_eval, &proof3.R_omegaX_omegaY_eval, &proof3.V_eval})
+            f.part2.push_back(scalar_to_hex(*s));
+        return f;
+    }
+    std::string to_json() const { return entries_json("proof_entries_part1", "proof_entries_part2", convert_format_for_solidity_verifier()); }
+};
+
+// the CRS parts `prove` uses (SigmaHolder::load of combined_sigma: libs/src/group_structures/mod.rs:313-551 for the names)
+struct ProverSigma {
+    Sigma1 sigma1;
+    DeviceVec<G1Affine> gamma_inv_o_inst, eta_inv_li_o_inter_alpha4_kj, delta_inv_li_o_prv;
+    std::vector<G1Affine> delta_inv_alphak_xh_tx, delta_inv_alpha4_xj_tx, delta_inv_alphak_yi_ty;   // 3x3, 2, 4x3
+    G1Affine delta, eta;
+    static ProverSigma from_payload(const CrsPayload &crs, const SetupParams &sp) {
+        size_t m_i = sp.l_D - sp.l, rs_x = std::max(2 * sp.n, 2 * m_i), rs_y = 2 * sp.s_max;
+        auto want = [&](CrsPayload::Section s, size_t pts, const char *name) {
+            if (crs.points(s) != pts) throw Error(std::string("CRS section ") + name + " does not match setupParams.json");
+        };
+        want(CrsPayload::XyPowers, rs_x * rs_y, "xy_powers");
+        want(CrsPayload::GammaInvOInst, sp.l, "gamma_inv_o_inst");
+        want(CrsPayload::EtaInvLiOInterAlpha4Kj, m_i * sp.s_max, "eta_inv_li_o_inter_alpha4_kj");
+        want(CrsPayload::DeltaInvLiOPrv, (sp.m_D - sp.l_D) * sp.s_max, "delta_inv_li_o_prv");
+        want(CrsPayload::DeltaInvAlphakXhTx, 9, "delta_inv_alphak_xh_tx");
+        want(CrsPayload::DeltaInvAlpha4XjTx, 2, "delta_inv_alpha4_xj_tx");
+        want(CrsPayload::DeltaInvAlphakYiTy, 12, "delta_inv_alphak_yi_ty");
+        auto host = [&](CrsPayload::Section s) { return std::vector<G1Affine>(crs.g1(s), crs.g1(s) + crs.points(s)); };
+        const G1Affine *singles = crs.g1(CrsPayload::G1Singles);   // G, x, y, delta, eta, lagrange_KL
+        return ProverSigma{Sigma1(crs.upload(CrsPayload::XyPowers), rs_x, rs_y),
+                           crs.upload(CrsPayload::GammaInvOInst),
+                           crs.upload(CrsPayload::EtaInvLiOInterAlpha4Kj),
+                           crs.upload(CrsPayload::DeltaInvLiOPrv),
+                           host(CrsPayload::DeltaInvAlphakXhTx),
+                           host(CrsPayload::DeltaInvAlpha4XjTx),
+                           host(CrsPayload::DeltaInvAlphakYiTy),
+                           singles[3],
+                           singles[4]};
+    }
+};
+
+struct ProverInputs {   // the documents Prover::init reads (lib.rs:679-835)
+    SetupParams sp;
+    std::vector<SubcircuitInfo> infos;
+    std::vector<size_t> n_consts;   // subcircuitInfo.json "Nconsts", by position in infos
+    std::vector<PlacementVariables> pv;
+    std::vector<Permutation> perm;
+    std::vector<ScalarField> a_pub_user, a_pub_block;
+    std::string qap_path;
+};
+
+namespace prover_detail {
+
+using Poly = DensePolynomialExt;
+using Term = std::pair<ScalarField, const Poly *>;
+
+// poly_comb! (lib.rs:30-38)
+inline Poly poly_comb(std::initializer_list<Term> terms) {
+    Poly acc;
+    bool first = true;
+    for (const Term &t : terms) {
+        Poly p = *t.second * t.first;
+        if (first) acc = std::move(p), first = false;
+        else acc = acc + p;
+    }
+    return acc;
+}
+inline Poly sparse(const std::vector<std::pair<size_t, ScalarField>> &entries, size_t xs, size_t ys) {
+    std::vector<ScalarField> c(xs * ys);
+    for (auto &e : entries) c.at(e.first) = e.second;
+    return Poly::from_coeffs(c, xs, ys);
+}
+// lib.rs:48-68: (sum c_i T^i) * (T^exponent - 1) along one axis
+template <size_t K>
+inline Poly low_degree_times_vanishing(const std::array<ScalarField, K> &coeffs, size_t exponent, bool x_axis) {
+    if (exponent == 0 || K > exponent) throw Error("low_degree_times_vanishing: bad exponent");
+    size_t size = next_pow2(exponent + K);
+    std::vector<std::pair<size_t, ScalarField>> e;
+    for (size_t i = 0; i < K; i++) {
+        e.push_back({i, fr_neg(coeffs[i])});
+        e.push_back({i + exponent, coeffs[i]});
+    }
+    return x_axis ? sparse(e, size, 1) : sparse(e, 1, size);
+}
+inline Poly vanishing(size_t size, bool x_axis) {   // lib.rs:849-894
+    std::vector<std::pair<size_t, ScalarField>> e = {{0, fr_neg(fr_one())}, {size, fr_one()}};
+    return x_axis ? sparse(e, 2 * size, 1) : sparse(e, 1, 2 * size);
+}
+inline Poly unit_evals(size_t size, size_t index, bool x_axis) {   // the Lagrange polynomials K, L, K0 (lib.rs:2018-2100)
+    std::vector<ScalarField> e(size);
+    e.at(index) = fr_one();
+    DeviceVec<ScalarField> d = DeviceVec<ScalarField>::from_host(e);
+    return x_axis ? Poly::from_rou_evals(d, size, 1) : Poly::from_rou_evals(d, 1, size);
+}
+// &poly + &scalar / &poly - &scalar (bivariate_polynomial/mod.rs:1042-1116, 1189-1262): only coefficient (0,0) changes
+inline Poly add_const(const Poly &p, const ScalarField &s) {
+    Poly out = p.clone();
+    ScalarField c0 = fr_add(out.get_coeff(0, 0), s);
+    check(tkmk_memcpy_h2d(out.poly.ptr(), &c0, sizeof c0), "memcpy_h2d");
+    return out;
+}
+inline Poly sub_const(const Poly &p, const ScalarField &s) { return add_const(p, fr_neg(s)); }
+inline Poly mul_by_x_minus_one(const Poly &p) { return p.mul_monomial(1, 0) - p; }
+inline Poly mul_by_one_minus_x(const Poly &p) { return p - p.mul_monomial(1, 0); }
+inline Poly mul_by_linear(const Poly &p, const std::array<ScalarField, 2> &c, bool x_axis) {   // lib.rs:80-94
+    return p * c[0] + (x_axis ? p.mul_monomial(1, 0) : p.mul_monomial(0, 1)) * c[1];
+}
+inline Poly mul_by_term9(const Poly &p, const std::array<ScalarField, 2> &rB_X, const std::array<ScalarField, 2> &rB_Y,
+                         const ScalarField &t_mi_eval, const ScalarField &t_smax_eval) {   // lib.rs:96-124
+    ScalarField constant = fr_add(fr_mul(t_mi_eval, rB_X[0]), fr_mul(t_smax_eval, rB_Y[0]));
+    Poly partial = p * constant + p.mul_monomial(1, 0) * fr_mul(t_mi_eval, rB_X[1]);
+    return partial + p.mul_monomial(0, 1) * fr_mul(t_smax_eval, rB_Y[1]);
+}
+// several equally long linear combinations of G1 points in one batched MSM call (G1serde `+`, `-`, `* scalar`)
+inline std::vector<G1Affine> g1_lincombs(const std::vector<std::vector<std::pair<ScalarField, G1Affine>>> &rows) {
+    size_t k = rows.at(0).size();
+    std::vector<ScalarField> sc;
+    std::vector<G1Affine> pts;
+    for (auto &r : rows) {
+        if (r.size() != k) throw Error("g1_lincombs: ragged rows");
+        for (auto &t : r) sc.push_back(t.first), pts.push_back(t.second);
+    }
+    tkmk_msm_config cfg = tkmk_msm_default_config();
+    cfg.batch_size = (int)rows.size();
+    cfg.are_points_shared_in_batch = false;
+    std::vector<tkmk_g1_projective> res(rows.size());
+    check(bls12_381_msm(sc.data(), pts.data(), (int)k, &cfg, res.data()), "msm::msm");
+    std::vector<G1Affine> out;
+    for (auto &r : res) out.push_back(projective_to_affine(r));
+    return out;
+}
+
+}  // namespace prover_detail
+
+class Prover {
+    using Poly = DensePolynomialExt;
+
+  public:
+    SetupParams sp;
+    size_t m_i = 0;
+    const ProverSigma *sigma = nullptr;
+    Mixer mixer;
+    Poly bXY, uXY, vXY, wXY, rXY, a_free_X, t_n, t_mi, t_smax, s0XY, s1XY;
+    Poly q0XY, q1XY, q2XY, q3XY;
+    std::unique_ptr<Poly> w_zk, term_b_zk, lagrange_kl_xy;   // ProverCache (lib.rs:297-301)
+    std::map<std::string, double> timing;
+
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    // Prover::init (lib.rs:675-1206) after the JSON documents are parsed
+    static std::pair<std::unique_ptr<Prover>, Binding> init(const ProverInputs &in, const ProverSigma &sigma, const Mixer &mixer) {
+        using namespace prover_detail;
+        double t0 = now();
+        std::unique_ptr<Prover> p(new Prover());
+        p->sp = in.sp;
+        const SetupParams &sp = in.sp;
+        size_t m_i = sp.l_D - sp.l, n = sp.n, s_max = sp.s_max;
+        if (!is_pow2(m_i) || !is_pow2(n) || !is_pow2(s_max) || !is_pow2(sp.l_free)) throw Error("setup shape: n, s_max, l_D - l, l_free must be powers of two");
+        p->m_i = m_i;
+        p->sigma = &sigma;
+        p->mixer = mixer;
+        init_ntt_domain_for_size(4 * std::max(m_i, n) * 2 * s_max);   // prover_verifier_ntt_domain_size (libs/src/utils/mod.rs:51-58)
+        p->bXY = gen_bXY(in.pv, in.infos, sp);
+        std::map<size_t, SubcircuitR1CS> r1cs_cache;
+        auto r1cs_of = [&](size_t id) -> const SubcircuitR1CS & {
+            auto it = r1cs_cache.find(id);
+            if (it == r1cs_cache.end()) {
+                R1csBinary b = R1csBinary::read(in.qap_path + "/r1cs/subcircuit" + std::to_string(in.infos.at(id).id) + ".r1cs");
+                it = r1cs_cache.emplace(id, SubcircuitR1CS::from_r1cs_sparse_only(b, sp, in.infos.at(id), in.n_consts.at(id))).first;
+            }
+            return it->second;
+        };
+        auto uvw = read_R1CS_gen_uvwXY(r1cs_of, in.pv, in.infos, sp);
+        p->uXY = std::move(uvw[0]), p->vXY = std::move(uvw[1]), p->wXY = std::move(uvw[2]);
+        p->rXY = Poly::zero();
+        p->a_free_X = gen_a_free_X(in.a_pub_user, in.a_pub_block, sp);
+        p->t_n = vanishing(n, true), p->t_mi = vanishing(m_i, true), p->t_smax = vanishing(s_max, false);
+        auto s01 = permutation_to_poly(in.perm, m_i, s_max);
+        p->s0XY = std::move(s01.first), p->s1XY = std::move(s01.second);
+        p->timing["init.build"] = now() - t0;
+
+        double t1 = now();
+        const Mixer &mx = mixer;
+        Binding b;
+        b.A_free = sigma.sigma1.encode_poly(p->a_free_X);
+        b.O_pub_free = encode_O_pub_free(sigma.gamma_inv_o_inst, in.pv, in.infos);
+        G1Affine O_mid_core = encode_O_mid_no_zk(sigma.eta_inv_li_o_inter_alpha4_kj, in.pv, in.infos, sp);
+        G1Affine O_prv_core = encode_O_prv_no_zk(sigma.delta_inv_li_o_prv, in.pv, in.infos, sp);
+        const auto &xh = sigma.delta_inv_alphak_xh_tx, &xj = sigma.delta_inv_alpha4_xj_tx, &yi = sigma.delta_inv_alphak_yi_ty;
+        ScalarField zero{};
+        std::vector<std::pair<ScalarField, G1Affine>> mid = {{fr_one(), O_mid_core}, {mx.rO_mid, sigma.delta}};
+        while (mid.size() < 16) mid.push_back({zero, O_mid_core});
+        std::vector<std::pair<ScalarField, G1Affine>> prv = {   // lib.rs:1146-1160
+            {fr_one(), O_prv_core}, {fr_neg(mx.rO_mid), sigma.eta},
+            {mx.rU_X, xh[0]}, {mx.rV_X, xh[3]}, {mx.rW_X[0], xh[6]}, {mx.rW_X[1], xh[7]}, {mx.rW_X[2], xh[8]},
+            {mx.rB_X[0], xj[0]}, {mx.rB_X[1], xj[1]},
+            {mx.rU_Y, yi[0]}, {mx.rV_Y, yi[3]}, {mx.rW_Y[0], yi[6]}, {mx.rW_Y[1], yi[7]}, {mx.rW_Y[2], yi[8]},
+            {mx.rB_Y[0], yi[9]}, {mx.rB_Y[1], yi[10]}};
+        auto both = g1_lincombs({mid, prv});
+        b.O_mid = both[0], b.O_prv = both[1];
+        p->timing["init.binding"] = now() - t1;
+        p->timing["init.total"] = now() - t0;
+        return {std::move(p), b};
+    }
+
+    // f = b + th0 s0 + th1 s1 + th2,  g = b + th0 X + th1 Y + th2 (lib.rs:1807-1811)
+    std::pair<Poly, Poly> fg(const std::vector<ScalarField> &th) const {
+        using namespace prover_detail;
+        ScalarField zero{};
+        Poly X_mono = Poly::from_coeffs(std::vector<ScalarField>{zero, fr_one()}, 2, 1);
+        Poly Y_mono = Poly::from_coeffs(std::vector<ScalarField>{zero, fr_one()}, 1, 2);
+        Poly f = add_const((bXY + s0XY * th[0]) + s1XY * th[1], th[2]);
+        Poly g = add_const((bXY + X_mono * th[0]) + Y_mono * th[1], th[2]);
+        return {std::move(f), std::move(g)};
+    }
+    Poly blinded_R() const { return rXY + (t_mi * mixer.rR_X + t_smax * mixer.rR_Y); }
+    Poly blinded_V() const {
+        using namespace prover_detail;
+        return poly_comb({{fr_one(), &vXY}, {mixer.rV_X, &t_n}, {mixer.rV_Y, &t_smax}});
+    }
+
+    // prove0 (lib.rs:1446-1782)
+    Proof0 prove0() {
+        using namespace prover_detail;
+        const Mixer &mx = mixer;
+        size_t n = sp.n, s_max = sp.s_max;
+        Poly p0XY = uXY * vXY - wXY;
+        auto q01 = p0XY.div_by_vanishing_opt((int64_t)n, (int64_t)s_max);
+        q0XY = std::move(q01.first), q1XY = std::move(q01.second);
+        Poly rW_X = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_X.begin(), mx.rW_X.end()), 4, 1);
+        Poly rW_Y = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_Y.begin(), mx.rW_Y.end()), 1, 4);
+        ScalarField one = fr_one(), minus_one = fr_neg(one);
+        Poly UXY = poly_comb({{one, &uXY}, {mx.rU_X, &t_n}, {mx.rU_Y, &t_smax}});
+        Poly VXY = blinded_V();
+        w_zk.reset(new Poly(low_degree_times_vanishing(mx.rW_X, n, true) + low_degree_times_vanishing(mx.rW_Y, s_max, false)));
+        Poly WXY = wXY + *w_zk;
+        Poly Q_AX_XY = poly_comb({{one, &q0XY}, {mx.rU_X, &vXY}, {mx.rV_X, &uXY}, {minus_one, &rW_X}, {fr_mul(mx.rU_X, mx.rV_X), &t_n},
+                                  {fr_mul(mx.rU_Y, mx.rV_X), &t_smax}});
+        Poly Q_AY_XY = poly_comb({{one, &q1XY}, {mx.rU_Y, &vXY}, {mx.rV_Y, &uXY}, {minus_one, &rW_Y}, {fr_mul(mx.rU_X, mx.rV_Y), &t_n},
+                                  {fr_mul(mx.rU_Y, mx.rV_Y), &t_smax}});
+        term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
+        Poly BXY = bXY + *term_b_zk;
+        auto c = sigma->sigma1.encode_polys({&UXY, &VXY, &WXY, &Q_AX_XY, &Q_AY_XY, &BXY});
+        return Proof0{c[0], c[1], c[2], c[3], c[4], c[5]};
+    }
+
+    // prove1 (lib.rs:1784-1956)
+    Proof1 prove1(const std::vector<ScalarField> &thetas) {
+        size_t s_max = sp.s_max, cells = m_i * s_max;
+        auto f_g = fg(thetas);
+        f_g.first.resize(m_i, s_max);
+        f_g.second.resize(m_i, s_max);
+        DeviceVec<ScalarField> f_ev(cells), g_ev(cells), tr(cells), sfx(cells);
+        f_g.first.to_rou_evals(nullptr, nullptr, f_ev);
+        f_g.second.to_rou_evals(nullptr, nullptr, g_ev);
+        // r[last] = 1, r[idx] = r[idx + 1] * (g / f)[idx + 1] over the TRANSPOSED (s_max x m_i) order (lib.rs:1858-1866)
+        tkmk_vecops_config c = dev_cfg();
+        check(bls12_381_vector_div(g_ev.ptr(), f_ev.ptr(), cells, &c, g_ev.ptr()), "vector_div");
+        check(bls12_381_matrix_transpose(g_ev.ptr(), (uint32_t)m_i, (uint32_t)s_max, &c, tr.ptr()), "transpose");
+        check(tkmk_vec_suffix_product(tr.ptr(), cells, sfx.ptr(), nullptr), "tkmk_vec_suffix_product");
+        check(bls12_381_matrix_transpose(sfx.ptr(), (uint32_t)s_max, (uint32_t)m_i, &c, tr.ptr()), "transpose");
+        rXY = Poly::from_rou_evals(tr, m_i, s_max);
+        Poly RXY = blinded_R();
+        return Proof1{sigma->sigma1.encode_poly(RXY)};
+    }
+
+    // prove2 (lib.rs:1958-2270)
+    Proof2 prove2(const std::vector<ScalarField> &thetas, const ScalarField &kappa0) {
+        using namespace prover_detail;
+        const Mixer &mx = mixer;
+        size_t s_max = sp.s_max;
+        ScalarField kappa0_sq = fr_mul(kappa0, kappa0), one = fr_one();
+        ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(s_max));
+        Poly r_omegaX = rXY.scale_coeffs(&w_inv_x, nullptr);
+        Poly r_omegaX_omegaY = r_omegaX.scale_coeffs(nullptr, &w_inv_y);
+        auto f_g = fg(thetas);
+        const Poly &fXY = f_g.first, &gXY = f_g.second;
+        lagrange_kl_xy.reset(new Poly(unit_evals(m_i, m_i - 1, true) * unit_evals(s_max, s_max - 1, false)));
+        const Poly &KL = *lagrange_kl_xy;
+        Poly K0 = unit_evals(m_i, 0, true);
+
+        using E = PolyExpr;
+        auto r_g = [&]() { return E::mul(E::poly(rXY), E::poly(gXY)); };
+        E p1 = E::mul(E::sub(E::poly(rXY), E::scalar(one)), E::poly(KL));
+        E p2 = E::mul_x_minus_one(E::sub(r_g(), E::mul(E::poly(r_omegaX), E::poly(fXY))));
+        E p3 = E::mul(E::poly(K0), E::sub(r_g(), E::mul(E::poly(r_omegaX_omegaY), E::poly(fXY))));
+        std::vector<std::pair<ScalarField, E>> terms;
+        terms.emplace_back(one, std::move(p1));
+        terms.emplace_back(kappa0, std::move(p2));
+        terms.emplace_back(kappa0_sq, std::move(p3));
+        Poly p_comb = E::weighted_sum(std::move(terms)).evaluate_fused_with_domain(4 * m_i, 2 * s_max);
+        auto q23 = p_comb.div_by_vanishing_opt((int64_t)m_i, (int64_t)s_max);
+        q2XY = std::move(q23.first), q3XY = std::move(q23.second);
+        Poly r_D1 = rXY - r_omegaX, r_D2 = rXY - r_omegaX_omegaY, g_D = gXY - fXY;
+
+        auto q_c = [&](const Poly &quot, const std::array<ScalarField, 2> &rB, const ScalarField &rR, bool x_axis) {
+            Poly d1_comb = mul_by_linear(r_D1, rB, x_axis) + g_D * rR;
+            Poly d2_comb = mul_by_linear(r_D2, rB, x_axis) + g_D * rR;
+            Poly xm1_d1 = mul_by_x_minus_one(d1_comb);
+            Poly k0_d2 = K0 * d2_comb;
+            return poly_comb({{one, &quot}, {rR, &KL}, {kappa0, &xm1_d1}, {kappa0_sq, &k0_d2}});
+        };
+        Poly Q_CX_XY = q_c(q2XY, mx.rB_X, mx.rR_X, true);
+        Poly Q_CY_XY = q_c(q3XY, mx.rB_Y, mx.rR_Y, false);
+        auto c = sigma->sigma1.encode_polys({&Q_CX_XY, &Q_CY_XY});
+        return Proof2{c[0], c[1]};
+    }
+
+    // prove3 (lib.rs:2272-2354)
+    Proof3 prove3(const ScalarField &chi, const ScalarField &zeta) const {
+        ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(sp.s_max));
+        Proof3 out;
+        out.V_eval = blinded_V().eval(chi, zeta);
+        Poly RXY = blinded_R();
+        out.R_eval = RXY.eval(chi, zeta);
+        Poly R_omegaX = RXY.scale_coeffs(&w_inv_x, nullptr);
+        out.R_omegaX_eval = R_omegaX.eval(chi, zeta);
+        out.R_omegaX_omegaY_eval = R_omegaX.scale_coeffs(nullptr, &w_inv_y).eval(chi, zeta);
+        return out;
+    }
+
+    // prove4 (lib.rs:2356-3206)
+    std::pair<Proof4, Proof4Test> prove4(const Proof3 &proof3, const std::vector<ScalarField> &thetas, const ScalarField &kappa0,
+                                        const ScalarField &chi, const ScalarField &zeta, const ScalarField &kappa1) {
+        using namespace prover_detail;
+        const Mixer &mx = mixer;
+        size_t n = sp.n, s_max = sp.s_max;
+        ScalarField one = fr_one(), minus_one = fr_neg(one);
+        auto ev = [&](const Poly &p) { return p.eval(chi, zeta); };
+
+        // Pi_A: arithmetic constraints + the opening of V (lib.rs:2383-2532)
+        ScalarField t_n_eval = t_n.eval(chi, one), t_smax_eval = t_smax.eval(one, zeta), small_v_eval = ev(vXY);
+        Poly rW_X = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_X.begin(), mx.rW_X.end()), 4, 1);
+        Poly rW_Y = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_Y.begin(), mx.rW_Y.end()), 1, 4);
+        if (!w_zk) w_zk.reset(new Poly(low_degree_times_vanishing(mx.rW_X, n, true) + low_degree_times_vanishing(mx.rW_Y, s_max, false)));
+        Poly V_minus = sub_const(blinded_V(), proof3.V_eval);
+        Poly pA_XY = poly_comb({{kappa1, &V_minus},
+                                {small_v_eval, &uXY},
+                                {minus_one, &wXY},
+                                {fr_neg(t_n_eval), &q0XY},
+                                {fr_neg(t_smax_eval), &q1XY},
+                                {fr_mul(small_v_eval, mx.rU_X), &t_n},
+                                {fr_mul(small_v_eval, mx.rU_Y), &t_smax},
+                                {fr_neg(fr_add(fr_mul(mx.rU_X, t_n_eval), fr_mul(mx.rU_Y, t_smax_eval))), &vXY},
+                                {t_n_eval, &rW_X},
+                                {t_smax_eval, &rW_Y},
+                                {minus_one, w_zk.get()}});
+        auto piA = pA_XY.div_by_ruffini(chi, zeta);
+
+        // M, N: openings of R at (chi / w_x, zeta) and (chi / w_x, zeta / w_y) (lib.rs:2534-2701)
+        ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(s_max));
+        Poly RXY = blinded_R();
+        auto M = sub_const(RXY, proof3.R_omegaX_eval).div_by_ruffini(fr_mul(w_inv_x, chi), zeta);
+        auto N = sub_const(RXY, proof3.R_omegaX_omegaY_eval).div_by_ruffini(fr_mul(w_inv_x, chi), fr_mul(w_inv_y, zeta));
+
+        // Pi_C: copy constraints (lib.rs:2703-3130)
+        Poly r_omegaX = rXY.scale_coeffs(&w_inv_x, nullptr);
+        Poly r_omegaX_omegaY = r_omegaX.scale_coeffs(nullptr, &w_inv_y);
+        auto f_g = fg(thetas);
+        const Poly &fXY = f_g.first, &gXY = f_g.second;
+        ScalarField t_mi_eval = fr_sub(fr_pow(chi, m_i), one), t_s_max_eval = fr_sub(fr_pow(zeta, s_max), one);
+        Poly K0 = unit_evals(m_i, 0, true);
+        ScalarField K0_eval = ev(K0), small_r = ev(rXY), small_r_wx = ev(r_omegaX), small_r_wxy = ev(r_omegaX_omegaY);
+        if (!lagrange_kl_xy) lagrange_kl_xy.reset(new Poly(unit_evals(m_i, m_i - 1, true) * unit_evals(s_max, s_max - 1, false)));
+        Poly term5 = poly_comb({{small_r, &gXY}, {fr_neg(small_r_wx), &fXY}});
+        Poly term6 = poly_comb({{small_r, &gXY}, {fr_neg(small_r_wxy), &fXY}});
+        ScalarField chi_m1 = fr_sub(chi, one), kappa0_sq = fr_mul(kappa0, kappa0);
+        Poly pC_XY = poly_comb({{fr_sub(small_r, one), lagrange_kl_xy.get()},
+                                {fr_mul(kappa0, chi_m1), &term5},
+                                {fr_mul(kappa0_sq, K0_eval), &term6},
+                                {fr_neg(t_mi_eval), &q2XY},
+                                {fr_neg(t_s_max_eval), &q3XY}});
+        Poly r_D1 = rXY - r_omegaX, r_D2 = rXY - r_omegaX_omegaY;
+        ScalarField r_D1_eval = ev(r_D1), r_D2_eval = ev(r_D2);
+        if (!term_b_zk) term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
+        Poly g_minus_f = gXY - fXY;
+        Poly term10 = g_minus_f * fr_add(fr_mul(mx.rR_X, t_mi_eval), fr_mul(mx.rR_Y, t_s_max_eval));
+        Poly r_d1_t = mul_by_term9(r_D1, mx.rB_X, mx.rB_Y, t_mi_eval, t_s_max_eval) + term10;
+        Poly one_minus_x_times = mul_by_one_minus_x(r_d1_t);
+        Poly LHS_zk1 = poly_comb({{fr_mul(chi_m1, r_D1_eval), term_b_zk.get()}, {one, &one_minus_x_times}, {chi_m1, &term10}});
+        Poly r_d2_t = mul_by_term9(r_D2, mx.rB_X, mx.rB_Y, t_mi_eval, t_s_max_eval) + term10;
+        Poly k0_r_d2_t = K0 * r_d2_t;
+        Poly LHS_zk2 = poly_comb({{fr_mul(K0_eval, r_D2_eval), term_b_zk.get()}, {K0_eval, &term10}, {minus_one, &k0_r_d2_t}});
+        Poly R_minus_eval = sub_const(RXY, proof3.R_eval);
+        ScalarField k1_2 = fr_mul(kappa1, kappa1);
+        Poly LHS_for_copy = poly_comb({{k1_2, &pC_XY},
+                                       {fr_mul(k1_2, kappa0), &LHS_zk1},
+                                       {fr_mul(fr_mul(k1_2, kappa0), kappa0), &LHS_zk2},
+                                       {fr_mul(k1_2, kappa1), &R_minus_eval}});
+        auto piC = LHS_for_copy.div_by_ruffini(chi, zeta);
+
+        // Pi_B: opening of a_free (lib.rs:3137-3181)
+        ScalarField A_eval = ev(a_free_X);
+        auto piB = sub_const(a_free_X, A_eval).div_by_ruffini(chi, zeta);
+
+        auto c = sigma->sigma1.encode_polys({&std::get<0>(piA), &std::get<1>(piA), &std::get<0>(M), &std::get<1>(M), &std::get<0>(N), &std::get<1>(N),
+                                             &std::get<0>(piC), &std::get<1>(piC), &std::get<0>(piB)});
+        const G1Affine &Pi_AX = c[0], &Pi_AY = c[1], &M_X = c[2], &M_Y = c[3], &N_X = c[4], &N_Y = c[5], &Pi_CX = c[6], &Pi_CY = c[7], &Pi_B0 = c[8];
+        ScalarField k1_4 = fr_mul(k1_2, k1_2), zero{};
+        auto sums = g1_lincombs({{{k1_4, Pi_B0}, {zero, Pi_B0}, {zero, Pi_B0}},   // encode(pi_B) * kappa1^4 (lib.rs:3180)
+                                 {{one, Pi_AX}, {one, Pi_CX}, {k1_4, Pi_B0}},      // lib.rs:3183-3184
+                                 {{one, Pi_AY}, {one, Pi_CY}, {zero, Pi_AY}}});
+        Proof4 p4{sums[1], sums[2], M_X, M_Y, N_X, N_Y};
+        Proof4Test t{Pi_CX, Pi_CY, Pi_AX, Pi_AY, sums[0], M_X, M_Y, N_X, N_Y};
+        return {p4, t};
+    }
+};
+
+// the round loop of prove/src/main.rs:47-76
+inline Proof run_rounds(Prover &prover, const Binding &binding, std::map<std::string, double> *times = nullptr) {
+    TranscriptManager manager;
+    auto timed = [&](const char *name, const std::function<void()> &fn) {
+        double t = Prover::now();
+        fn();
+        check(tkmk_device_synchronize(), "synchronize");
+        if (times) (*times)[name] = Prover::now() - t;
+    };
+    Proof proof;
+    proof.binding = binding;
+    timed("prove0", [&] { proof.proof0 = prover.prove0(); });
+    const Proof0 &p0 = proof.proof0;
+    manager.add_proof0(p0.U, p0.V, p0.W, p0.Q_AX, p0.Q_AY, p0.B);
+    std::vector<ScalarField> thetas = manager.get_thetas();
+    timed("prove1", [&] { proof.proof1 = prover.prove1(thetas); });
+    manager.add_proof1(proof.proof1.R);
+    ScalarField kappa0 = manager.get_kappa0();
+    timed("prove2", [&] { proof.proof2 = prover.prove2(thetas, kappa0); });
+    manager.add_proof2(proof.proof2.Q_CX, proof.proof2.Q_CY);
+    auto cz = manager.get_chi_zeta();
+    timed("prove3", [&] { proof.proof3 = prover.prove3(cz.first, cz.second); });
+    const Proof3 &p3 = proof.proof3;
+    manager.add_proof3(p3.V_eval, p3.R_eval, p3.R_omegaX_eval, p3.R_omegaX_omegaY_eval);
+    ScalarField kappa1 = manager.get_kappa1();
+    timed("prove4", [&] { proof.proof4 = prover.prove4(p3, thetas, kappa0, cz.first, cz.second, kappa1).first; });
+    return proof;
+}
+
+}  // namespace tkmk
