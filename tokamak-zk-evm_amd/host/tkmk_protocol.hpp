@@ -13,6 +13,13 @@
 #include <cstdio>
 #include <fstream>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <memory>
+
 #include "tkmk_host.hpp"
 
 namespace tkmk {
@@ -230,12 +237,27 @@ inline std::string entries_json(const char *k1, const char *k2, const FormattedE
 struct CrsPayload {
     enum Section { G1Singles, XyPowers, GammaInvOInst, EtaInvLiOInterAlpha4Kj, DeltaInvLiOPrv, DeltaInvAlphakXhTx, DeltaInvAlpha4XjTx,
                    DeltaInvAlphakYiTy, G2Points, Count };
-    std::vector<uint8_t> data;
+    // a borrowed view of the payload bytes: either an owned buffer (parse) or a read-only mapping of the file (read; xy_powers
+    // alone is 384 MiB at the production shape, so sections go from the page cache to the device without a host copy)
+    struct View {
+        const uint8_t *p = nullptr;
+        size_t n = 0;
+        const uint8_t *data() const { return p; }
+        size_t size() const { return n; }
+    };
+    View data;
+    std::shared_ptr<void> keep;   // owns the buffer or the mapping
     size_t offset[Count]{}, length[Count]{};
 
     static CrsPayload parse(std::vector<uint8_t> bytes) {
+        auto owned = std::make_shared<std::vector<uint8_t>>(std::move(bytes));
+        CrsPayload c = parse_view(View{owned->data(), owned->size()});
+        c.keep = owned;
+        return c;
+    }
+    static CrsPayload parse_view(View view) {
         CrsPayload c;
-        c.data = std::move(bytes);
+        c.data = view;
         const auto &d = c.data;
         if (d.size() < 12 || std::memcmp(d.data(), "TKCRS001", 8) != 0) throw Error("not a TKCRS001 payload");
         uint32_t count;
@@ -259,16 +281,25 @@ struct CrsPayload {
         return c;
     }
     static CrsPayload read(const std::string &path) {
-        std::ifstream f(path, std::ios::binary);
-        if (!f) throw Error("No reference string is found. Run the Setup first (expected " + path + ").");
-        return parse(std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()));
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw Error("No reference string is found. Run the Setup first (expected " + path + ").");
+        struct stat st;
+        if (::fstat(fd, &st) != 0 || st.st_size <= 0) {
+            ::close(fd);
+            throw Error("cannot stat " + path);
+        }
+        size_t n = (size_t)st.st_size;
+        void *m = ::mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) throw Error("cannot map " + path);
+        std::shared_ptr<void> mapping(m, [n](void *q) { ::munmap(q, n); });
+        CrsPayload c = parse_view(View{static_cast<const uint8_t *>(m), n});
+        c.keep = mapping;
+        return c;
     }
     size_t points(Section s) const { return length[s] / 96; }
     const G1Affine *g1(Section s) const { return reinterpret_cast<const G1Affine *>(data.data() + offset[s]); }
-    DeviceVec<G1Affine> upload(Section s) const {
-        std::vector<G1Affine> v(g1(s), g1(s) + points(s));
-        return DeviceVec<G1Affine>::from_host(v);
-    }
+    DeviceVec<G1Affine> upload(Section s) const { return DeviceVec<G1Affine>::from_host(g1(s), points(s)); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------

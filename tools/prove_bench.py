@@ -118,8 +118,64 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
         "generate_s": round(gen_s, 2), "stage_crs_s": round(crs_s, 2), "checked": bool(check)}
 
 
+def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0x746F6B616D616B04):
+    """the same workload through tokamak-zk-evm_amd/bin/prove (C++ host side): every input as a file in the reference's formats,
+    the CRS as the TKCRS001 payload; times are the binary's own printout (inputs + CRS loading included in its total)"""
+    import re
+    import shutil
+    import subprocess
+    import synth_circuit
+    import tkmk
+    from tkmk import crs as crsmod
+    inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=13, n_out=100, n_in=200, n_prv=n_prv, k_pub=85,
+                                  l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements)
+    tmp = tempfile.mkdtemp(prefix="tkmk_prove_native_")
+    try:
+        synth_circuit.write(inst, tmp)
+        sp = inst["setup_params"]
+        (sigma1, tables, singles), g = stage_crs(tkmk, sp, seed)
+        zero = np.zeros(96, np.uint8)
+        sections = {"g1": np.concatenate([g, zero, zero, singles["delta"], singles["eta"], zero]), "xy_powers": sigma1.xy_powers.to_host(),
+                    "g2": np.zeros(10 * 192, np.uint8)}
+        sections.update({k: v.to_host() for k, v in tables.items()})
+        os.makedirs(os.path.join(tmp, "crs"))
+        with open(os.path.join(tmp, "crs", "combined_sigma.tkcrs"), "wb") as f:
+            f.write(crsmod.build_payload(sections))
+        crs_bytes = os.path.getsize(os.path.join(tmp, "crs", "combined_sigma.tkcrs"))
+        pv_bytes = os.path.getsize(os.path.join(inst["synth"], "placementVariables.json"))
+        del sections, sigma1, tables
+        tkmk.release_scratch()
+        binary = os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "prove")
+        cmd = [binary, "--crs", os.path.join(tmp, "crs"), "--synthesizer-stat", inst["synth"], "--output", os.path.join(tmp, "out"),
+               "--subcircuit-library", inst["qap"]]
+        os.makedirs(os.path.join(tmp, "out"))
+        runs = []
+        for _ in range(repeat):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr)
+            rec = {m.group(1): float(m.group(2)) for m in re.finditer(r"^(\S+)\s+([0-9.]+) s$", r.stdout, re.M)}
+            rec["total"] = float(re.search(r"Total elapsed time: ([0-9.]+)s", r.stdout).group(1))
+            rec["rounds"] = round(sum(rec["prove%d" % k] for k in range(5)), 4)
+            rec["process_wall"] = round(wall, 3)
+            runs.append(rec)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    best = min(runs, key=lambda r: r["total"])
+    slots = sp["n"] * sp["s_max"]
+    compute = best["init.total"] + best["rounds"]
+    return {"workload": "native bin/prove (files in, proof.json out): synthetic circuit n=%d m_I=%d s_max=%d, %d placements, %d real R1CS rows" % (
+        sp["n"], sp["l_D"] - sp["l"], sp["s_max"], len(inst["placement_variables"]), inst["r1cs_rows"]),
+        "constraint_slots": slots, "r1cs_rows": inst["r1cs_rows"], "seconds": best, "runs": runs,
+        "constraint_slots_per_s": round(slots / best["total"]), "constraint_slots_per_s_init_plus_rounds": round(slots / compute),
+        "crs_payload_bytes": crs_bytes, "placement_variables_json_bytes": pv_bytes}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--native", action="store_true", help="time tokamak-zk-evm_amd/bin/prove on files instead of the Python prover")
     ap.add_argument("--s-max", type=int, default=256)
     ap.add_argument("--placements", type=int, default=None, help="used placements (default: all s_max; the reference's run has 166)")
     ap.add_argument("--pool", type=int, default=24, help="distinct gate witnesses")
@@ -131,7 +187,10 @@ def main():
     args = ap.parse_args()
     import tkmk
     tkmk.set_device(0)
-    out = run(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.check, args.seed, args.profile_host)
+    if args.native:
+        out = run_native(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.seed)
+    else:
+        out = run(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.check, args.seed, args.profile_host)
     out["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md)"}
     print(json.dumps(out))
 
