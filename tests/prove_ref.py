@@ -400,3 +400,96 @@ def verify_copy(d, s, ch, p4t, crs, sp, s0_commit, s1_commit, kl_commit, kappa2)
     aux_x = p4t["Pi_CX"] + p4t["M_X"] * kappa2 + p4t["N_X"] * kappa2 ** 2
     aux_y = p4t["Pi_CY"] + p4t["M_Y"] * kappa2 + p4t["N_Y"] * kappa2 ** 2
     return (lhs + aux - aux_x * crs["tau_x"] - aux_y * crs["tau_y"]) % R == 0
+
+
+# ---- setup in the exponent: the discrete logarithms of every CRS entry (Sigma::gen) ----
+def lagrange_at(val, size):
+    """L_i(val), i < size, over the size-th roots of unity — what gen_evaled_lagrange_bases (libs/src/vector_operations/mod.rs:19-28)
+    obtains as the inverse NTT of the power vector; here from the closed form w^i (val^size - 1) / (size (val - w^i))"""
+    w = oracle.to_ints(oracle.root_of_unity(size), 32)[0]
+    t = (pow(val, size, R) - 1) * inv(size) % R
+    return [pow(w, i, R) * t % R * inv(val - pow(w, i, R)) % R for i in range(size)]
+
+
+def sigma_gen(inst, tau):
+    """trusted-setup main (setup/trusted-setup/src/main.rs:117-160) + Sigma1::gen (libs/src/group_structures/mod.rs:361-551):
+    tau = {"x", "y", "alpha", "gamma", "delta", "eta"} -> dict of discrete logarithms with the keys RefProver expects,
+    plus the trapdoor scalars themselves (Sigma2::gen, :752-777) and lagrange_KL"""
+    sp = inst["setup_params"]
+    n, s_max, l, l_free, l_user, l_user_out, l_D, m_D = (sp[k] for k in ("n", "s_max", "l", "l_free", "l_user", "l_user_out", "l_D", "m_D"))
+    m_i = l_D - l
+    x, y, a = tau["x"], tau["y"], tau["alpha"]
+    k_vec, l_vec, m_vec, x_lag = lagrange_at(x, m_i), lagrange_at(y, s_max), lagrange_at(x, l_free), lagrange_at(x, n)
+    # o_j(x) = alpha u_j(x) + alpha^2 v_j(x) + alpha^3 w_j(x), u_j(x) = sum_rows A[row][j] L_row(x) (field_structures/mod.rs:67-165)
+    o_vec = [0] * m_D
+    for sub in inst["subs"]:
+        uvw = [[0] * sub.n_wires for _ in range(3)]
+        for row, abc in enumerate(sub.rows):
+            for m in range(3):
+                for wire, c in abc[m]:
+                    uvw[m][wire] = (uvw[m][wire] + c * x_lag[row]) % R
+        for j in range(sub.n_wires):
+            o = (a * uvw[0][j] + a * a * uvw[1][j] + pow(a, 3, R) * uvw[2][j]) % R
+            if o:
+                o_vec[sub.flatten_map[j]] = o
+    gi, di, ei = inv(tau["gamma"]), inv(tau["delta"]), inv(tau["eta"])
+    user_vec = [l_vec[0]] * l_user_out + [l_vec[1]] * (l_user - l_user_out) + [l_vec[2]] * (l_free - l_user) + [l_vec[3]] * (l - l_free)
+    gamma_tbl = [gi * (user_vec[j] * o_vec[j] + (m_vec[j] if j < l_free else 0)) % R for j in range(l)]
+    a4 = pow(a, 4, R)
+    eta_tbl = [[ei * (o_vec[l + j] + a4 * k_vec[j]) % R * l_vec[i] % R for i in range(s_max)] for j in range(m_i)]
+    delta_tbl = [[di * o_vec[l_D + j] % R * l_vec[i] % R for i in range(s_max)] for j in range(m_D - l_D)]
+    t_n, t_mi, t_s = (pow(x, n, R) - 1) % R, (pow(x, m_i, R) - 1) % R, (pow(y, s_max, R) - 1) % R
+    return {"tau_x": x, "tau_y": y, "alpha": a, "gamma": tau["gamma"], "delta": tau["delta"], "eta": tau["eta"],
+            "gamma_inv_o_inst": gamma_tbl, "eta_inv_li_o_inter_alpha4_kj": eta_tbl, "delta_inv_li_o_prv": delta_tbl,
+            "delta_inv_alphak_xh_tx": [[di * pow(a, k, R) * pow(x, h, R) * t_n % R for h in range(3)] for k in (1, 2, 3)],
+            "delta_inv_alpha4_xj_tx": [di * a4 * pow(x, j, R) * t_mi % R for j in range(2)],
+            "delta_inv_alphak_yi_ty": [[di * pow(a, k, R) * pow(y, i, R) * t_s % R for i in range(3)] for k in (1, 2, 3, 4)],
+            "lagrange_KL": l_vec[s_max - 1] * k_vec[m_i - 1] % R, "o_vec": o_vec}
+
+
+def preprocess(rp, inst, crs):
+    """Preprocess::gen (preprocess/src/lib.rs:32-82): commitments to s0, s1 and O_pub_fix = sum a_pub_function[i] * gamma table tail"""
+    sp = inst["setup_params"]
+    a_fn = [hex_fr(h) for h in inst["instance"]["a_pub_function"]]
+    start = sp["l"] - len(a_fn)
+    return {"s0": rp.commit(rp.s0), "s1": rp.commit(rp.s1),
+            "O_pub_fix": sum(v * crs["gamma_inv_o_inst"][start + i] for i, v in enumerate(a_fn)) % R}
+
+
+def verify_binding(d, s, ch, p4t, crs, pre, a_free, kappa2):
+    """verify-rust/src/lib.rs:198-202, 319-352:  e(LHS_B + AUX_B, H) e(B, [a^4]H) e(U, [a]H) e(V, [a^2]H) e(W, [a^3]H)
+    = e(O_pub_fix + O_pub_free, [gamma]H) e(O_mid, [eta]H) e(O_prv, [delta]H) e(kappa2 Pi_B, [x]H)"""
+    chi, zeta, k1, a = ch["chi"], ch["zeta"], ch["kappa1"], crs["alpha"]
+    a_eval = a_free.eval(chi, zeta)
+    lhs_b = d["A_free"] * (1 + kappa2 * k1 ** 4) - kappa2 * k1 ** 4 * a_eval
+    left = lhs_b + p4t["Pi_B"] * kappa2 * chi + d["B"] * a ** 4 + d["U"] * a + d["V"] * a ** 2 + d["W"] * a ** 3
+    right = ((pre["O_pub_fix"] + d["O_pub_free"]) * crs["gamma"] + d["O_mid"] * crs["eta"] + d["O_prv"] * crs["delta"]
+             + p4t["Pi_B"] * kappa2 * crs["tau_x"])
+    return (left - right) % R == 0
+
+
+def verify_snark(d, s, ch, crs, sp, pre, a_free, kappa2):
+    """verify-rust/src/lib.rs:248-289: the single combined check a verifier runs (uses Pi_X / Pi_Y, not the Proof4Test parts)"""
+    th, k0, chi, zeta, k1, a = ch["thetas"], ch["kappa0"], ch["chi"], ch["zeta"], ch["kappa1"], crs["alpha"]
+    m_i, s_max = sp["l_D"] - sp["l"], sp["s_max"]
+    wxi = inv(oracle.to_ints(oracle.root_of_unity(m_i), 32)[0])
+    wyi = inv(oracle.to_ints(oracle.root_of_unity(s_max), 32)[0])
+    t_n_e, t_mi_e, t_s_e = (pow(chi, sp["n"], R) - 1) % R, (pow(chi, m_i, R) - 1) % R, (pow(zeta, s_max, R) - 1) % R
+    k0_e = 1 if chi == 1 else t_mi_e * inv(m_i) * inv(chi - 1) % R
+    lhs_a = d["U"] * s["V_eval"] - d["W"] + (d["V"] - s["V_eval"]) * k1 - d["Q_AX"] * t_n_e - d["Q_AY"] * t_s_e
+    F = d["B"] + pre["s0"] * th[0] + pre["s1"] * th[1] + th[2]
+    G = d["B"] + crs["tau_x"] * th[0] + crs["tau_y"] * th[1] + th[2]
+    term1 = (crs["lagrange_KL"] * (s["R_eval"] - 1) + (G * s["R_eval"] - F * s["R_omegaX_eval"]) * (k0 * (chi - 1))
+             + (G * s["R_eval"] - F * s["R_omegaX_omegaY_eval"]) * (k0 * k0 * k0_e) - d["Q_CX"] * t_mi_e - d["Q_CY"] * t_s_e)
+    lhs_c = (term1 * k1 ** 2 + (d["R"] - s["R_eval"]) * k1 ** 3 + (d["R"] - s["R_omegaX_eval"]) * kappa2
+             + (d["R"] - s["R_omegaX_omegaY_eval"]) * kappa2 ** 2)
+    lhs_b = d["A_free"] * (1 + kappa2 * k1 ** 4) - kappa2 * k1 ** 4 * a_free.eval(chi, zeta)
+    lhs = lhs_b + (lhs_a + lhs_c) * kappa2
+    aux = (d["Pi_X"] * (kappa2 * chi) + d["Pi_Y"] * (kappa2 * zeta) + d["M_X"] * (kappa2 ** 2 * wxi * chi) + d["M_Y"] * (kappa2 ** 2 * zeta)
+           + d["N_X"] * (kappa2 ** 3 * wxi * chi) + d["N_Y"] * (kappa2 ** 3 * wyi * zeta))
+    aux_x = d["Pi_X"] * kappa2 + d["M_X"] * kappa2 ** 2 + d["N_X"] * kappa2 ** 3
+    aux_y = d["Pi_Y"] * kappa2 + d["M_Y"] * kappa2 ** 2 + d["N_Y"] * kappa2 ** 3
+    left = lhs + aux + d["B"] * a ** 4 + d["U"] * a + d["V"] * a ** 2 + d["W"] * a ** 3
+    right = ((pre["O_pub_fix"] + d["O_pub_free"]) * crs["gamma"] + d["O_mid"] * crs["eta"] + d["O_prv"] * crs["delta"]
+             + aux_x * crs["tau_x"] + aux_y * crs["tau_y"])
+    return (left - right) % R == 0

@@ -10,7 +10,9 @@ Inputs: tests/synth_circuit.py (random satisfying subcircuits in the reference's
 proof / witness fixtures and cannot be built here, so the proof bytes themselves are "parity unpinned"; what pins them is
 the commit identity (trusted-setup/src/main.rs:236-246), the transcript known answers (tests/test_transcript.py) and the
 verifier equations.  Not covered: verify_binding (needs Sigma::gen's QAP-derived tables; the binding tables here are random
-multiples of G, so O_mid / O_prv / O_pub_free are checked as the linear combinations the prover must form, nothing more)."""
+multiples of G, so O_mid / O_prv / O_pub_free are checked as the linear combinations the prover must form, nothing more).
+Update: the CRS now comes from the product's own Sigma.gen (tkmk/setup.py, checked entry by entry against the restated
+setup), so verify_binding and the combined verify_snark equation are checked too — a proof from the GPU path verifies."""
 import json
 import os
 import random
@@ -27,37 +29,53 @@ def _pins():
     return json.load(open(os.path.join(HERE, "golden", "pins.json")))
 
 
-def stage_crs(gpu, oracle, sp, rnd):
-    """fixed-tau CRS resident in HBM + the discrete logarithms of every entry"""
-    from tkmk.sigma import Sigma1
+def _tau():
     pins = _pins()
-    R = oracle.R_MOD
-    tx, ty = int(pins["tau_x"], 16), int(pins["tau_y"], 16)
+    return {k: int(pins["tau_" + k], 16) for k in ("x", "y", "alpha", "gamma", "delta", "eta")}
+
+
+def stage_crs(gpu, oracle, inst):
+    """the CRS of the fixed-tau trusted setup (setup/trusted-setup/src/main.rs:68-80), generated on the device by the product's
+    Sigma.gen (tkmk/setup.py) from the circuit's .r1cs files, + the discrete logarithm of every entry from the restatement
+    (prove_ref.sigma_gen).  -> ((sigma1, tables, singles), dlogs, g)"""
+    import prove_ref
+    from tkmk.setup import Sigma
+    pins = _pins()
     g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
+    sigma = Sigma.gen(inst["setup_params"], _tau(), inst["qap"], inst["infos"], np.frombuffer(bytes(g), np.uint8))
+    return sigma, prove_ref.sigma_gen(inst, _tau()), g
+
+
+def test_sigma_gen_equals_restated_setup(gpu, oracle, tmp_path):
+    """every G1 entry of the generated reference string is [dlog]G for the dlog the restated setup computes; the TKCRS001
+    payload written by Sigma.write reads back to the same sections"""
+    import prove_ref
+    import synth_circuit
+    from tkmk import crs as crsmod
+    inst = synth_circuit.build(str(tmp_path), random.Random(5), s_max=8, n_gate_kinds=2, used_placements=7)
+    sp = inst["setup_params"]
+    sigma, crs, g = stage_crs(gpu, oracle, inst)
+    R = oracle.R_MOD
     m_i, s_max = sp["l_D"] - sp["l"], sp["s_max"]
-    rs_x, rs_y = max(2 * sp["n"], 2 * m_i), 2 * s_max
-
-    def pts(scalars):
-        return gpu.g1_batch_scalar_mul_device(gpu.DeviceBuffer.from_host(oracle.to_bytes(scalars, 32)), g, len(scalars))
-
-    rand = lambda k: [rnd.randrange(1, R) for _ in range(k)]                          # noqa: E731
-    crs = {"tau_x": tx, "tau_y": ty, "delta": rnd.randrange(1, R), "eta": rnd.randrange(1, R),
-           "gamma_inv_o_inst": rand(sp["l"]),
-           "eta_inv_li_o_inter_alpha4_kj": [rand(s_max) for _ in range(m_i)],
-           "delta_inv_li_o_prv": [rand(s_max) for _ in range(sp["m_D"] - sp["l_D"])],
-           "delta_inv_alphak_xh_tx": [rand(3) for _ in range(3)], "delta_inv_alpha4_xj_tx": rand(2),
-           "delta_inv_alphak_yi_ty": [rand(3) for _ in range(4)]}
     flat = lambda t: [v for row in t for v in row]                                    # noqa: E731
-    sigma1 = Sigma1(pts([pow(tx, i, R) * pow(ty, j, R) % R for i in range(rs_x) for j in range(rs_y)]), rs_x, rs_y)
-    tables = {"gamma_inv_o_inst": pts(crs["gamma_inv_o_inst"]),
-              "eta_inv_li_o_inter_alpha4_kj": pts(flat(crs["eta_inv_li_o_inter_alpha4_kj"])),
-              "delta_inv_li_o_prv": pts(flat(crs["delta_inv_li_o_prv"])),
-              "delta_inv_alphak_xh_tx": pts(flat(crs["delta_inv_alphak_xh_tx"])),
-              "delta_inv_alpha4_xj_tx": pts(crs["delta_inv_alpha4_xj_tx"]),
-              "delta_inv_alphak_yi_ty": pts(flat(crs["delta_inv_alphak_yi_ty"]))}
-    singles = {"delta": np.asarray(oracle.g1_scalar_mul(oracle.to_bytes([crs["delta"]], 32), g)),
-               "eta": np.asarray(oracle.g1_scalar_mul(oracle.to_bytes([crs["eta"]], 32), g))}
-    return (sigma1, tables, singles), crs, g
+    want = {"gamma_inv_o_inst": crs["gamma_inv_o_inst"], "eta_inv_li_o_inter_alpha4_kj": flat(crs["eta_inv_li_o_inter_alpha4_kj"]),
+            "delta_inv_li_o_prv": flat(crs["delta_inv_li_o_prv"]), "delta_inv_alphak_xh_tx": flat(crs["delta_inv_alphak_xh_tx"]),
+            "delta_inv_alpha4_xj_tx": crs["delta_inv_alpha4_xj_tx"], "delta_inv_alphak_yi_ty": flat(crs["delta_inv_alphak_yi_ty"])}
+    assert any(crs["o_vec"]) and any(want["delta_inv_li_o_prv"])
+    for name, dlogs in want.items():
+        got = sigma.tables[name].to_host().reshape(-1, 96)
+        exp = np.asarray(oracle.g1_batch_scalar_mul(oracle.to_bytes(dlogs, 32), g)).reshape(-1, 96)
+        assert got.shape == exp.shape and (got == exp).all(), name
+    rs_x, rs_y = max(2 * sp["n"], 2 * m_i), 2 * s_max
+    mon = [pow(crs["tau_x"], i, R) * pow(crs["tau_y"], j, R) % R for i in range(rs_x) for j in range(rs_y)]
+    assert (sigma.sigma1.xy_powers.to_host().reshape(-1, 96) == np.asarray(oracle.g1_batch_scalar_mul(oracle.to_bytes(mon, 32), g)).reshape(-1, 96)).all()
+    for name, d in (("G", 1), ("x", crs["tau_x"]), ("y", crs["tau_y"]), ("delta", crs["delta"]), ("eta", crs["eta"]), ("lagrange_KL", crs["lagrange_KL"])):
+        assert (sigma.singles[name] == np.asarray(prove_ref.g1_of(d, g))).all(), name
+    path = sigma.write(str(tmp_path / "crs"))
+    sections = crsmod.read_payload(path)
+    crsmod.check_shapes(sections, sp)
+    assert (np.asarray(sections["eta_inv_li_o_inter_alpha4_kj"]) == sigma.tables["eta_inv_li_o_inter_alpha4_kj"].to_host()).all()
+    assert (np.asarray(crsmod.single_g1(sections, "delta")) == sigma.singles["delta"]).all()
 
 
 def seeded_mixer(seed):
@@ -66,7 +84,7 @@ def seeded_mixer(seed):
 
 
 @pytest.mark.parametrize("seed,shape", [(11, dict(s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6)),
-                                        (12, dict(s_max=4, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=3)),
+                                        (12, dict(s_max=8, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=6)),
                                         (13, dict(s_max=16, n_gate_kinds=1, n_out=3, n_in=2, n_prv=2, k_pub=3))])
 def test_prove_equals_reference_restatement_and_verifies(gpu, oracle, tmp_path, seed, shape):
     import prove_ref
@@ -76,7 +94,8 @@ def test_prove_equals_reference_restatement_and_verifies(gpu, oracle, tmp_path, 
     rnd = random.Random(seed)
     inst = synth_circuit.build(str(tmp_path), rnd, **shape)
     sp = inst["setup_params"]
-    sigma, crs, g = stage_crs(gpu, oracle, sp, rnd)
+    sigma_obj, crs, g = stage_crs(gpu, oracle, inst)
+    sigma = sigma_obj.prover_view()
     mixer = seeded_mixer(seed)
 
     prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, testing_mode=True, sigma=sigma)
@@ -91,10 +110,17 @@ def test_prove_equals_reference_restatement_and_verifies(gpu, oracle, tmp_path, 
     for name, d in ref_p4t.items():
         assert (np.asarray(p4t[name]) == np.asarray(prove_ref.g1_of(d, g))).all(), name
     assert all(v == 0 for v in rp.remainders.values()), rp.remainders
-    # the verifier's equations on the discrete logarithms (s0, s1, lagrange_KL commitments are CRS / preprocess data)
+    # all four verifier equations on the discrete logarithms, with the preprocess round run by the product on the same CRS
+    from tkmk.preprocess import Preprocess
+    pre_pts = Preprocess.gen(sigma[0], sigma[1]["gamma_inv_o_inst"], inst["permutation"], inst["instance"], sp)
+    pre = prove_ref.preprocess(rp, inst, crs)
+    for name in ("s0", "s1", "O_pub_fix"):
+        assert (np.asarray(getattr(pre_pts, name)) == np.asarray(prove_ref.g1_of(pre[name], g))).all(), name
+    k2 = rnd.randrange(1, oracle.R_MOD)
     assert prove_ref.verify_arith(dlogs, ref_scalars, ref_ch, ref_p4t, crs, sp)
-    assert prove_ref.verify_copy(dlogs, ref_scalars, ref_ch, ref_p4t, crs, sp, rp.commit(rp.s0), rp.commit(rp.s1), rp.commit(rp.KL),
-                                 kappa2=rnd.randrange(1, oracle.R_MOD))
+    assert prove_ref.verify_copy(dlogs, ref_scalars, ref_ch, ref_p4t, crs, sp, pre["s0"], pre["s1"], crs["lagrange_KL"], kappa2=k2)
+    assert prove_ref.verify_binding(dlogs, ref_scalars, ref_ch, ref_p4t, crs, pre, rp.a_free, k2)
+    assert prove_ref.verify_snark(dlogs, ref_scalars, ref_ch, crs, sp, pre, rp.a_free, k2)
     # a tampered evaluation must fail them
     bad = dict(ref_scalars, V_eval=(ref_scalars["V_eval"] + 1) % oracle.R_MOD)
     assert not prove_ref.verify_arith(dlogs, bad, ref_ch, ref_p4t, crs, sp)
@@ -110,42 +136,34 @@ def test_testing_mode_rejects_bad_witness_and_bad_copy(gpu, oracle, tmp_path):
     import synth_circuit
     from tkmk.prove import Prover
     rnd = random.Random(21)
-    inst = synth_circuit.build(str(tmp_path), rnd, s_max=4, n_gate_kinds=1)
-    sigma, _, _ = stage_crs(gpu, oracle, inst["setup_params"], rnd)
+    inst = synth_circuit.build(str(tmp_path), rnd, s_max=8, n_gate_kinds=1, used_placements=6)
+    sigma = stage_crs(gpu, oracle, inst)[0].prover_view()
     pv_path = os.path.join(inst["synth"], "placementVariables.json")
     good = json.load(open(pv_path))
     # (a) break one private wire of a gate placement: b and the copy constraints stay fine, R1CS does not
     bad = json.loads(json.dumps(good))
-    sub = inst["subs"][bad[1]["subcircuitId"]]
-    bad[1]["variables"][list(sub.prvs())[0]] = "0x5"
+    sub = inst["subs"][bad[4]["subcircuitId"]]
+    bad[4]["variables"][list(sub.prvs())[0]] = "0x5"
     json.dump(bad, open(pv_path, "w"))
     prover, _ = Prover.init(inst["qap"], inst["synth"], None, mixer=seeded_mixer(1), testing_mode=True, sigma=sigma)
     with pytest.raises(AssertionError, match="do not satisfy R1CS"):
         prover.prove0()
     # (b) break an input wire that a copy constraint ties to its source: caught in init
     bad = json.loads(json.dumps(good))
-    bad[1]["variables"][list(sub.ins())[0]] = "0x7"
+    bad[4]["variables"][list(sub.ins())[0]] = "0x7"
     json.dump(bad, open(pv_path, "w"))
     with pytest.raises(AssertionError, match="copy constraint"):
         Prover.init(inst["qap"], inst["synth"], None, mixer=seeded_mixer(1), testing_mode=True, sigma=sigma)
     json.dump(good, open(pv_path, "w"))
 
 
-def _stage_crs_file(gpu, oracle, sp, rnd, crs_dir):
-    from tkmk import crs as crsmod
-    (sigma1, tables, singles), crs, g = stage_crs(gpu, oracle, sp, rnd)
-    zero_g1 = np.zeros(96, np.uint8)
-    g_aff = np.frombuffer(bytes(g), np.uint8)
-    sections = {"g1": np.concatenate([g_aff, zero_g1, zero_g1, singles["delta"], singles["eta"], zero_g1]),
-                "xy_powers": sigma1.xy_powers.to_host(), "g2": np.zeros(10 * 192, np.uint8)}
-    sections.update({k: v.to_host() for k, v in tables.items()})
-    os.makedirs(crs_dir, exist_ok=True)
-    with open(os.path.join(crs_dir, "combined_sigma.tkcrs"), "wb") as f:
-        f.write(crsmod.build_payload(sections))
-    return (sigma1, tables, singles), crs, g
+def _stage_crs_file(gpu, oracle, inst, crs_dir):
+    sigma, crs, g = stage_crs(gpu, oracle, inst)
+    sigma.write(crs_dir)
+    return sigma.prover_view(), crs, g
 
 
-@pytest.mark.parametrize("seed,shape", [(41, dict(s_max=8, n_gate_kinds=2)), (42, dict(s_max=4, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=3))])
+@pytest.mark.parametrize("seed,shape", [(41, dict(s_max=8, n_gate_kinds=2)), (42, dict(s_max=8, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=6))])
 def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
     """tokamak-zk-evm_amd/bin/prove (host/prove_main.cpp over host/tkmk_prover.hpp, the C++ host side) writes the same proof.json as
     the Python prover for the same blinding scalars, and both equal the exponent restatement"""
@@ -160,7 +178,7 @@ def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
     inst = synth_circuit.build(str(tmp_path), rnd, **shape)
     sp = inst["setup_params"]
     crs_dir, out_dir = str(tmp_path / "crs"), str(tmp_path / "out")
-    sigma, crs, g = _stage_crs_file(gpu, oracle, sp, rnd, crs_dir)
+    sigma, crs, g = _stage_crs_file(gpu, oracle, inst, crs_dir)
     os.makedirs(out_dir)
     mixer = seeded_mixer(seed)
     hx = lambda v: [hx(e) for e in v] if isinstance(v, list) else "0x%x" % v          # noqa: E731
@@ -198,17 +216,10 @@ def test_prove_cli_files_in_files_out(gpu, oracle, tmp_path):
     from tkmk import crs as crsmod
     from tkmk import proofio
     rnd = random.Random(31)
-    inst = synth_circuit.build(str(tmp_path), rnd, s_max=4, n_gate_kinds=2)
+    inst = synth_circuit.build(str(tmp_path), rnd, s_max=8, n_gate_kinds=2, used_placements=7)
     sp = inst["setup_params"]
-    (sigma1, tables, singles), crs, g = stage_crs(gpu, oracle, sp, rnd)
-    zero_g1 = np.zeros(96, np.uint8)
-    g_aff = np.frombuffer(bytes(g), np.uint8)
-    sections = {"g1": np.concatenate([g_aff, zero_g1, zero_g1, singles["delta"], singles["eta"], zero_g1]),
-                "xy_powers": sigma1.xy_powers.to_host(), "g2": np.zeros(10 * 192, np.uint8)}
-    sections.update({k: v.to_host() for k, v in tables.items()})
     crs_dir, out_dir = tmp_path / "crs", tmp_path / "out"
-    crs_dir.mkdir()
-    (crs_dir / "combined_sigma.tkcrs").write_bytes(crsmod.build_payload(sections))
+    _, crs, g = _stage_crs_file(gpu, oracle, inst, str(crs_dir))
     pkg = os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd")
     cmd = [sys.executable, "-m", "tkmk.cli", "prove", "--crs", str(crs_dir), "--synthesizer-stat", inst["synth"], "--output", str(out_dir),
            "--subcircuit-library", inst["qap"]]

@@ -9,6 +9,8 @@ the field names of libs/src/iotools/mod.rs:166-177,366-372,399-406,458-469.
 
 Layout of one subcircuit's local wires: [0] = the constant 1, then outputs, then inputs, then private wires
 (Out_idx = [1, n_out], In_idx = [1 + n_out, n_in]).  Global wire ranges: [0, l) public, [l, l_D) interface, [l_D, m_D) private.
+Subcircuits 0..3 are the four public buffers of the library (bufferPubOut / PubIn / BlockIn / EVMIn) and occupy placements
+0..3, as the CRS assumes (gamma_inv_o_inst is built with L_0..L_3(tau_y) for them: libs/src/group_structures/mod.rs:405-440).
 """
 import json
 import os
@@ -65,9 +67,13 @@ class Subcircuit:
         return w
 
 
-def buffer_pub_in(sid, k):
-    """the shape of the library's bufferPubIn: out_i * 1 = in_i"""
-    s = Subcircuit(sid, "bufferPubIn", k, k, 0)
+BUFFER_NAMES = ("bufferPubOut", "bufferPubIn", "bufferBlockIn", "bufferEVMIn")
+
+
+def buffer(sid, name, k):
+    """the shape of the library's four public buffers: out_i * 1 = in_i.  bufferPubOut's OUTPUTS are public wires, the other
+    three have public INPUTS (libs/src/group_structures/mod.rs:184-229 picks Out_idx / In_idx accordingly)"""
+    s = Subcircuit(sid, name, k, k, 0)
     for o, i in zip(s.outs(), s.ins()):
         s.define(o, [(i, 1)], [(0, 1)], [])
     return s
@@ -84,17 +90,24 @@ def random_gates(sid, rnd, n_out, n_in, n_prv, fan=3):
 
 
 def generate(rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub=2, used_placements=None, l_free=4, l_extra=4, n=None,
-             m_i=None, pool=None):
+             m_i=None, pool=None, k_out=1):
     """-> the instance in memory (setup params, subcircuit infos, placements with witnesses, permutation, instance).
-    pool=K (production shapes): only K distinct gate witnesses are computed — every placement past the first K re-uses one
-    of them together with its input wiring, so generation stays at K forward evaluations however many placements there are;
-    the copy constraints (one cycle per consumed source wire) and R1CS satisfaction hold exactly as in the unpooled case."""
-    subs = [buffer_pub_in(0, k_pub)] + [random_gates(1 + g, rnd, n_out, n_in, n_prv) for g in range(n_gate_kinds)]
-    l_user = k_pub
-    assert l_user <= l_free
-    l = l_free + l_extra
-    # interface wires: constant + outputs + inputs of every subcircuit (the public buffer's inputs are public wires)
-    need_iface = sum(1 + s.n_out + (0 if s.id == 0 else s.n_in) for s in subs)
+
+    Public wires follow the layout the CRS is built for (Sigma1::gen, libs/src/group_structures/mod.rs:405-440): placement 0 is
+    bufferPubOut (k_out = l_user_out public outputs), 1 bufferPubIn (k_pub user inputs), 2 bufferBlockIn (l_free - l_user block
+    inputs), 3 bufferEVMIn (l_extra = l - l_free function inputs); gate placements follow, fed by the buffers' interface outputs
+    and by earlier gates, and bufferPubOut takes its inputs from gate outputs.  Every feed is a copy constraint.
+    pool=K (production shapes): only K distinct gate witnesses are computed — every gate placement past the first K re-uses one
+    of them together with its input wiring, so generation stays at K forward evaluations however many placements there are."""
+    l_user_out, l_user = k_out, k_out + k_pub
+    k_block, k_fn = l_free - l_user, l_extra
+    assert k_block >= 0 and l_free & (l_free - 1) == 0
+    l = l_free + k_fn
+    subs = [buffer(i, name, k) for i, (name, k) in enumerate(zip(BUFFER_NAMES, (k_out, k_pub, k_block, k_fn)))]
+    subs += [random_gates(4 + g, rnd, n_out, n_in, n_prv) for g in range(n_gate_kinds)]
+    pub_base = (0, l_user_out, l_user, l_free)        # first public wire of each buffer
+    # interface wires: constant + the non-public side of the buffers, constant + outputs + inputs of the gates
+    need_iface = sum(1 + s.n_out for s in subs[:4]) + sum(1 + s.n_out + s.n_in for s in subs[4:])
     if m_i is None:
         m_i = 1 << (need_iface - 1).bit_length()
     assert need_iface <= m_i and m_i & (m_i - 1) == 0
@@ -104,51 +117,58 @@ def generate(rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub=2, us
         fm = [0] * s.n_wires
         fm[0] = nxt_iface
         nxt_iface += 1
-        for w in s.outs():
+        public = s.outs() if s.id == 0 else (s.ins() if s.id < 4 else ())
+        for w in list(s.outs()) + list(s.ins()):
+            if w in public:
+                continue
             fm[w] = nxt_iface
             nxt_iface += 1
-        for j, w in enumerate(s.ins()):
-            if s.id == 0:
-                fm[w] = j                              # public user inputs: global indices [0, l_user)
-            else:
-                fm[w] = nxt_iface
-                nxt_iface += 1
+        for j, w in enumerate(public):
+            fm[w] = pub_base[s.id] + j
         for w in s.prvs():
             fm[w] = nxt_prv
             nxt_prv += 1
         s.flatten_map = fm
     m_D = nxt_prv
-    n_min = 1 << (max(len(s.rows) for s in subs) - 1).bit_length()
+    n_min = 1 << max(0, max(len(s.rows) for s in subs) - 1).bit_length()
     n = n_min if n is None else n
     assert n >= n_min
-    sp = {"l_free": l_free, "l_user_out": 0, "l_user": l_user, "l": l, "l_D": l_D, "m_D": m_D, "n": n, "s_D": len(subs), "s_max": s_max}
+    sp = {"l_free": l_free, "l_user_out": l_user_out, "l_user": l_user, "l": l, "l_D": l_D, "m_D": m_D, "n": n, "s_D": len(subs), "s_max": s_max}
     infos = [{"id": s.id, "name": s.name, "Nwires": s.n_wires, "Nconsts": len(s.rows), "Out_idx": [1, s.n_out],
               "In_idx": [1 + s.n_out, s.n_in], "flattenMap": s.flatten_map} for s in subs]
 
-    # placements: 0 = the public buffer, then gates fed by earlier outputs; every feed is a copy constraint
     used = s_max if used_placements is None else used_placements
+    assert 5 <= used <= s_max, "four buffers and at least one gate placement"
     hx = lambda v: "0x%x" % v                                                        # noqa: E731
-    pub_vals = [rnd.randrange(R) for _ in range(k_pub)]
-    placements = [(subs[0], subs[0].witness(pub_vals))]
-    hexes = [[hx(v) for v in placements[0][1]]]
-    sources = [None]                                  # per placement: the (placement, wire) feeding each input
-    produced = [(0, w) for w in subs[0].outs()]       # (placement, local wire) whose value may be consumed
+    placements, hexes, sources = [None] * 4, [None] * 4, [None] * 4
+    produced = []                                     # (placement, local wire) whose value may be consumed
+    for b in (1, 2, 3):
+        w = subs[b].witness([rnd.randrange(R) for _ in subs[b].ins()])
+        placements[b], hexes[b] = (subs[b], w), [hx(v) for v in w]
+        produced += [(b, o) for o in subs[b].outs()]
     consumers = {}                                    # source (placement, wire) -> [(placement, wire), ...]
-    for p in range(1, used):
-        if pool is not None and p > pool:
-            q = 1 + rnd.randrange(pool)               # same subcircuit, same sources, same witness as placement q
+    gate_outs = []
+    for p in range(4, used):
+        if pool is not None and p >= 4 + pool:
+            q = 4 + rnd.randrange(pool)               # same subcircuit, same sources, same witness as placement q
             s, w, srcs = placements[q][0], placements[q][1], sources[q]
             hexes.append(hexes[q])
         else:
-            s = subs[1 + rnd.randrange(n_gate_kinds)]
+            s = subs[4 + rnd.randrange(n_gate_kinds)]
             srcs = [rnd.choice(produced) for _ in s.ins()]
             w = s.witness([placements[sp_][1][sw] for sp_, sw in srcs])
             hexes.append([hx(v) for v in w])
             produced += [(p, o) for o in s.outs()]
+            gate_outs += [(p, o) for o in s.outs()]
         placements.append((s, w))
         sources.append(srcs)
         for src, dst in zip(srcs, s.ins()):
             consumers.setdefault(src, []).append((p, dst))
+    srcs0 = [rnd.choice(gate_outs) for _ in subs[0].ins()]
+    w0 = subs[0].witness([placements[sp_][1][sw] for sp_, sw in srcs0])
+    placements[0], hexes[0] = (subs[0], w0), [hx(v) for v in w0]
+    for src, dst in zip(srcs0, subs[0].ins()):
+        consumers.setdefault(src, []).append((0, dst))
     cell = lambda pl, wire: (placements[pl][0].flatten_map[wire] - l, pl)              # noqa: E731   (row, col)
     perm = []
     for src, dsts in consumers.items():
@@ -156,8 +176,9 @@ def generate(rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub=2, us
         for a, b in zip(cyc, cyc[1:] + cyc[:1]):
             perm.append({"row": a[0], "col": a[1], "X": b[0], "Y": b[1]})
     pv = [{"subcircuitId": s.id, "variables": h} for (s, _), h in zip(placements, hexes)]
-    instance = {"a_pub_user": [hx(v) for v in pub_vals], "a_pub_block": [hx(rnd.randrange(R)) for _ in range(l_free - l_user)],
-                "a_pub_function": [hx(rnd.randrange(R)) for _ in range(l - l_free)]}
+    pub = lambda b, wires: [hx(placements[b][1][w]) for w in wires]                    # noqa: E731
+    instance = {"a_pub_user": pub(0, subs[0].outs()) + pub(1, subs[1].ins()), "a_pub_block": pub(2, subs[2].ins()),
+                "a_pub_function": pub(3, subs[3].ins())}
     return {"setup_params": sp, "infos": infos, "subs": subs, "placements": placements, "placement_variables": pv,
             "instance": instance, "permutation": perm, "m_i": m_i,
             "r1cs_rows": sum(len(s.rows) for s, _ in placements)}
