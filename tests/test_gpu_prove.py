@@ -209,7 +209,8 @@ def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
 
 
 def test_prove_cli_files_in_files_out(gpu, oracle, tmp_path):
-    """process-level surface of `prove` (prove/src/main.rs:8-25): directories in, proof.json out; CRS staged as TKCRS001"""
+    """process-level surface: `setup --fixed-tau` (setup/trusted-setup/src/main.rs:27-46) writes the CRS, `preprocess` and `prove`
+    (preprocess/src/main.rs, prove/src/main.rs:8-25) read it: directories in, preprocess.json / proof.json out"""
     import subprocess
     import sys
     import synth_circuit
@@ -219,8 +220,15 @@ def test_prove_cli_files_in_files_out(gpu, oracle, tmp_path):
     inst = synth_circuit.build(str(tmp_path), rnd, s_max=8, n_gate_kinds=2, used_placements=7)
     sp = inst["setup_params"]
     crs_dir, out_dir = tmp_path / "crs", tmp_path / "out"
-    _, crs, g = _stage_crs_file(gpu, oracle, inst, str(crs_dir))
     pkg = os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd")
+    r = subprocess.run([sys.executable, "-m", "tkmk.cli", "setup", "--fixed-tau", "--subcircuit-library", inst["qap"], "--output", str(crs_dir)],
+                       cwd=pkg, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    sigma_obj, crs, g = stage_crs(gpu, oracle, inst)
+    assert open(crs_dir / "combined_sigma.tkcrs", "rb").read() == sigma_obj.payload()      # the command is Sigma.gen with the fixed tau
+    r = subprocess.run([sys.executable, "-m", "tkmk.cli", "preprocess", "--crs", str(crs_dir), "--synthesizer-stat", inst["synth"], "--output",
+                        str(out_dir), "--subcircuit-library", inst["qap"]], cwd=pkg, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
     cmd = [sys.executable, "-m", "tkmk.cli", "prove", "--crs", str(crs_dir), "--synthesizer-stat", inst["synth"], "--output", str(out_dir),
            "--subcircuit-library", inst["qap"]]
     runs = []
@@ -236,6 +244,10 @@ def test_prove_cli_files_in_files_out(gpu, oracle, tmp_path):
         assert (np.asarray(p_a[k]) == np.asarray(prove_ref.g1_of(bind[k], g))).all()
         assert (np.asarray(p_a[k]) == np.asarray(p_b[k])).all()
     assert not (np.asarray(p_a["U"]) == np.asarray(p_b["U"])).all()       # fresh mixer every run (lib.rs:1040-1080)
+    pre_pts = proofio.recover_preprocess(json.load(open(out_dir / "preprocess.json")))
+    pre = prove_ref.preprocess(rp, inst, crs)
+    for k in ("s0", "s1", "O_pub_fix"):
+        assert (np.asarray(pre_pts[k]) == np.asarray(prove_ref.g1_of(pre[k], g))).all(), k
     # missing CRS -> the reference's message and a non-zero exit
     os.remove(crs_dir / "combined_sigma.tkcrs")
     r = subprocess.run(cmd, cwd=pkg, capture_output=True, text=True, timeout=600)

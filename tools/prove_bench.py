@@ -3,8 +3,8 @@
 Shapes: --s-max 256 is the reference's production shape (n = 4096, m_I = 4096, s_max = 256: 2^20 constraint slots;
 reference walls 45.70 s CPU / 21.08 s CUDA with 166 placements); --s-max 1024 is BASELINE.json configs[3]'s
 "2^22-constraint circuit" (SURVEY.md §8d cfg 4).  The circuit comes from tools/synth_circuit.py (random satisfying
-subcircuits, iden3 .r1cs files on disk, synthesizer documents handed over in memory); the CRS is the fixed-tau recipe
-(xy_powers[i * 2 s_max + j] = [tau_x^i tau_y^j]G built on the device), the binding tables are random multiples of G.
+subcircuits, iden3 .r1cs files on disk, synthesizer documents handed over in memory); the CRS is the fixed-tau trusted setup of
+that circuit, generated on the device by tkmk/setup.py (Sigma.gen: xy_powers and the QAP-derived binding tables).
 --check runs the reference's testing-mode assertions (R1CS satisfaction, Lemma 3, quotient identities, zero remainders)
 at full size and compares three commitments with [P(tau_x, tau_y)]G.
 
@@ -26,34 +26,12 @@ PINS = json.load(open(os.path.join(ROOT, "tests", "golden", "pins.json")))      
 TAU_X, TAU_Y = int(PINS["tau_x"], 16), int(PINS["tau_y"], 16)
 
 
-def stage_crs(tkmk, sp, seed):
-    from tkmk.prove import fr
-    from tkmk.sigma import Sigma1
-    pins = PINS
-    g = np.frombuffer(int(pins["fixed_tau_g1_x"], 16).to_bytes(48, "little") + int(pins["fixed_tau_g1_y"], 16).to_bytes(48, "little"), np.uint8).copy()
-    m_i, s_max = sp["l_D"] - sp["l"], sp["s_max"]
-    rs_x, rs_y = max(2 * sp["n"], 2 * m_i), 2 * s_max
-    lib = tkmk.lib()
-    one = np.zeros(32, np.uint8)
-    one[0] = 1
-    ones = tkmk.DeviceBuffer.from_host(np.tile(one, rs_x * rs_y))
-    mon = tkmk.DeviceBuffer(32 * rs_x * rs_y)          # mon[i][j] = tau_x^i tau_y^j
-    tkmk._check(lib.tkmk_poly_scale_coeffs(tkmk._p(ones), rs_x, rs_y, tkmk._p(fr(TAU_X)), tkmk._p(fr(TAU_Y)), tkmk._p(mon), None),
-                "tkmk_poly_scale_coeffs")
-    sigma1 = Sigma1(tkmk.g1_batch_scalar_mul_device(mon, g, rs_x * rs_y), rs_x, rs_y)
-
-    def rand_pts(k, first):
-        return tkmk.g1_batch_scalar_mul_device(tkmk.fr_random_device(seed, k, first=first), g, k)
-
-    sizes = {"gamma_inv_o_inst": sp["l"], "eta_inv_li_o_inter_alpha4_kj": m_i * s_max, "delta_inv_li_o_prv": (sp["m_D"] - sp["l_D"]) * s_max,
-             "delta_inv_alphak_xh_tx": 9, "delta_inv_alpha4_xj_tx": 2, "delta_inv_alphak_yi_ty": 12}
-    tables, first = {}, 0
-    for name, k in sizes.items():
-        tables[name] = rand_pts(k, first)
-        first += k
-    two = rand_pts(2, first).to_host()
-    singles = {"delta": two[:96].copy(), "eta": two[96:].copy()}
-    return (sigma1, tables, singles), g
+def stage_crs(tkmk, inst):
+    """the reference string of the fixed-tau trusted setup for this circuit, generated on the device (tkmk/setup.py)"""
+    from tkmk.setup import Sigma
+    g = np.frombuffer(int(PINS["fixed_tau_g1_x"], 16).to_bytes(48, "little") + int(PINS["fixed_tau_g1_y"], 16).to_bytes(48, "little"), np.uint8).copy()
+    tau = {k: int(PINS["tau_" + k], 16) for k in ("x", "y", "alpha", "gamma", "delta", "eta")}
+    return Sigma.gen(inst["setup_params"], tau, inst["qap"], inst["infos"], g), g
 
 
 def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, seed=0x746F6B616D616B04, profile_host=False):
@@ -68,7 +46,8 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
     sp = inst["setup_params"]
     gen_s = time.perf_counter() - t
     t = time.perf_counter()
-    sigma, g = stage_crs(tkmk, sp, seed)
+    sigma_obj, g = stage_crs(tkmk, inst)
+    sigma = sigma_obj.prover_view()
     tkmk.synchronize()
     crs_s = time.perf_counter() - t
     inputs = {"setup_params": sp, "subcircuit_infos": inst["infos"], "placement_variables": inst["placement_variables"],
@@ -109,7 +88,7 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
         del prover
-    del sigma
+    del sigma, sigma_obj
     return {"workload": "prove (init + prove0..4): synthetic circuit n=%d m_I=%d s_max=%d, %d placements, %d real R1CS rows" % (
         sp["n"], sp["l_D"] - sp["l"], sp["s_max"], len(inst["placement_variables"]), inst["r1cs_rows"]),
         "setup_params": sp, "constraint_slots": slots, "r1cs_rows": inst["r1cs_rows"], "seconds": best, "runs": runs,
@@ -133,17 +112,14 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
     try:
         synth_circuit.write(inst, tmp)
         sp = inst["setup_params"]
-        (sigma1, tables, singles), g = stage_crs(tkmk, sp, seed)
-        zero = np.zeros(96, np.uint8)
-        sections = {"g1": np.concatenate([g, zero, zero, singles["delta"], singles["eta"], zero]), "xy_powers": sigma1.xy_powers.to_host(),
-                    "g2": np.zeros(10 * 192, np.uint8)}
-        sections.update({k: v.to_host() for k, v in tables.items()})
-        os.makedirs(os.path.join(tmp, "crs"))
-        with open(os.path.join(tmp, "crs", "combined_sigma.tkcrs"), "wb") as f:
-            f.write(crsmod.build_payload(sections))
+        t_setup = time.perf_counter()
+        sigma_obj, g = stage_crs(tkmk, inst)
+        tkmk.synchronize()
+        setup_s = time.perf_counter() - t_setup
+        sigma_obj.write(os.path.join(tmp, "crs"))
         crs_bytes = os.path.getsize(os.path.join(tmp, "crs", "combined_sigma.tkcrs"))
         pv_bytes = os.path.getsize(os.path.join(inst["synth"], "placementVariables.json"))
-        del sections, sigma1, tables
+        del sigma_obj
         tkmk.release_scratch()
         binary = os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "prove")
         cmd = [binary, "--crs", os.path.join(tmp, "crs"), "--synthesizer-stat", inst["synth"], "--output", os.path.join(tmp, "out"),
@@ -170,7 +146,7 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
         sp["n"], sp["l_D"] - sp["l"], sp["s_max"], len(inst["placement_variables"]), inst["r1cs_rows"]),
         "constraint_slots": slots, "r1cs_rows": inst["r1cs_rows"], "seconds": best, "runs": runs,
         "constraint_slots_per_s": round(slots / best["total"]), "constraint_slots_per_s_init_plus_rounds": round(slots / compute),
-        "crs_payload_bytes": crs_bytes, "placement_variables_json_bytes": pv_bytes}
+        "crs_payload_bytes": crs_bytes, "placement_variables_json_bytes": pv_bytes, "sigma_gen_s": round(setup_s, 3)}
 
 
 def main():
