@@ -285,6 +285,14 @@ def _prove_secondary(tkmk):
                     "per_round_s": {k: r["seconds"][k] for k in ("prove0", "prove1", "prove2", "prove3", "prove4")},
                     "constraint_slots": r["constraint_slots"], "r1cs_rows": r["r1cs_rows"]}
         tkmk.release_scratch()
+    # the same production-shape proof through the native binary (C++ host side): files in the reference's formats in, proof.json
+    # out, a fresh process per run, CRS payload and JSON inputs loaded inside the timed total
+    r = prove_bench.run_native(s_max=256, placements=166, repeat=2)
+    out["native_production_2p20"] = {"workload": r["workload"], "constraints_per_s": r["constraint_slots_per_s"],
+                                     "constraints_per_s_init_plus_rounds": r["constraint_slots_per_s_init_plus_rounds"],
+                                     "wall_s": r["seconds"]["total"], "seconds": r["seconds"], "sigma_gen_s": r["sigma_gen_s"],
+                                     "crs_payload_bytes": r["crs_payload_bytes"], "placement_variables_json_bytes": r["placement_variables_json_bytes"]}
+    tkmk.release_scratch()
     out["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md §1)"}
     return out
 

@@ -147,13 +147,13 @@ inline ScalarField fr_inv(const ScalarField &a) {
     return r;
 }
 // ScalarField::from_hex on a HexString (libs/src/iotools/mod.rs:126-146): optional 0x, big-endian digits, reduced mod r
-inline ScalarField fr_from_hex(const std::string &h) {
-    size_t off = (h.size() >= 2 && h[0] == '0' && (h[1] == 'x' || h[1] == 'X')) ? 2 : 0;
-    size_t nd = h.size() - off;
+inline ScalarField fr_from_hex(const char *h, size_t len) {
+    size_t off = (len >= 2 && h[0] == '0' && (h[1] == 'x' || h[1] == 'X')) ? 2 : 0;
+    size_t nd = len - off;
     if (nd > 64) throw Error("hex scalar longer than 32 bytes");
     uint8_t le[32] = {};
     for (size_t k = 0; k < nd; k++) {   // digit k counted from the least significant end
-        char c = h[h.size() - 1 - k];
+        char c = h[len - 1 - k];
         int v = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
         if (v < 0) throw Error("invalid hex digit in scalar");
         le[k / 2] |= (uint8_t)(v << (4 * (k & 1)));
@@ -163,5 +163,6 @@ inline ScalarField fr_from_hex(const std::string &h) {
     while (frh::geq(v, frh::MOD)) v = frh::sub_raw(v, frh::MOD);
     return frh::store(v);
 }
+inline ScalarField fr_from_hex(const std::string &h) { return fr_from_hex(h.data(), h.size()); }
 
 }  // namespace tkmk
