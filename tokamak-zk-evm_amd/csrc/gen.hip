@@ -62,6 +62,93 @@ __global__ __launch_bounds__(128) void k_g1_batch_scalar_mul(const typename Fr::
     tk_store(out + i, r);
 }
 
+// ---- fixed-base path for large batches (CRS generation: 2^22 .. 2^24 multiples of one generator, Sigma1::gen) ----
+// table[j * 256 + d] = [d * 2^(8 j)] P as affine Montgomery points ((0,0) for d = 0), j < ceil(bits / 8): a scalar is then
+// one mixed addition per byte instead of 256 doublings + 64 general additions, and the affine conversion shares one inversion
+// between FB_K results (Montgomery's trick, prefix products staged in LDS).
+constexpr int FB_K = 16;
+
+template <class Fq>
+__global__ __launch_bounds__(64) void k_fb_window_bases(affine_t<Fq> base, int windows, affine_t<Fq> *__restrict__ table) {
+    using G1 = ec<Fq>;
+    int j = threadIdx.x;
+    if (j >= windows) return;
+    affine_t<Fq> b = base;
+    if (!G1::is_inf(b)) {
+        b.x = Fq::to_mont(Fq::canon(b.x));
+        b.y = Fq::to_mont(Fq::canon(b.y));
+    }
+    xyzz_t<Fq> acc = G1::from_affine(b);
+    for (int k = 0; k < 8 * j; k++) acc = G1::dbl(acc);
+    table[j * 256 + 1] = G1::to_affine(acc);   // Montgomery form kept
+}
+template <class Fq>
+__global__ __launch_bounds__(256) void k_fb_table_rows(int windows, affine_t<Fq> *__restrict__ table) {
+    using G1 = ec<Fq>;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= windows * 256) return;
+    int j = e >> 8, d = e & 255;
+    if (d == 1) return;
+    affine_t<Fq> out;
+    out.x = Fq::zero();
+    out.y = Fq::zero();
+    if (d) {
+        affine_t<Fq> b = table[j * 256 + 1];
+        xyzz_t<Fq> acc = G1::inf();
+        for (int bit = 7; bit >= 0; bit--) {
+            acc = G1::dbl(acc);
+            if ((d >> bit) & 1) acc = G1::add_mixed(acc, b);
+        }
+        out = G1::to_affine(acc);
+    }
+    table[e] = out;
+}
+// rows d = 1 are read by k_fb_table_rows while other lanes write rows d != 1 of the same table: disjoint entries
+template <class Fr, class Fq>
+__global__ __launch_bounds__(128) void k_fb_accumulate(const typename Fr::E *__restrict__ scalars, const affine_t<Fq> *__restrict__ table,
+                                                      int windows, uint64_t n, xyzz_t<Fq> *__restrict__ acc_out) {
+    using G1 = ec<Fq>;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typename Fr::E s = Fr::canon(tk_load(scalars + i));
+    xyzz_t<Fq> acc = G1::inf();
+    for (int j = 0; j < windows; j++) {
+        uint32_t d = (s.l[j >> 2] >> ((j & 3) * 8)) & 255u;
+        if (d) acc = G1::add_mixed(acc, table[j * 256 + d]);
+    }
+    acc_out[i] = acc;
+}
+template <class Fq>
+__global__ __launch_bounds__(64) void k_fb_to_affine(const xyzz_t<Fq> *__restrict__ acc, uint64_t n, affine_t<Fq> *__restrict__ out) {
+    using E = typename Fq::E;
+    __shared__ E pref[FB_K][64];
+    uint64_t first = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * FB_K;
+    if (first >= n) return;
+    int cnt = (int)((n - first) < (uint64_t)FB_K ? (n - first) : (uint64_t)FB_K);
+    E run = Fq::one();
+    for (int k = 0; k < cnt; k++) {   // pref[k] = product of the non-zero zzz before k
+        pref[k][threadIdx.x] = run;
+        E z = acc[first + k].zzz;
+        if (!Fq::is_zero(z)) run = Fq::mul(run, z);
+    }
+    E inv = Fq::inv(run);
+    for (int k = cnt - 1; k >= 0; k--) {
+        xyzz_t<Fq> p = acc[first + k];
+        affine_t<Fq> r;
+        if (Fq::is_zero(p.zz)) {
+            r.x = Fq::zero();
+            r.y = Fq::zero();
+        } else {
+            E izzz = Fq::mul(inv, pref[k][threadIdx.x]);
+            inv = Fq::mul(inv, p.zzz);
+            E izz = Fq::sqr(Fq::mul(p.zz, izzz));   // (ZZ / ZZZ)^2 = 1 / ZZ
+            r.x = Fq::from_mont(Fq::mul(p.x, izz));
+            r.y = Fq::from_mont(Fq::mul(p.y, izzz));
+        }
+        tk_store(out + first + k, r);
+    }
+}
+
 template <class Fr>
 static tkmk_error fr_random_device(uint64_t seed, uint64_t first, uint64_t n, void *out_dev, tkmk_stream s) {
     if (!out_dev && n) return TKMK_ERR_INVALID_POINTER;
@@ -90,10 +177,32 @@ static tkmk_error g1_batch_scalar_mul_device(const void *scalars_dev, const uint
         b.x.l[i] = base_x[i];
         b.y.l[i] = base_y[i];
     }
-    hipLaunchKernelGGL((k_g1_batch_scalar_mul<Fr, Fq>), tk_div_up(n, 128), 128, 0, tk_stream(s), (const typename Fr::E *)scalars_dev, b,
-                       n, (affine_t<Fq> *)out_dev);
+    hipStream_t st = tk_stream(s);
+    if (n < 8192) {   // small batches (single CRS points, test vectors): the table would cost more than it saves
+        hipLaunchKernelGGL((k_g1_batch_scalar_mul<Fr, Fq>), tk_div_up(n, 128), 128, 0, st, (const typename Fr::E *)scalars_dev, b, n,
+                           (affine_t<Fq> *)out_dev);
+        TK_HIP(hipGetLastError());
+        TK_HIP(hipStreamSynchronize(st));
+        return TKMK_SUCCESS;
+    }
+    constexpr int windows = (int)sizeof(typename Fr::E) / 4 * 4;   // one byte per window over the whole limb array (32 for both curves)
+    static_assert(windows <= 64, "k_fb_window_bases runs one lane per window");
+    const uint64_t tile = (uint64_t)1 << 22;                        // 768 MiB of XYZZ scratch per tile
+    tk_frame frame(st);
+    tk_scratch tbl, acc;
+    TK_TRY(tbl.alloc((size_t)windows * 256 * sizeof(affine_t<Fq>), st));
+    TK_TRY(acc.alloc((size_t)(n < tile ? n : tile) * sizeof(xyzz_t<Fq>), st));
+    hipLaunchKernelGGL((k_fb_window_bases<Fq>), 1, 64, 0, st, b, windows, tbl.as<affine_t<Fq>>());
+    hipLaunchKernelGGL((k_fb_table_rows<Fq>), tk_div_up((uint64_t)windows * 256, 256), 256, 0, st, windows, tbl.as<affine_t<Fq>>());
+    for (uint64_t off = 0; off < n; off += tile) {
+        uint64_t m = n - off < tile ? n - off : tile;
+        hipLaunchKernelGGL((k_fb_accumulate<Fr, Fq>), tk_div_up(m, 128), 128, 0, st, (const typename Fr::E *)scalars_dev + off,
+                           (const affine_t<Fq> *)tbl.p, windows, m, acc.as<xyzz_t<Fq>>());
+        hipLaunchKernelGGL((k_fb_to_affine<Fq>), tk_div_up(tk_div_up(m, FB_K), 64), 64, 0, st, (const xyzz_t<Fq> *)acc.p, m,
+                           (affine_t<Fq> *)out_dev + off);
+    }
     TK_HIP(hipGetLastError());
-    TK_HIP(hipStreamSynchronize(tk_stream(s)));
+    TK_HIP(hipStreamSynchronize(st));
     return TKMK_SUCCESS;
 }
 TK_API tkmk_error tkmk_g1_batch_scalar_mul_device(const tkmk_fr *scalars_dev, const tkmk_g1_affine *base_host, uint64_t n,
