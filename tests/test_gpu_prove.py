@@ -256,3 +256,61 @@ def test_prove_cli_files_in_files_out(gpu, oracle, tmp_path):
     os.remove(crs_dir / "combined_sigma.tkcrs")
     r = subprocess.run(cmd, cwd=pkg, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "No reference string is found" in (r.stderr + r.stdout)
+
+
+def _dist_prove_worker(rank, world, port, tmp, seed, q):
+    import sys
+    root = os.path.dirname(HERE)
+    sys.path[:0] = [root, os.path.join(root, "tokamak-zk-evm_amd"), os.path.join(root, "tools"), HERE]
+    import torch.distributed as dist
+    import oracle
+    import synth_circuit
+    import tkmk
+    from tkmk.prove import Prover, run_rounds
+    from tkmk.setup import Sigma
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tkmk.set_device(0)                               # rehearsal: both ranks on GPU 0 (one-GPU box); RCCL ranks use their own GPU
+        inst = synth_circuit.build(os.path.join(tmp, "rank%d" % rank), random.Random(seed), s_max=8, n_gate_kinds=2, used_placements=7)
+        pins = _pins()
+        g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
+        sigma = Sigma.gen(inst["setup_params"], _tau(), inst["qap"], inst["infos"], np.frombuffer(bytes(g), np.uint8))
+        sigma.sigma1.dist, sigma.sigma1.comm_device = dist, "cpu"
+        prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=seeded_mixer(seed), sigma=sigma.prover_view())
+        points, scalars, _, _, _ = run_rounds(prover, binding)
+        q.put((rank, {k: bytes(np.asarray(v)) for k, v in points.items()}, scalars))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_prove_with_round_commits_spread_over_two_ranks(gpu, oracle, tmp_path):
+    """SURVEY.md §8e row 4 in the real prover: two ranks (gloo; both on GPU 0 here) replicate the polynomial work, each runs the
+    commitments it owns (sharding.balanced_assignment), one all_gather per round — both end with the single-process proof"""
+    import socket
+    import synth_circuit
+    import torch.multiprocessing as mp
+    from tkmk.prove import Prover, run_rounds
+    seed = 51
+    inst = synth_circuit.build(str(tmp_path / "single"), random.Random(seed), s_max=8, n_gate_kinds=2, used_placements=7)
+    sigma = stage_crs(gpu, oracle, inst)[0]
+    prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=seeded_mixer(seed), sigma=sigma.prover_view())
+    points, scalars, _, _, _ = run_rounds(prover, binding)
+    want = {k: bytes(np.asarray(v)) for k, v in points.items()}
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_prove_worker, args=(r, 2, port, str(tmp_path), seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=400) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in got) == [0, 1]
+    for _, pts, sc in got:
+        assert pts == want and sc == scalars

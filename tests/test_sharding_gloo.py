@@ -174,3 +174,62 @@ def test_round_commits_sharded_world2_gloo():
         p.join(240)
         assert p.exitcode == 0
     assert dict(q.get(timeout=10) for _ in range(world)) == {0: True, 1: True}
+
+
+def test_balanced_assignment_is_deterministic_and_balanced():
+    from tkmk import sharding
+    # one prove4 round at the production shape: two 4 M-point commits, five ~1 M, two tiny (prove/src/lib.rs prove4)
+    sizes = [1052929, 257, 1052929, 258, 1052929, 258, 4194304, 512, 127]
+    for world in (1, 2, 4, 8):
+        owner = sharding.balanced_assignment(sizes, world)
+        assert owner == sharding.balanced_assignment(list(sizes), world) and set(owner) <= set(range(world))
+        load = [sum(s for s, o in zip(sizes, owner) if o == q) for q in range(world)]
+        assert max(load) <= max(max(sizes), -(-sum(sizes) // world) + max(s for s in sizes if s < max(sizes)))
+    assert sharding.balanced_assignment(sizes, 2).count(0) + sharding.balanced_assignment(sizes, 2).count(1) == len(sizes)
+    assert sharding.balanced_assignment([], 4) == []
+
+
+def _balanced_worker(rank, world, port, sizes, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tokamak-zk-evm_amd"))
+    import torch.distributed as dist
+    import oracle
+    from tkmk import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        jobs = [(oracle.fr_random(60 + k, n), oracle.g1_random_bases(80 + k, n), n) for k, n in enumerate(sizes)]
+        touched = []
+
+        def oracle_multi(js):                    # test-only stand-in for tkmk.msm_multi: 96-byte affine results
+            touched.extend(j[2] for j in js)
+            return np.concatenate([oracle.g1_msm(s, p, threads=1) for s, p, _ in js]) if js else np.zeros(0, np.uint8)
+
+        got = sharding.commits_balanced(oracle_multi, dist, jobs, sizes, result_bytes=96, device="cpu")
+        want = np.stack([oracle.g1_msm(s, p, threads=1) for s, p, _ in jobs])
+        owner = sharding.balanced_assignment(sizes, world)
+        mine = [sizes[j] for j in range(len(sizes)) if owner[j] == rank]
+        q.put((rank, bool((got == want).all()) and touched == mine))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_round_commits_balanced_world2_gloo():
+    """the commits of one round spread by size (what Sigma1.encode_polys does when a process group is set): every rank ends with
+    all commitments in job order, each MSM ran on exactly one rank, the big job sits alone"""
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_balanced_worker, args=(r, world, port, [9, 70, 11, 8, 10, 12], q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=10) for _ in range(world)) == {0: True, 1: True}

@@ -121,3 +121,41 @@ def commits_sharded(msm_multi, dist, jobs, result_bytes=144, device="cuda"):
         for k, j in enumerate(jobs_of_rank(n, q, G)):
             res[j] = got[k]
     return res
+
+
+def balanced_assignment(sizes, world):
+    """jobs -> ranks by size: largest first onto the least loaded rank (ties to the lower rank), the same on every rank.
+    A prover round mixes 4 M-point and few-hundred-point commits, so j mod G would leave ranks idle.  -> [rank of job j]"""
+    load = [0] * world
+    owner = [0] * len(sizes)
+    for j in sorted(range(len(sizes)), key=lambda k: (-int(sizes[k]), k)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[j] = r
+        load[r] += int(sizes[j])
+    return owner
+
+
+def commits_balanced(msm_multi, dist, jobs, sizes, result_bytes=144, device="cuda"):
+    """commits_sharded with balanced_assignment(sizes): ONE all_gather of max-jobs-per-rank results; every rank returns all
+    commitments in job order.  jobs[j] is only touched on its owner."""
+    import torch
+    n = len(jobs)
+    if dist is None or dist.get_world_size() == 1 or n == 0:
+        return np.asarray(msm_multi(jobs)).reshape(n, result_bytes)
+    G, r = dist.get_world_size(), dist.get_rank()
+    owner = balanced_assignment(sizes, G)
+    per_rank = [[j for j in range(n) if owner[j] == q] for q in range(G)]
+    slots = max(len(v) for v in per_rank)
+    buf = np.zeros((slots, result_bytes), np.uint8)
+    mine = per_rank[r]
+    if mine:
+        buf[:len(mine)] = np.asarray(msm_multi([jobs[j] for j in mine])).reshape(len(mine), result_bytes)
+    t = torch.from_numpy(buf).to(device)
+    out = [torch.empty_like(t) for _ in range(G)]
+    dist.all_gather(out, t)
+    res = np.zeros((n, result_bytes), np.uint8)
+    for q in range(G):
+        got = out[q].cpu().numpy()
+        for k, j in enumerate(per_rank[q]):
+            res[j] = got[k]
+    return res

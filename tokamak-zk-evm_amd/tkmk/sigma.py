@@ -14,6 +14,9 @@ from tkmk.poly import DensePolynomialExt
 
 
 class Sigma1:
+    dist = None            # torch.distributed module with an initialised process group: the commits of a round are spread over the ranks
+    comm_device = "cuda"   # where the gathered results travel ("cpu" for a gloo rehearsal)
+
     def __init__(self, xy_powers, rs_x_size, rs_y_size):
         """xy_powers[i*rs_y_size + j] = [tau_x^i tau_y^j]G as 96-byte affine records (host array or DeviceBuffer);
         rs_x_size = max(2n, 2(l_D - l)), rs_y_size = 2 s_max (iotools/mod.rs:2050-2051)"""
@@ -52,7 +55,14 @@ class Sigma1:
         prove/src/lib.rs prove0) in one pipelined tkmk_msm_multi call -> [96-byte affine, ...]"""
         jobs = [self._gather(p) for p in polys]
         live = [j for j in jobs if j is not None]
-        res = tkmk.projective_to_affine_bytes(tkmk.msm_multi(live)) if live else np.zeros(0, np.uint8)
+        if self.dist is not None and self.dist.get_world_size() > 1 and live:
+            # every rank holds the same polynomials (the rounds are replicated, Fiat-Shamir keeps them in lock step); each runs
+            # the MSMs it owns through its own pipelined multi-MSM and ONE all_gather returns all commitments (SURVEY.md §8e)
+            from tkmk import sharding
+            proj = sharding.commits_balanced(tkmk.msm_multi, self.dist, live, [j[2] for j in live], device=self.comm_device)
+            res = tkmk.projective_to_affine_bytes(np.ascontiguousarray(proj).reshape(-1))
+        else:
+            res = tkmk.projective_to_affine_bytes(tkmk.msm_multi(live)) if live else np.zeros(0, np.uint8)
         out, k = [], 0
         for j in jobs:
             if j is None:
