@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--no-bn254", action="store_true", help="skip the secondary BN254 G1 MSM measurement (BASELINE.json configs[1] as worded)")
     ap.add_argument("--no-prove", action="store_true",
                     help="skip the full-prove measurements (BASELINE.json configs[3] and the reference's production shape)")
+    ap.add_argument("--prove-dist", action="store_true",
+                    help="N > 1 only: also time the production-shape prove with each round's commitments spread over the ranks")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
@@ -112,6 +114,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    prove_dist = None
+    if dist is not None and world > 1 and args.prove_dist:      # every rank takes part: replicated rounds, commitments by owner
+        scalars.free()
+        bases.free()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import prove_bench
+        r = prove_bench.run(s_max=256, placements=166, repeat=3, dist=dist, comm_device=comm_device)
+        prove_dist = {"workload": r["workload"] + ", commitments of each round spread over %d ranks" % world, "wall_s": r["seconds"]["total"],
+                      "init_s": r["seconds"]["init"], "rounds_s": r["seconds"]["rounds"], "constraints_per_s": r["constraint_slots_per_s"],
+                      "per_round_s": {k: r["seconds"][k] for k in ("prove0", "prove1", "prove2", "prove3", "prove4")}}
+
     acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
     sections = {}
     for name in ("convert_bases", "digits", "hist", "scan", "scatter", "accumulate", "combine", "reduce_segments",
@@ -158,11 +171,13 @@ def main():
                               "peak": MAD_PEAK_PER_S,
                               "frac": n * ADDS_PER_POINT * MADS_PER_BUCKET_ADD / (kernel_ms * 1e-3) / MAD_PEAK_PER_S},
         }
+        if prove_dist is not None:
+            out["prove_dist"] = prove_dist
         if world > 1:      # the CPU baseline and the secondary figures are N = 1 material; keep the scaling runs lean
             args.no_cpu_baseline = args.no_bn254 = args.no_ntt = args.no_prove = True
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(tkmk, args.cpu_sample_logn)
-        if not args.no_bn254 or not args.no_ntt:
+        if (not args.no_bn254 or not args.no_ntt) and prove_dist is None:
             scalars.free()
             bases.free()
         if not args.no_bn254:
@@ -207,6 +222,17 @@ def _bn254_secondary(tkmk, logn):
     tkmk.synchronize()
     dt = (time.perf_counter() - t0) / steps
     tkmk.profile_enable(False)
+    prove_dist = None
+    if dist is not None and world > 1 and args.prove_dist:      # every rank takes part: replicated rounds, commitments by owner
+        scalars.free()
+        bases.free()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import prove_bench
+        r = prove_bench.run(s_max=256, placements=166, repeat=3, dist=dist, comm_device=comm_device)
+        prove_dist = {"workload": r["workload"] + ", commitments of each round spread over %d ranks" % world, "wall_s": r["seconds"]["total"],
+                      "init_s": r["seconds"]["init"], "rounds_s": r["seconds"]["rounds"], "constraints_per_s": r["constraint_slots_per_s"],
+                      "per_round_s": {k: r["seconds"][k] for k in ("prove0", "prove1", "prove2", "prove3", "prove4")}}
+
     acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
     s.free()
     b.free()

@@ -34,7 +34,10 @@ def stage_crs(tkmk, inst):
     return Sigma.gen(inst["setup_params"], tau, inst["qap"], inst["infos"], g), g
 
 
-def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, seed=0x746F6B616D616B04, profile_host=False):
+def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, seed=0x746F6B616D616B04, profile_host=False,
+        dist=None, comm_device="cuda"):
+    """dist = torch.distributed with an initialised group: every rank calls run() with the same arguments, replicates the
+    polynomial work and runs only the commitments it owns (Sigma1.dist, sharding.commits_balanced)"""
     import synth_circuit
     import tkmk
     from tkmk.prove import Prover, fr, random_mixer, run_rounds
@@ -47,6 +50,8 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
     gen_s = time.perf_counter() - t
     t = time.perf_counter()
     sigma_obj, g = stage_crs(tkmk, inst)
+    if dist is not None:
+        sigma_obj.sigma1.dist, sigma_obj.sigma1.comm_device = dist, comm_device
     sigma = sigma_obj.prover_view()
     tkmk.synchronize()
     crs_s = time.perf_counter() - t
@@ -56,6 +61,8 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
     best, runs = None, []
     for rep in range(repeat):
         tkmk.synchronize()
+        if dist is not None:
+            dist.barrier()
         t0 = time.perf_counter()
         prover, binding = Prover.init_from(inputs, inst["qap"], mixer=random_mixer(random.Random(rep)), testing_mode=check, sigma=sigma)
         tkmk.synchronize()
