@@ -90,6 +90,11 @@ int tkmk_is_hip_build(void);
 /* host-only: Keccak-256 (original 0x01 padding), the hash of the Fiat-Shamir transcript — replaces the tiny_keccak calls of
  * RollingKeccakTranscript::update / get_challenge_raw (prove/src/lib.rs:3247-3394); no device is touched */
 tkmk_error tkmk_keccak256(const uint8_t *data, size_t len, uint8_t out[32]);
+/* host-only: offsets and lengths of the 3 * n_constraints linear combinations of an iden3 .r1cs constraints section (the walk of
+ * R1csBinary::scan_constraints, libs/src/iotools/mod.rs:613-650); *consumed = bytes walked (compare with section_bytes for
+ * trailing bytes); INVALID_ARGUMENT if the section ends inside the walk */
+tkmk_error tkmk_r1cs_index(const uint8_t *section, size_t section_bytes, uint32_t n_constraints, uint32_t field_size,
+                           uint64_t *starts, uint32_t *counts, size_t *consumed);
 
 /* ---------------------------------------------------------------------------------------------
  * MSM — replaces icicle_core::msm::msm<G1> (extern "C" bls12_381_msm in ICICLE v3) as called at

@@ -37,6 +37,36 @@ void keccak_f1600(uint64_t a[25]) {   // lane (x, y) at a[x + 5 y]
 
 }  // namespace
 
+// Index of the constraints section of an iden3 .r1cs file (packages/backend/libs/src/iotools/mod.rs:613-650 walks the same
+// layout): 3 linear combinations per constraint, each a u32 count followed by count x (u32 wire, field_size-byte coefficient).
+// starts[3 r + m] = byte offset (from `section`) of the first record of matrix m in constraint r, counts[3 r + m] = its length.
+// TKMK_SUCCESS when all 3 * n_constraints combinations lie inside the section (*consumed = bytes walked: the caller compares it
+// with section_bytes to detect trailing bytes); TKMK_ERR_INVALID_ARGUMENT when the section ends inside the walk.
+TK_API tkmk_error tkmk_r1cs_index(const uint8_t *section, size_t section_bytes, uint32_t n_constraints, uint32_t field_size,
+                                  uint64_t *starts, uint32_t *counts, size_t *consumed) {
+    if (!section || !starts || !counts) return TKMK_ERR_INVALID_POINTER;
+    size_t off = 0;
+    const size_t rec = 4 + (size_t)field_size;
+    for (uint64_t k = 0; k < (uint64_t)n_constraints * 3; k++) {
+        if (off + 4 > section_bytes) {
+            if (consumed) *consumed = off;
+            return TKMK_ERR_INVALID_ARGUMENT;
+        }
+        uint32_t cnt;
+        std::memcpy(&cnt, section + off, 4);
+        off += 4;
+        starts[k] = off;
+        counts[k] = cnt;
+        if ((size_t)cnt > (section_bytes - off) / rec) {
+            if (consumed) *consumed = off;
+            return TKMK_ERR_INVALID_ARGUMENT;
+        }
+        off += (size_t)cnt * rec;
+    }
+    if (consumed) *consumed = off;
+    return TKMK_SUCCESS;
+}
+
 TK_API tkmk_error tkmk_keccak256(const uint8_t *data, size_t len, uint8_t out[32]) {
     if ((!data && len) || !out) return TKMK_ERR_INVALID_ARGUMENT;
     const size_t rate = 136;

@@ -26,6 +26,7 @@ SECTION_COUNT = 9
 G1_BYTES, G2_BYTES = 96, 192
 G1_SINGLES = ("G", "x", "y", "delta", "eta", "lagrange_KL")
 G2_POINTS = ("H", "alpha", "alpha2", "alpha3", "alpha4", "gamma", "delta", "eta", "x", "y")
+SMALL_TABLES = ("delta_inv_alphak_xh_tx", "delta_inv_alpha4_xj_tx", "delta_inv_alphak_yi_ty")
 SECTION_NAMES = ("g1", "xy_powers", "gamma_inv_o_inst", "eta_inv_li_o_inter_alpha4_kj", "delta_inv_li_o_prv",
                  "delta_inv_alphak_xh_tx", "delta_inv_alpha4_xj_tx", "delta_inv_alphak_yi_ty", "g2")
 
@@ -100,5 +101,6 @@ def load_sigma1(sections, setup_params):
     n, s_max = setup_params["n"], setup_params["s_max"]
     up = lambda name: tkmk.DeviceBuffer.from_host(np.ascontiguousarray(sections[name]))   # noqa: E731
     sigma1 = Sigma1(up("xy_powers"), max(2 * n, 2 * m_i), 2 * s_max)
-    tables = {name: up(name) for name in SECTION_NAMES[2:8] if sections[name].size}
+    # the three 2..12-point tables are only ever read on the host (O_prv's blinding terms, prove/src/lib.rs:1146-1160)
+    tables = {name: (np.array(sections[name]) if name in SMALL_TABLES else up(name)) for name in SECTION_NAMES[2:8] if sections[name].size}
     return sigma1, tables

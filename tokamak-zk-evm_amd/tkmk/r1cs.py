@@ -122,24 +122,23 @@ class R1csBinary:
         fs = self.field_size
         if fs != 32:
             return self._csr_slow()
-        # pass 1 (sequential by format): the count word of every linear combination -> its start offset and length
-        starts = [[] for _ in range(3)]
-        counts = [[] for _ in range(3)]
-        unpack = struct.unpack_from
-        n = len(data)
-        for _ in range(self.n_constraints):
-            for m in range(3):
-                if off + 4 > n:
-                    raise R1csError("unexpected end of R1CS file")
-                cnt = unpack("<I", data, off)[0]
-                off += 4
-                starts[m].append(off)
-                counts[m].append(cnt)
-                off += cnt * 36
-                if off > n:
-                    raise R1csError("unexpected end of R1CS file")
-        if off != end:
-            raise R1csError("R1CS constraints section has %d trailing bytes" % max(0, end - off))
+        # pass 1 (sequential by format): the count word of every linear combination -> its start offset and length, by the
+        # library's host-only walker (a Python loop over 3 * n_constraints count words costs 3 ms per production subcircuit)
+        nlc = 3 * self.n_constraints
+        st = np.zeros(nlc, np.uint64)
+        ct = np.zeros(nlc, np.uint32)
+        used = ctypes.c_size_t(0)
+        section = (np.frombuffer(data, np.uint8, self.constraints_size, self.constraints_offset) if self.constraints_size
+                   else np.zeros(1, np.uint8))
+        rc = tkmk.lib().tkmk_r1cs_index(tkmk._p(section), ctypes.c_size_t(self.constraints_size), ctypes.c_uint32(self.n_constraints),
+                                        ctypes.c_uint32(fs), tkmk._p(st.view(np.uint8)), tkmk._p(ct.view(np.uint8)), ctypes.byref(used))
+        if rc != 0:
+            raise R1csError("unexpected end of R1CS file")
+        if used.value != self.constraints_size:
+            raise R1csError("R1CS constraints section has %d trailing bytes" % max(0, self.constraints_size - used.value))
+        st = st.astype(np.int64) + self.constraints_offset
+        starts = [st[m::3] for m in range(3)]
+        counts = [ct[m::3] for m in range(3)]
         # pass 2: all (wire, coefficient) records of one matrix in a single gather
         raw = np.frombuffer(data, np.uint8)
         out = []

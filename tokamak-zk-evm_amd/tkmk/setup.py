@@ -163,8 +163,8 @@ class Sigma:
         small = {"delta_inv_alphak_xh_tx": [di * pow(a, k, R) * pow(x, h, R) * t_n % R for k in (1, 2, 3) for h in range(3)],
                  "delta_inv_alpha4_xj_tx": [di * a4 * pow(x, j, R) * t_mi % R for j in range(2)],
                  "delta_inv_alphak_yi_ty": [di * pow(a, k, R) * pow(y, i, R) * t_s % R for k in (1, 2, 3, 4) for i in range(3)]}
-        for name, sc in small.items():
-            tables[name] = pts(tkmk.DeviceBuffer.from_host(_frs(sc)), len(sc))
+        for name, sc in small.items():                   # read on the host only (crsmod.SMALL_TABLES)
+            tables[name] = pts(tkmk.DeviceBuffer.from_host(_frs(sc)), len(sc)).to_host()
         single_scalars = [1, x, y, tau["delta"], tau["eta"], l_vec[s_max - 1] * k_vec[m_i - 1] % R]
         sing = pts(tkmk.DeviceBuffer.from_host(_frs(single_scalars)), 6).to_host().reshape(6, 96)
         singles = {name: sing[i].copy() for i, name in enumerate(crsmod.G1_SINGLES)}
@@ -178,7 +178,7 @@ class Sigma:
         """TKCRS001 bytes (tkmk/crs.py); the G2 section is zero (see the module docstring)"""
         sections = {"g1": np.concatenate([self.singles[k] for k in crsmod.G1_SINGLES]), "xy_powers": self.sigma1.xy_powers.to_host(),
                     "g2": np.zeros(len(crsmod.G2_POINTS) * crsmod.G2_BYTES, np.uint8)}
-        sections.update({k: v.to_host() for k, v in self.tables.items()})
+        sections.update({k: (v.to_host() if isinstance(v, tkmk.DeviceBuffer) else np.asarray(v, np.uint8)) for k, v in self.tables.items()})
         return crsmod.build_payload(sections)
 
     def write(self, out_dir):
