@@ -10,7 +10,6 @@
 #include <cstdlib>
 #include <fstream>
 #include <string>
-#include <thread>
 
 #include "tkmk_json.hpp"
 #include "tkmk_prover.hpp"
@@ -136,8 +135,11 @@ int main(int argc, char **argv) {
         double t_start = Prover::now();
         int ndev = 0;
         if (tkmk_device_count(&ndev) != TKMK_SUCCESS || ndev < 1) throw Error("no HIP device: the MI355X backend has no CPU fallback");
-        std::string crs_path = crs_dir + "/combined_sigma.tkcrs";
-        if (!std::ifstream(crs_path)) throw Error("No reference string is found. Run the Setup first (expected " + crs_path + ").");
+        check(tkmk_set_device(0), "set_device");   // check_device(): device id 0 (libs/src/utils/mod.rs:88-110)
+        void *warm = nullptr;                        // first allocation: the HIP runtime and the code objects come up here
+        check(tkmk_malloc(&warm, 256), "malloc");
+        check(tkmk_free(warm), "free");
+        double t_dev = Prover::now();
         printf("Prover initialization...\n");
         ProverInputs in;
         in.qap_path = lib_dir;
@@ -145,29 +147,6 @@ int main(int argc, char **argv) {
         in.sp = SetupParams{jp.at("l").as_size(),   jp.at("l_user_out").as_size(), jp.at("l_user").as_size(), jp.at("l_free").as_size(),
                             jp.at("l_D").as_size(), jp.at("m_D").as_size(),        jp.at("n").as_size(),      jp.at("s_D").as_size(),
                             jp.at("s_max").as_size()};
-        // device start-up (HIP runtime, code objects) and the CRS upload do not depend on the synthesizer documents: they run on a
-        // second thread while this one parses the JSON inputs
-        std::unique_ptr<ProverSigma> sigma_ptr;
-        std::exception_ptr crs_error;
-        double t_dev = 0, t_crs = 0;
-        std::thread crs_thread([&] {
-            try {
-                check(tkmk_set_device(0), "set_device");   // check_device(): device id 0 (libs/src/utils/mod.rs:88-110)
-                void *warm = nullptr;
-                check(tkmk_malloc(&warm, 256), "malloc");
-                check(tkmk_free(warm), "free");
-                t_dev = Prover::now();
-                CrsPayload crs = CrsPayload::read(crs_path);
-                sigma_ptr.reset(new ProverSigma(ProverSigma::from_payload(crs, in.sp)));
-                t_crs = Prover::now();
-            } catch (...) {
-                crs_error = std::current_exception();
-            }
-        });
-        struct Joiner {
-            std::thread &t;
-            ~Joiner() { if (t.joinable()) t.join(); }
-        } joiner{crs_thread};
         {
             const json::Value jinfo = json::read_file(lib_dir + "/subcircuitInfo.json");
             for (const json::Value &e : jinfo.items()) {
@@ -193,12 +172,12 @@ int main(int argc, char **argv) {
             in.a_pub_user = hex_list(jinst.at("a_pub_user"));
             in.a_pub_block = hex_list(jinst.at("a_pub_block"));
         }
+        std::string crs_path = crs_dir + "/combined_sigma.tkcrs";
+        if (!std::ifstream(crs_path)) throw Error("No reference string is found. Run the Setup first (expected " + crs_path + ").");
         double t_load = Prover::now();
-        crs_thread.join();
-        if (crs_error) std::rethrow_exception(crs_error);
-        check(tkmk_set_device(0), "set_device");
-        ProverSigma &sigma = *sigma_ptr;
-        double t_ready = Prover::now();
+        CrsPayload crs = CrsPayload::read(crs_path);
+        ProverSigma sigma = ProverSigma::from_payload(crs, in.sp);
+        double t_crs = Prover::now();
         const char *mixer_file = std::getenv("TKMK_PROVE_MIXER");
         Mixer mixer = mixer_file ? mixer_from_json(json::read_file(mixer_file)) : Mixer::random();
 
@@ -213,8 +192,7 @@ int main(int argc, char **argv) {
         if (!f) throw Error("cannot write " + path);
         f << proof.to_json();
         f.close();
-        printf("device.init %.3f s\nload.crs    %.3f s\nload.inputs %.3f s\nload.total  %.3f s\n", t_dev - t_start, t_crs - t_dev, t_load - t_start,
-               t_ready - t_start);   // device.init + load.crs overlap load.inputs
+        printf("device.init %.3f s\nload.inputs %.3f s\nload.crs    %.3f s\n", t_dev - t_start, t_load - t_dev, t_crs - t_load);
         for (auto &kv : pb.first->timing) printf("%-11s %.3f s\n", kv.first.c_str(), kv.second);
         for (const char *k : {"prove0", "prove1", "prove2", "prove3", "prove4"}) printf("%-11s %.3f s\n", k, times[k]);
         double total = Prover::now() - t_start;
