@@ -222,17 +222,6 @@ def _bn254_secondary(tkmk, logn):
     tkmk.synchronize()
     dt = (time.perf_counter() - t0) / steps
     tkmk.profile_enable(False)
-    prove_dist = None
-    if dist is not None and world > 1 and args.prove_dist:      # every rank takes part: replicated rounds, commitments by owner
-        scalars.free()
-        bases.free()
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import prove_bench
-        r = prove_bench.run(s_max=256, placements=166, repeat=3, dist=dist, comm_device=comm_device)
-        prove_dist = {"workload": r["workload"] + ", commitments of each round spread over %d ranks" % world, "wall_s": r["seconds"]["total"],
-                      "init_s": r["seconds"]["init"], "rounds_s": r["seconds"]["rounds"], "constraints_per_s": r["constraint_slots_per_s"],
-                      "per_round_s": {k: r["seconds"][k] for k in ("prove0", "prove1", "prove2", "prove3", "prove4")}}
-
     acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
     s.free()
     b.free()

@@ -6,7 +6,6 @@ parsing as in libs/src/iotools/mod.rs:126-146) and the bases are gathered on the
 import numpy as np
 
 import tkmk
-from tkmk.r1cs import hex_to_fr
 
 _PUB_RANGES = {"bufferPubOut": "Out_idx", "bufferPubIn": "In_idx", "bufferBlockIn": "In_idx"}
 

@@ -7,7 +7,6 @@ placements on the host in the reference — runs as one kernel launch per (used 
 tkmk_r1cs_eval_rows; the transposes and the three inverse bivariate NTTs follow on the device.
 """
 import ctypes
-import json
 import os
 import struct
 from itertools import repeat as _repeat
@@ -117,8 +116,7 @@ class R1csBinary:
     def csr(self):
         """A, B, C as CSR triples (row_ptr u32, wire u32, coeff bytes), coefficients reduced mod r: the same walk and the same
         errors as scan_constraints, with each linear combination read as one numpy record array"""
-        data, off = self.data, self.constraints_offset
-        end = self.constraints_offset + self.constraints_size
+        data = self.data
         fs = self.field_size
         if fs != 32:
             return self._csr_slow()

@@ -112,7 +112,6 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
     import subprocess
     import synth_circuit
     import tkmk
-    from tkmk import crs as crsmod
     inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=13, n_out=80, n_in=170, n_prv=n_prv, k_out=65, k_pub=20,
                                   l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements)
     tmp = tempfile.mkdtemp(prefix="tkmk_prove_native_")
