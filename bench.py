@@ -298,7 +298,8 @@ def _prove_secondary(tkmk):
         out[key] = {"workload": r["workload"], "constraints_per_s": r["constraint_slots_per_s"], "r1cs_rows_per_s": r["r1cs_rows_per_s"],
                     "wall_s": r["seconds"]["total"], "init_s": r["seconds"]["init"], "rounds_s": r["seconds"]["rounds"],
                     "per_round_s": {k: r["seconds"][k] for k in ("prove0", "prove1", "prove2", "prove3", "prove4")},
-                    "constraint_slots": r["constraint_slots"], "r1cs_rows": r["r1cs_rows"]}
+                    "constraint_slots": r["constraint_slots"], "r1cs_rows": r["r1cs_rows"],
+                    "msm_points": r["seconds"]["msm_points"], "ntt_elements": r["seconds"]["ntt_elements"], "hbm_roofline": r["hbm_roofline"]}
         tkmk.release_scratch()
     # the same production-shape proof through the native binary (C++ host side): files in the reference's formats in, proof.json
     # out, a fresh process per run, CRS payload and JSON inputs loaded inside the timed total

@@ -234,7 +234,17 @@ def release_ntt_domain(curve="bls12_381"):
     _domain_size.pop(curve, None)
 
 
+# algorithmic work issued through this binding since the last reset: points committed by MSM calls and elements transformed by
+# (bi)NTT calls (tools/prove_bench.py turns them into SURVEY.md §8d's algorithmic bytes: 128 B per point, 64 B per element)
+STATS = {"msm_points": 0, "ntt_elements": 0}
+
+
+def stats_reset():
+    STATS["msm_points"] = STATS["ntt_elements"] = 0
+
+
 def ntt(a, n, batch=1, columns_batch=False, inverse=False, coset_gen=None, out=None, stream=None, curve="bls12_381"):
+    STATS["ntt_elements"] += int(n) * int(batch)
     cfg = lib().tkmk_ntt_default_config()
     cfg.batch_size = batch
     cfg.columns_batch = columns_batch
@@ -250,6 +260,7 @@ def ntt(a, n, batch=1, columns_batch=False, inverse=False, coset_gen=None, out=N
 
 
 def bintt(a, x_size, y_size, inverse=False, coset_x=None, coset_y=None, out=None, stream=None, curve="bls12_381"):
+    STATS["ntt_elements"] += int(x_size) * int(y_size)
     out = _out_like(a, 32 * x_size * y_size, out)
     if _on_dev(a) != _on_dev(out):
         raise ValueError("tkmk_bintt takes both buffers on the same side")
@@ -382,6 +393,7 @@ def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize
     sym, aff = _CURVES[curve][0], _CURVES[curve][4]
     cfg = lib().tkmk_msm_default_config()
     n = _len(scalars) // batch if msm_size is None else msm_size
+    STATS["msm_points"] += int(n) * int(batch)
     cfg.batch_size = batch
     cfg.are_points_shared_in_batch = shared_points
     cfg.are_scalars_on_device = _on_dev(scalars)
@@ -421,6 +433,7 @@ def msm_multi(jobs, c=0, bitsize=0, stream=None, curve="bls12_381", precompute_f
     arr = (MsmJob * len(jobs))()
     for k, j in enumerate(jobs):
         n = j[2] if len(j) > 2 else _len(j[0])
+        STATS["msm_points"] += int(n)
         arr[k] = MsmJob(_p(j[0]).value, _p(j[1]).value, int(n))
     out = np.empty(aff // 2 * 3 * len(jobs), np.uint8)
     _check(getattr(lib(), sym)(arr, len(jobs), ctypes.byref(cfg), _p(out)), sym)

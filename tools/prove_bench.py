@@ -63,6 +63,7 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
         tkmk.synchronize()
         if dist is not None:
             dist.barrier()
+        tkmk.stats_reset()
         t0 = time.perf_counter()
         prover, binding = Prover.init_from(inputs, inst["qap"], mixer=random_mixer(random.Random(rep)), testing_mode=check, sigma=sigma)
         tkmk.synchronize()
@@ -70,6 +71,7 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
         points, scalars, challenges, _, times = run_rounds(prover, binding)
         total = time.perf_counter() - t0
         rec = dict({k: round(v, 4) for k, v in prover.timing.items()}, **{k: round(v, 4) for k, v in times.items()})
+        rec["msm_points"], rec["ntt_elements"] = tkmk.STATS["msm_points"], tkmk.STATS["ntt_elements"]
         rec["init"] = round(init_s, 4)
         rec["rounds"] = round(sum(times.values()), 4)
         rec["total"] = round(total, 4)
@@ -101,6 +103,13 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
         "setup_params": sp, "constraint_slots": slots, "r1cs_rows": inst["r1cs_rows"], "seconds": best, "runs": runs,
         "constraint_slots_per_s": round(slots / best["total"]), "r1cs_rows_per_s": round(inst["r1cs_rows"] / best["total"]),
         "constraint_slots_per_s_rounds_only": round(slots / best["rounds"]),
+        # SURVEY.md §8d algorithmic bytes of the proof's MSMs (128 B per point: scalar + base read once) and (bi)NTTs (64 B per
+        # element: read once, written once) over the wall time, against 8 TB/s — both kernels are integer-VALU bound, so this is small
+        "algorithmic_bytes": 128 * best["msm_points"] + 64 * best["ntt_elements"],
+        "hbm_roofline": {"achieved_GBps": round((128 * best["msm_points"] + 64 * best["ntt_elements"]) / best["total"] / 1e9, 1),
+                         "achieved_GBps_rounds_only": round((128 * best["msm_points"] + 64 * best["ntt_elements"]) / best["rounds"] / 1e9, 1),
+                         "peak_GBps": 8000.0,
+                         "frac": round((128 * best["msm_points"] + 64 * best["ntt_elements"]) / best["total"] / 1e9 / 8000.0, 5)},
         "generate_s": round(gen_s, 2), "stage_crs_s": round(crs_s, 2), "checked": bool(check)}
 
 
