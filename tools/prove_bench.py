@@ -113,7 +113,7 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
         "generate_s": round(gen_s, 2), "stage_crs_s": round(crs_s, 2), "checked": bool(check)}
 
 
-def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0x746F6B616D616B04):
+def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0x746F6B616D616B04, compare=False):
     """the same workload through tokamak-zk-evm_amd/bin/prove (C++ host side): every input as a file in the reference's formats,
     the CRS as the TKCRS001 payload; times are the binary's own printout (inputs + CRS loading included in its total)"""
     import re
@@ -134,12 +134,30 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
         sigma_obj.write(os.path.join(tmp, "crs"))
         crs_bytes = os.path.getsize(os.path.join(tmp, "crs", "combined_sigma.tkcrs"))
         pv_bytes = os.path.getsize(os.path.join(inst["synth"], "placementVariables.json"))
+        same = None
+        if compare:      # the Python prover and the binary on the same inputs with the same blinding scalars: identical proof.json content
+            from tkmk import proofio
+            from tkmk.prove import Prover, random_mixer, run_rounds
+            mixer = random_mixer(random.Random(7))
+            hx = lambda v: [hx(e) for e in v] if isinstance(v, list) else "0x%x" % v      # noqa: E731
+            json.dump({k: hx(v) for k, v in mixer.items()}, open(os.path.join(tmp, "mixer.json"), "w"))
+            prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, sigma=sigma_obj.prover_view())
+            points, scalars, _, _, _ = run_rounds(prover, binding)
+            want = proofio.format_proof(points, scalars)
+            del prover
         del sigma_obj
         tkmk.release_scratch()
         binary = os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "prove")
         cmd = [binary, "--crs", os.path.join(tmp, "crs"), "--synthesizer-stat", inst["synth"], "--output", os.path.join(tmp, "out"),
                "--subcircuit-library", inst["qap"]]
         os.makedirs(os.path.join(tmp, "out"))
+        if compare:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, TKMK_PROVE_MIXER=os.path.join(tmp, "mixer.json")))
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr)
+            same = json.load(open(os.path.join(tmp, "out", "proof.json"))) == want
+            if not same:
+                raise RuntimeError("native proof.json differs from the Python prover's for the same blinding scalars")
         runs = []
         for _ in range(repeat):
             t0 = time.perf_counter()
@@ -161,12 +179,14 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
         sp["n"], sp["l_D"] - sp["l"], sp["s_max"], len(inst["placement_variables"]), inst["r1cs_rows"]),
         "constraint_slots": slots, "r1cs_rows": inst["r1cs_rows"], "seconds": best, "runs": runs,
         "constraint_slots_per_s": round(slots / best["total"]), "constraint_slots_per_s_init_plus_rounds": round(slots / compute),
-        "crs_payload_bytes": crs_bytes, "placement_variables_json_bytes": pv_bytes, "sigma_gen_s": round(setup_s, 3)}
+        "crs_payload_bytes": crs_bytes, "placement_variables_json_bytes": pv_bytes, "sigma_gen_s": round(setup_s, 3),
+        "equals_python_prover": same}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--native", action="store_true", help="time tokamak-zk-evm_amd/bin/prove on files instead of the Python prover")
+    ap.add_argument("--compare", action="store_true", help="with --native: also check the binary's proof.json against the Python prover's")
     ap.add_argument("--s-max", type=int, default=256)
     ap.add_argument("--placements", type=int, default=None, help="used placements (default: all s_max; the reference's run has 166)")
     ap.add_argument("--pool", type=int, default=24, help="distinct gate witnesses")
@@ -179,7 +199,7 @@ def main():
     import tkmk
     tkmk.set_device(0)
     if args.native:
-        out = run_native(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.seed)
+        out = run_native(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.seed, args.compare)
     else:
         out = run(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.check, args.seed, args.profile_host)
     out["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md)"}
