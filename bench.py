@@ -186,6 +186,8 @@ def main():
             out["ntt"] = _ntt_secondary(tkmk)
         if not args.no_prove:
             out["prove"] = _prove_secondary(tkmk)
+            if "cpu_baseline" in out:
+                out["prove"]["cpu_estimate"] = _prove_cpu_estimate(tkmk, out["prove"]["production_2p20"], out["cpu_baseline"])
         out["result_x_lo"] = int.from_bytes(bytes(result[:8]), "little")
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -311,6 +313,31 @@ def _prove_secondary(tkmk):
     tkmk.release_scratch()
     out["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md §1)"}
     return out
+
+
+def _prove_cpu_estimate(tkmk, prod, msm_baseline):
+    """What the MSM + NTT share of the production-shape proof costs on this box's host cores with the oracle's C port (the reference's
+    Rust + ICICLE CPU prover cannot be built offline; its own published run is 45.7 s on ~8 threads of other hardware).  Not a
+    measured proof: the proof's counted work (points committed, NTT elements) times the oracle's measured rates — the MSM rate
+    from cpu_baseline's sample, the NTT rate from one 1024 x 1024 bivariate transform timed here and checked against the GPU.
+    A lower bound for a CPU prover (polynomial bookkeeping, divisions and host glue come on top)."""
+    import oracle
+    threads = msm_baseline["cores"]
+    xs = ys = 1024
+    a = tkmk.fr_random_device(SEED + 9, xs * ys)
+    ah = a.to_host()
+    oracle.bintt(ah[:32 * 64 * 64], 64, 64)
+    t0 = time.perf_counter()
+    want = oracle.bintt(ah, xs, ys)
+    dt = time.perf_counter() - t0
+    ok = bool((np.asarray(tkmk.bintt(a, xs, ys).to_host()) == np.asarray(want)).all())
+    ntt_rate = xs * ys / dt
+    msm_s = prod["msm_points"] / msm_baseline["points_per_s"]
+    ntt_s = prod["ntt_elements"] / ntt_rate
+    return {"kind": "port, extrapolated from bounded samples (MSM + NTT share only)", "cores": threads, "msm_points_per_s": msm_baseline["points_per_s"],
+            "ntt_elements_per_s": ntt_rate, "ntt_sample": "one 1024 x 1024 bivariate NTT, %.3f s, matches the GPU: %s" % (dt, ok),
+            "msm_s": msm_s, "ntt_s": ntt_s, "seconds": msm_s + ntt_s, "gpu_wall_s": prod["wall_s"],
+            "constraints_per_s": prod["constraint_slots"] / (msm_s + ntt_s)}
 
 
 def _usable_cpus(omp_threads):
