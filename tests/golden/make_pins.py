@@ -44,6 +44,9 @@ out["g1_generator_y_limbs"] = [int(t, 0) for t in re.findall(r"0x[0-9a-fA-F]+|\d
 src = open(REF + "/backend/setup/trusted-setup/src/main.rs").read()
 m = re.search(r"G1Affine::from_limbs\(\s*BaseField::from_hex\(\"(0x[0-9a-f]+)\"\).*?BaseField::from_hex\(\"(0x[0-9a-f]+)\"\)", src, re.S)
 out["fixed_tau_g1_x"], out["fixed_tau_g1_y"] = m.group(1), m.group(2)
+# the fixed G2 generator of the same recipe (main.rs:75-78): G2BaseField::from_hex over the whole 96-byte limb array
+m = re.search(r"G2Affine::from_limbs\(\s*G2BaseField::from_hex\(\"(0x[0-9a-f]+)\"\).*?G2BaseField::from_hex\(\"(0x[0-9a-f]+)\"\)", src, re.S)
+out["fixed_tau_g2_x"], out["fixed_tau_g2_y"] = m.group(1), m.group(2)
 
 src = open(REF + "/backend/libs/src/field_structures/mod.rs").read()
 body = src[src.index("pub fn gen_fixed"):]

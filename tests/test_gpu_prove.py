@@ -42,7 +42,9 @@ def stage_crs(gpu, oracle, inst):
     from tkmk.setup import Sigma
     pins = _pins()
     g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
-    sigma = Sigma.gen(inst["setup_params"], _tau(), inst["qap"], inst["infos"], np.frombuffer(bytes(g), np.uint8))
+    from tkmk import g2
+    sigma = Sigma.gen(inst["setup_params"], _tau(), inst["qap"], inst["infos"], np.frombuffer(bytes(g), np.uint8),
+                      g2.from_hex_pair(pins["fixed_tau_g2_x"], pins["fixed_tau_g2_y"]))
     return sigma, prove_ref.sigma_gen(inst, _tau()), g
 
 
@@ -77,6 +79,11 @@ def test_sigma_gen_equals_restated_setup(gpu, oracle, tmp_path):
     crsmod.check_shapes(sections, sp)
     assert (np.asarray(sections["eta_inv_li_o_inter_alpha4_kj"]) == sigma.tables["eta_inv_li_o_inter_alpha4_kj"].to_host()).all()
     assert (np.asarray(crsmod.single_g1(sections, "delta")) == sigma.singles["delta"]).all()
+    # Sigma2 in the payload: ten 192-byte records, H first, [alpha]H second (tkmk/g2.py; relations in tests/test_g2.py)
+    from tkmk import g2
+    recs = np.asarray(sections["g2"]).reshape(10, 192)
+    h = g2.from_hex_pair(_pins()["fixed_tau_g2_x"], _pins()["fixed_tau_g2_y"])
+    assert g2.decode(recs[0]) == h and g2.decode(recs[1]) == g2.scalar_mul(crs["alpha"], h) and g2.decode(recs[9]) == g2.scalar_mul(crs["tau_y"], h)
 
 
 def seeded_mixer(seed):

@@ -68,31 +68,34 @@ FIXED_TAU = {   # Tau::gen_fixed (packages/backend/libs/src/field_structures/mod
 }
 FIXED_G1 = (0x0b001b4cc05fa01578be7d4e821d6ff58f2a05c584fba3cb31a37942dece65eadec9a878add2282f7c2513abb8d4ab05,   # setup/trusted-setup/src/main.rs:71-74
             0x15e237775397ed22eef43dd36cdca277c9cf6fa7e4ffff0a5bb4b20a82392caacf0f63fb6cdb02bccf2f5af14970d6b9)
+FIXED_G2 = ("0x1116094a7c01d4fd8abcfea69c658c92c037765bee00556b8d4063c33540b316ac68a2d913d3adc3b43c7d7cc7505cfc17206c8ae661f247979b3f1daa7fb6d5f7ce9c17b5ed1d7e8b421a2508b3f09a603e6a5fab3fcde7364fd178d656ac36",   # main.rs:75-78
+            "0x15bf297a4b9842fb1a3a6f2dbf6b94de06997b11b2f72436c22efbb48d2f74b0de7239ea182a2ee50c23ae3d0be6fdee09459611409874fe4b04b1a7e42cb84eb4ae01728dc55dbd1343fda8d0fe94a299fc757acc1d2602a49a005b4ff90190")
 STD_G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,     # the standard generator
           0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
 
 
 def _setup(args):
     """trusted-setup's argument surface (setup/trusted-setup/src/main.rs:27-46): --subcircuit-library DIR --output DIR [--fixed-tau].
-    Writes <out>/combined_sigma.tkcrs (G1 side; tkmk/setup.py)"""
+    Writes <out>/combined_sigma.tkcrs (tkmk/setup.py: G1 side on the device, the ten G2 points on the host)"""
     import secrets
     import time
     import numpy as np
     import tkmk
-    from tkmk import setup
+    from tkmk import g2, setup
     if tkmk.device_count() < 1:
         raise SystemExit("no HIP device: the MI355X backend has no CPU fallback")
     tkmk.set_device(0)
     aff = lambda xy: np.frombuffer(xy[0].to_bytes(48, "little") + xy[1].to_bytes(48, "little"), np.uint8).copy()   # noqa: E731
     if args.fixed_tau:
-        print("Using hardcoded G1 generator and tau")
-        tau, g1 = FIXED_TAU, aff(FIXED_G1)
+        print("Using hardcoded G1, G2 generators and tau")
+        tau, g1, h2 = FIXED_TAU, aff(FIXED_G1), g2.from_hex_pair(*FIXED_G2)
     else:                                               # Tau::gen + a random G1 point = [h]G for a random h
         tau = {k: 1 + secrets.randbelow(setup.R - 1) for k in setup.TAU_FIELDS}
         h = tkmk.DeviceBuffer.from_host(setup._fr(1 + secrets.randbelow(setup.R - 1)))
         g1 = tkmk.g1_batch_scalar_mul_device(h, aff(STD_G1), 1).to_host()
+        h2 = g2.scalar_mul(1 + secrets.randbelow(setup.R - 1), g2.STD_G2)
     t0 = time.perf_counter()
-    _, path = setup.trusted_setup(args.subcircuit_library, args.output, tau, g1)
+    _, path = setup.trusted_setup(args.subcircuit_library, args.output, tau, g1, h2)
     print("combined_sigma.tkcrs written to %s (%.3f s)" % (path, time.perf_counter() - t0))
 
 

@@ -12,8 +12,8 @@ Where the work runs:
   * the table scalars (outer products with L_i(tau_y), scalings by gamma^-1 / eta^-1 / delta^-1) with the Fr vector ops;
   * every point as one fixed-base batched scalar multiplication (tkmk_g1_batch_scalar_mul_device): 2^22 .. 2^24 of them
     for xy_powers, (m_D - l_D) * s_max for delta_inv_li_o_prv.
-G2 (Sigma2: nine scalar multiplications of the G2 generator, consumed only by the pairing verifier) is not built: there is
-no G2 arithmetic in this backend; the payload's G2 section is left zero.
+Sigma2 (H and its nine multiples by the trapdoor scalars, consumed only by the pairing verifiers) is ten single-point operations;
+they run on the host (tkmk/g2.py), as in the reference; without a G2 generator the payload's G2 section is left zero.
 """
 import json
 import os
@@ -115,11 +115,12 @@ class Sigma:
     """the G1 side of the reference string, resident in HBM: `sigma1` (Sigma1 with xy_powers), `tables` (the six G1 tables of
     tkmk/crs.py), `singles` (G, x, y, delta, eta, lagrange_KL as 96-byte records)"""
 
-    def __init__(self, sigma1, tables, singles, setup_params):
+    def __init__(self, sigma1, tables, singles, setup_params, g2_points=None):
         self.sigma1, self.tables, self.singles, self.setup_params = sigma1, tables, singles, setup_params
+        self.g2_points = g2_points          # [H, alpha, alpha2, alpha3, alpha4, gamma, delta, eta, x, y] as tkmk.g2 points, or None
 
     @classmethod
-    def gen(cls, setup_params, tau, qap_path, subcircuit_infos, g1_gen):
+    def gen(cls, setup_params, tau, qap_path, subcircuit_infos, g1_gen, g2_gen=None):
         sp = setup_params
         n, s_max, l, l_free, l_user, l_user_out, l_d, m_d = (sp[k] for k in ("n", "s_max", "l", "l_free", "l_user", "l_user_out", "l_D", "m_D"))
         m_i = l_d - l
@@ -168,7 +169,11 @@ class Sigma:
         single_scalars = [1, x, y, tau["delta"], tau["eta"], l_vec[s_max - 1] * k_vec[m_i - 1] % R]
         sing = pts(tkmk.DeviceBuffer.from_host(_frs(single_scalars)), 6).to_host().reshape(6, 96)
         singles = {name: sing[i].copy() for i, name in enumerate(crsmod.G1_SINGLES)}
-        return cls(sigma1, tables, singles, sp)
+        g2_points = None
+        if g2_gen is not None:               # Sigma2::gen (:752-777) and H
+            from tkmk import g2
+            g2_points = g2.sigma2_gen(tau, g2_gen)
+        return cls(sigma1, tables, singles, sp, g2_points)
 
     def prover_view(self):
         """the (sigma1, tables, singles) triple Prover.init(sigma=...) takes"""
@@ -176,8 +181,13 @@ class Sigma:
 
     def payload(self):
         """TKCRS001 bytes (tkmk/crs.py); the G2 section is zero (see the module docstring)"""
+        if self.g2_points is None:
+            g2_section = np.zeros(len(crsmod.G2_POINTS) * crsmod.G2_BYTES, np.uint8)
+        else:
+            from tkmk import g2
+            g2_section = np.concatenate([g2.encode(p) for p in self.g2_points])
         sections = {"g1": np.concatenate([self.singles[k] for k in crsmod.G1_SINGLES]), "xy_powers": self.sigma1.xy_powers.to_host(),
-                    "g2": np.zeros(len(crsmod.G2_POINTS) * crsmod.G2_BYTES, np.uint8)}
+                    "g2": g2_section}
         sections.update({k: (v.to_host() if isinstance(v, tkmk.DeviceBuffer) else np.asarray(v, np.uint8)) for k, v in self.tables.items()})
         return crsmod.build_payload(sections)
 
@@ -189,12 +199,12 @@ class Sigma:
         return path
 
 
-def trusted_setup(qap_path, out_dir, tau, g1_gen):
-    """the file-level surface of the trusted setup for the G1 side: <qap_path>/{setupParams.json, subcircuitInfo.json, r1cs/*}
+def trusted_setup(qap_path, out_dir, tau, g1_gen, g2_gen=None):
+    """the file-level surface of the trusted setup: <qap_path>/{setupParams.json, subcircuitInfo.json, r1cs/*}
     in, <out_dir>/combined_sigma.tkcrs out"""
     with open(os.path.join(qap_path, "setupParams.json")) as f:
         sp = json.load(f)
     with open(os.path.join(qap_path, "subcircuitInfo.json")) as f:
         infos = json.load(f)
-    sigma = Sigma.gen(sp, tau, qap_path, infos, g1_gen)
+    sigma = Sigma.gen(sp, tau, qap_path, infos, g1_gen, g2_gen)
     return sigma, sigma.write(out_dir)
