@@ -493,3 +493,71 @@ def verify_snark(d, s, ch, crs, sp, pre, a_free, kappa2):
     right = ((pre["O_pub_fix"] + d["O_pub_free"]) * crs["gamma"] + d["O_mid"] * crs["eta"] + d["O_prv"] * crs["delta"]
              + aux_x * crs["tau_x"] + aux_y * crs["tau_y"])
     return (left - right) % R == 0
+
+
+# ---- the verifier's combined equation on real group elements (pairing from tests/pairing_ref.py) ----
+class LC:
+    """formal linear combination of named G1 points: {name: scalar}"""
+
+    def __init__(self, terms=None):
+        self.t = {k: v % R for k, v in (terms or {}).items()}
+
+    def __add__(self, o):
+        out = dict(self.t)
+        for k, v in o.t.items():
+            out[k] = (out.get(k, 0) + v) % R
+        return LC(out)
+
+    def __sub__(self, o):
+        return self + o * (R - 1)
+
+    def __mul__(self, s):
+        return LC({k: v * s for k, v in self.t.items()})
+
+    def point(self, named):
+        """-> affine (x, y) ints or None, through the oracle's MSM over the 96-byte records in `named`"""
+        import pairing_ref
+        keys = [k for k, v in self.t.items() if v]
+        if not keys:
+            return None
+        sc = oracle.to_bytes([self.t[k] for k in keys], 32)
+        pts = np.concatenate([np.asarray(named[k], np.uint8).reshape(96) for k in keys])
+        return pairing_ref.g1_from_record(oracle.g1_msm(sc, pts, threads=1))
+
+
+def verify_snark_pairing(points, s, ch, sp, crs_g1, pre_points, sigma2, a_eval, kappa2):
+    """Verifier::verify_snark (verify-rust/src/lib.rs:248-289) with actual pairings.  points: the proof's 19 G1 records by name;
+    crs_g1: {"G", "x", "y", "lagrange_KL"} records; pre_points: {"s0", "s1", "O_pub_fix"} records; sigma2: {"H", "alpha", "alpha2",
+    "alpha3", "alpha4", "gamma", "delta", "eta", "x", "y"} -> tkmk.g2 points.  True iff
+    e(LHS + AUX, H) e(B, a4) e(U, a) e(V, a2) e(W, a3) = e(O_pub_fix + O_pub_free, gamma) e(O_mid, eta) e(O_prv, delta) e(AUX_X, x) e(AUX_Y, y)"""
+    import pairing_ref
+    th, k0, chi, zeta, k1, k2 = ch["thetas"], ch["kappa0"], ch["chi"], ch["zeta"], ch["kappa1"], kappa2
+    m_i, s_max = sp["l_D"] - sp["l"], sp["s_max"]
+    wxi = inv(oracle.to_ints(oracle.root_of_unity(m_i), 32)[0])
+    wyi = inv(oracle.to_ints(oracle.root_of_unity(s_max), 32)[0])
+    t_n_e, t_mi_e, t_s_e = (pow(chi, sp["n"], R) - 1) % R, (pow(chi, m_i, R) - 1) % R, (pow(zeta, s_max, R) - 1) % R
+    k0_e = 1 if chi == 1 else t_mi_e * inv(m_i) * inv(chi - 1) % R
+    named = dict(points)
+    named.update({"crs.G": crs_g1["G"], "crs.x": crs_g1["x"], "crs.y": crs_g1["y"], "crs.KL": crs_g1["lagrange_KL"],
+                  "pre.s0": pre_points["s0"], "pre.s1": pre_points["s1"], "pre.O_pub_fix": pre_points["O_pub_fix"]})
+    p = lambda name: LC({name: 1})                                                    # noqa: E731
+    G = p("crs.G")
+    lhs_a = p("U") * s["V_eval"] - p("W") + (p("V") - G * s["V_eval"]) * k1 - p("Q_AX") * t_n_e - p("Q_AY") * t_s_e
+    F = p("B") + p("pre.s0") * th[0] + p("pre.s1") * th[1] + G * th[2]
+    Gp = p("B") + p("crs.x") * th[0] + p("crs.y") * th[1] + G * th[2]
+    term1 = (p("crs.KL") * (s["R_eval"] - 1) + (Gp * s["R_eval"] - F * s["R_omegaX_eval"]) * (k0 * (chi - 1))
+             + (Gp * s["R_eval"] - F * s["R_omegaX_omegaY_eval"]) * (k0 * k0 % R * k0_e) - p("Q_CX") * t_mi_e - p("Q_CY") * t_s_e)
+    lhs_c = (term1 * (k1 * k1) + (p("R") - G * s["R_eval"]) * pow(k1, 3, R) + (p("R") - G * s["R_omegaX_eval"]) * k2
+             + (p("R") - G * s["R_omegaX_omegaY_eval"]) * (k2 * k2))
+    lhs_b = p("A_free") * (1 + k2 * pow(k1, 4, R)) - G * (k2 * pow(k1, 4, R) % R * a_eval)
+    lhs = lhs_b + (lhs_a + lhs_c) * k2
+    aux = (p("Pi_X") * (k2 * chi) + p("Pi_Y") * (k2 * zeta) + p("M_X") * (k2 * k2 % R * wxi % R * chi) + p("M_Y") * (k2 * k2 % R * zeta)
+           + p("N_X") * (pow(k2, 3, R) * wxi % R * chi) + p("N_Y") * (pow(k2, 3, R) * wyi % R * zeta))
+    aux_x = p("Pi_X") * k2 + p("M_X") * (k2 * k2) + p("N_X") * pow(k2, 3, R)
+    aux_y = p("Pi_Y") * k2 + p("M_Y") * (k2 * k2) + p("N_Y") * pow(k2, 3, R)
+    neg = R - 1
+    pairs = [((lhs + aux).point(named), sigma2["H"]), (p("B").point(named), sigma2["alpha4"]), (p("U").point(named), sigma2["alpha"]),
+             (p("V").point(named), sigma2["alpha2"]), (p("W").point(named), sigma2["alpha3"]),
+             (((p("pre.O_pub_fix") + p("O_pub_free")) * neg).point(named), sigma2["gamma"]), ((p("O_mid") * neg).point(named), sigma2["eta"]),
+             ((p("O_prv") * neg).point(named), sigma2["delta"]), ((aux_x * neg).point(named), sigma2["x"]), ((aux_y * neg).point(named), sigma2["y"])]
+    return pairing_ref.pairing_product(pairs) == pairing_ref.F12.of(1)

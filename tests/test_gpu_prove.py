@@ -129,6 +129,22 @@ def test_prove_equals_reference_restatement_and_verifies(gpu, oracle, tmp_path, 
     assert prove_ref.verify_copy(dlogs, ref_scalars, ref_ch, ref_p4t, crs, sp, pre["s0"], pre["s1"], crs["lagrange_KL"], kappa2=k2)
     assert prove_ref.verify_binding(dlogs, ref_scalars, ref_ch, ref_p4t, crs, pre, rp.a_free, k2)
     assert prove_ref.verify_snark(dlogs, ref_scalars, ref_ch, crs, sp, pre, rp.a_free, k2)
+    if seed == 11:
+        # the same combined equation with ACTUAL pairings (tests/pairing_ref.py) on nothing but what the product produced: the GPU
+        # prover's points and evaluations, the preprocess points, and G / [x]G / [y]G / lagrange_KL / Sigma2 read back from the
+        # TKCRS001 payload the product's setup wrote
+        from tkmk import crs as crsmod
+        from tkmk import g2
+        from tkmk.prove import fr, fr_int
+        sections = crsmod.parse_payload(sigma_obj.payload())
+        crs_g1 = {k: np.asarray(crsmod.single_g1(sections, k)) for k in ("G", "x", "y", "lagrange_KL")}
+        recs = np.asarray(sections["g2"]).reshape(10, 192)
+        sigma2 = {name: g2.decode(recs[i]) for i, name in enumerate(crsmod.G2_POINTS)}
+        pre_points = {name: np.asarray(getattr(pre_pts, name)) for name in ("s0", "s1", "O_pub_fix")}
+        a_eval = fr_int(prover.a_free_X.eval(fr(challenges["chi"]), fr(challenges["zeta"])))
+        assert prove_ref.verify_snark_pairing(points, scalars, challenges, sp, crs_g1, pre_points, sigma2, a_eval, k2)
+        tampered = dict(points, M_Y=np.asarray(points["N_Y"]))
+        assert not prove_ref.verify_snark_pairing(tampered, scalars, challenges, sp, crs_g1, pre_points, sigma2, a_eval, k2)
     # a tampered evaluation must fail them
     bad = dict(ref_scalars, V_eval=(ref_scalars["V_eval"] + 1) % oracle.R_MOD)
     assert not prove_ref.verify_arith(dlogs, bad, ref_ch, ref_p4t, crs, sp)
