@@ -93,7 +93,8 @@ def seeded_mixer(seed):
 
 @pytest.mark.parametrize("seed,shape", [(11, dict(s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6)),
                                         (12, dict(s_max=8, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=6)),
-                                        (13, dict(s_max=16, n_gate_kinds=1, n_out=3, n_in=2, n_prv=2, k_pub=3))])
+                                        (13, dict(s_max=16, n_gate_kinds=1, n_out=3, n_in=2, n_prv=2, k_pub=3)),
+                                        (14, dict(s_max=8, n_gate_kinds=2, used_placements=6, k_out=0, k_pub=3))])   # l_user_out = 0: an empty bufferPubOut
 def test_prove_equals_reference_restatement_and_verifies(gpu, oracle, tmp_path, seed, shape):
     import prove_ref
     import synth_circuit
