@@ -3,7 +3,8 @@
 Shapes: --s-max 256 is the reference's production shape (n = 4096, m_I = 4096, s_max = 256: 2^20 constraint slots;
 reference walls 45.70 s CPU / 21.08 s CUDA with 166 placements); --s-max 1024 is BASELINE.json configs[3]'s
 "2^22-constraint circuit" (SURVEY.md §8d cfg 4).  The circuit comes from tools/synth_circuit.py (random satisfying
-subcircuits, iden3 .r1cs files on disk, synthesizer documents handed over in memory); the CRS is the fixed-tau trusted setup of
+subcircuits with 60 % of the private wires constant bits / small values, as real witnesses are; iden3 .r1cs files on disk, synthesizer
+documents handed over in memory); the CRS is the fixed-tau trusted setup of
 that circuit, generated on the device by tkmk/setup.py (Sigma.gen: xy_powers and the QAP-derived binding tables).
 --check runs the reference's testing-mode assertions (R1CS satisfaction, Lemma 3, quotient identities, zero remainders)
 at full size and compares three commitments with [P(tau_x, tau_y)]G.
@@ -43,7 +44,7 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
     from tkmk.prove import Prover, fr, random_mixer, run_rounds
     t = time.perf_counter()
     inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=13, n_out=80, n_in=170, n_prv=n_prv, k_out=65, k_pub=20,
-                                  l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements)
+                                  l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements, bit_fraction=0.6)
     tmp = tempfile.mkdtemp(prefix="tkmk_prove_bench_")
     synth_circuit.write(inst, tmp, synth_files=False)
     sp = inst["setup_params"]
@@ -122,7 +123,7 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
     import synth_circuit
     import tkmk
     inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=13, n_out=80, n_in=170, n_prv=n_prv, k_out=65, k_pub=20,
-                                  l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements)
+                                  l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements, bit_fraction=0.6)
     tmp = tempfile.mkdtemp(prefix="tkmk_prove_native_")
     try:
         synth_circuit.write(inst, tmp)

@@ -79,18 +79,24 @@ def buffer(sid, name, k):
     return s
 
 
-def random_gates(sid, rnd, n_out, n_in, n_prv, fan=3):
+def random_gates(sid, rnd, n_out, n_in, n_prv, fan=3, bit_fraction=0.0):
+    """bit_fraction of the private wires are constant bits / small values (w = c * 1 with c in {0, 1, small}): real witnesses are
+    dominated by 0/1 wires and small constants, which is what skews the buckets of the binding MSMs"""
     s = Subcircuit(sid, "synthGate%d" % sid, n_out, n_in, n_prv)
     known = [0] + list(s.ins())
     lc = lambda: [(w, rnd.randrange(1, R)) for w in rnd.sample(known, min(fan, len(known)))]   # noqa: E731
     for t in list(s.prvs()) + list(s.outs()):
-        s.define(t, lc(), lc(), lc() if rnd.random() < 0.5 else [])
+        if t in s.prvs() and rnd.random() < bit_fraction:
+            c = rnd.choice([0, 0, 0, 1, 1, 1, 1, rnd.randrange(2, 256)])
+            s.define(t, [(0, c)], [(0, 1)], [])
+        else:
+            s.define(t, lc(), lc(), lc() if rnd.random() < 0.5 else [])
         known.append(t)
     return s
 
 
 def generate(rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub=2, used_placements=None, l_free=4, l_extra=4, n=None,
-             m_i=None, pool=None, k_out=1):
+             m_i=None, pool=None, k_out=1, bit_fraction=0.0):
     """-> the instance in memory (setup params, subcircuit infos, placements with witnesses, permutation, instance).
 
     Public wires follow the layout the CRS is built for (Sigma1::gen, libs/src/group_structures/mod.rs:405-440): placement 0 is
@@ -104,7 +110,7 @@ def generate(rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub=2, us
     assert k_block >= 0 and l_free & (l_free - 1) == 0
     l = l_free + k_fn
     subs = [buffer(i, name, k) for i, (name, k) in enumerate(zip(BUFFER_NAMES, (k_out, k_pub, k_block, k_fn)))]
-    subs += [random_gates(4 + g, rnd, n_out, n_in, n_prv) for g in range(n_gate_kinds)]
+    subs += [random_gates(4 + g, rnd, n_out, n_in, n_prv, bit_fraction=bit_fraction) for g in range(n_gate_kinds)]
     pub_base = (0, l_user_out, l_user, l_free)        # first public wire of each buffer
     # interface wires: constant + the non-public side of the buffers, constant + outputs + inputs of the gates
     need_iface = sum(1 + s.n_out for s in subs[:4]) + sum(1 + s.n_out + s.n_in for s in subs[4:])
