@@ -233,6 +233,20 @@ def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
     assert r2.returncode == 0, r2.stderr
     p2, _ = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
     assert (np.asarray(p2["A_free"]) == np.asarray(points["A_free"])).all() and not (np.asarray(p2["U"]) == np.asarray(points["U"])).all()
+    # a CRS generated for another shape: refused with the section named (Rust would index out of bounds / panic)
+    sp_path = os.path.join(inst["qap"], "setupParams.json")
+    good_sp = open(sp_path).read()
+    json.dump(dict(sp, s_max=2 * sp["s_max"]), open(sp_path, "w"))
+    r4 = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r4.returncode != 0 and "does not match setupParams.json" in r4.stderr
+    open(sp_path, "w").write(good_sp)
+    # corrupted witness document: an error, not a crash
+    pv_path = os.path.join(inst["synth"], "placementVariables.json")
+    good_pv = open(pv_path).read()
+    open(pv_path, "w").write(good_pv[:len(good_pv) // 2])
+    r5 = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r5.returncode == 1 and "placementVariables.json" in r5.stderr
+    open(pv_path, "w").write(good_pv)
     os.remove(os.path.join(crs_dir, "combined_sigma.tkcrs"))
     r3 = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r3.returncode != 0 and "No reference string is found" in r3.stderr
