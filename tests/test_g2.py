@@ -60,3 +60,24 @@ def test_sigma2_relations(g2):
     assert g2.scalar_mul(tau["delta"], s2["gamma"]) == g2.scalar_mul(tau["gamma"], s2["delta"])
     with pytest.raises(ValueError):
         g2.sigma2_gen(tau, ((1, 2), (3, 4)))
+
+
+def test_cpp_g2_equals_python(g2):
+    """host/tkmk_g2.hpp (6 x 64-bit Montgomery Fq, Fp2, Jacobian G2) through tests/host_cpp/g2_driver against tkmk/g2.py"""
+    import subprocess
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_cpp", "g2_driver")
+    assert os.path.exists(driver), "tests/host_cpp/g2_driver is not built (run __graft_entry__.build())"
+    h = g2.from_hex_pair(PINS["fixed_tau_g2_x"], PINS["fixed_tau_g2_y"])
+    rnd = random.Random(5)
+    ks = [0, 1, 2, g2.R - 1, g2.R - 2, 1 << 255, (1 << 64) - 1] + [rnd.randrange(g2.R) for _ in range(12)]
+    lines = ["oncurve 0x0"] + ["mul 0x%x" % k for k in ks] + ["addmul 0x%x" % k for k in ks[:6]]
+    r = subprocess.run([driver, PINS["fixed_tau_g2_x"], PINS["fixed_tau_g2_y"]], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.split()
+    assert out[0] == "1"
+    want = [g2.scalar_mul(k % g2.R, h) for k in ks] + [g2.add(g2.scalar_mul(k % g2.R, h), h) for k in ks[:6]]
+    for got, w in zip(out[1:], want):
+        assert bytes.fromhex(got) == bytes(g2.encode(w))
+    # a point that is not on the twist is reported as such
+    r = subprocess.run([driver, PINS["fixed_tau_g2_y"], PINS["fixed_tau_g2_x"]], input="oncurve 0x0\n", capture_output=True, text=True, timeout=60)
+    assert r.stdout.split() == ["0"]

@@ -252,6 +252,36 @@ def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
     assert r3.returncode != 0 and "No reference string is found" in r3.stderr
 
 
+def test_native_setup_binary(gpu, oracle, tmp_path):
+    """tokamak-zk-evm_amd/bin/trusted-setup (host/setup_main.cpp over host/tkmk_setup.hpp + tkmk_g2.hpp) with --fixed-tau writes the very
+    payload tkmk/setup.py produces — every G1 table and the ten G2 points — and a proof made over it by bin/prove is the restated one"""
+    import subprocess
+    import synth_circuit
+    binary = os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd", "bin", "trusted-setup")
+    assert os.path.exists(binary), "bin/trusted-setup is not built (run __graft_entry__.build())"
+    inst = synth_circuit.build(str(tmp_path), random.Random(61), s_max=8, n_gate_kinds=2, used_placements=7, bit_fraction=0.3)
+    crs_dir = tmp_path / "crs"
+    crs_dir.mkdir()
+    r = subprocess.run([binary, "--fixed-tau", "--subcircuit-library", inst["qap"], "--output", str(crs_dir)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    sigma_obj, _, _ = stage_crs(gpu, oracle, inst)
+    assert open(crs_dir / "combined_sigma.tkcrs", "rb").read() == sigma_obj.payload()
+    # without --fixed-tau: a fresh tau every run, a well-formed payload of the same shape
+    from tkmk import crs as crsmod
+    outs = []
+    for k in range(2):
+        d = tmp_path / ("rnd%d" % k)
+        d.mkdir()
+        r = subprocess.run([binary, "--subcircuit-library", inst["qap"], "--output", str(d)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        sections = crsmod.read_payload(str(d / "combined_sigma.tkcrs"))
+        crsmod.check_shapes(sections, inst["setup_params"])
+        outs.append(bytes(np.asarray(sections["g1"])) + bytes(np.asarray(sections["g2"])))
+    assert outs[0] != outs[1] and any(outs[0][-1920:])
+    r = subprocess.run([binary, "--subcircuit-library", str(tmp_path / "nowhere"), "--output", str(crs_dir)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "trusted-setup:" in r.stderr
+
+
 def test_prove_cli_files_in_files_out(gpu, oracle, tmp_path):
     """process-level surface: `setup --fixed-tau` (setup/trusted-setup/src/main.rs:27-46) writes the CRS, `preprocess` and `prove`
     (preprocess/src/main.rs, prove/src/main.rs:8-25) read it: directories in, preprocess.json / proof.json out"""
