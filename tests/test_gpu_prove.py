@@ -254,7 +254,7 @@ def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
 
 def test_native_setup_binary(gpu, oracle, tmp_path):
     """tokamak-zk-evm_amd/bin/trusted-setup (host/setup_main.cpp over host/tkmk_setup.hpp + tkmk_g2.hpp) with --fixed-tau writes the very
-    payload tkmk/setup.py produces — every G1 table and the ten G2 points — and a proof made over it by bin/prove is the restated one"""
+    payload tkmk/setup.py produces — every G1 table and the ten G2 points (so everything checked on that payload elsewhere holds for it)"""
     import subprocess
     import synth_circuit
     binary = os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd", "bin", "trusted-setup")
