@@ -282,6 +282,53 @@ def test_native_setup_binary(gpu, oracle, tmp_path):
     assert r.returncode == 1 and "trusted-setup:" in r.stderr
 
 
+def test_native_pipeline_setup_preprocess_prove_then_verify_with_pairings(gpu, oracle, tmp_path):
+    """the user's flow with the three native binaries — bin/trusted-setup, bin/preprocess, bin/prove: directories in, files out — and then
+    what a verifier does with the files alone (verify-rust/src/lib.rs:54-117,248-289): recover the points, replay the transcript for the
+    challenges, interpolate a_pub from instance.json, and evaluate the combined equation with actual pairings against the CRS file's
+    G1 singles and Sigma2 (tests/pairing_ref.py).  No prover state, no discrete logarithm, fresh random blinding."""
+    import subprocess
+    import prove_ref
+    import synth_circuit
+    from tkmk import crs as crsmod
+    from tkmk import g2, proofio
+    from tkmk.transcript import TranscriptManager
+    bin_dir = os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd", "bin")
+    rnd = random.Random(71)
+    inst = synth_circuit.build(str(tmp_path), rnd, s_max=8, n_gate_kinds=2, used_placements=8, bit_fraction=0.4)
+    sp = inst["setup_params"]
+    crs_dir, out_dir = str(tmp_path / "crs"), str(tmp_path / "out")
+    os.makedirs(crs_dir)
+    os.makedirs(out_dir)
+    common = ["--synthesizer-stat", inst["synth"], "--output", out_dir, "--subcircuit-library", inst["qap"]]
+    for cmd in ([os.path.join(bin_dir, "trusted-setup"), "--fixed-tau", "--subcircuit-library", inst["qap"], "--output", crs_dir],
+                [os.path.join(bin_dir, "preprocess"), "--crs", crs_dir] + common, [os.path.join(bin_dir, "prove"), "--crs", crs_dir] + common):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (cmd[0], r.stderr)
+    points, scalars = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
+    pre_points = proofio.recover_preprocess(json.load(open(os.path.join(out_dir, "preprocess.json"))))
+    m = TranscriptManager()                                  # Verifier::collect_challenges
+    m.add_proof0(*(points[k] for k in ("U", "V", "W", "Q_AX", "Q_AY", "B")))
+    thetas = m.get_thetas()
+    m.add_proof1(points["R"])
+    kappa0 = m.get_kappa0()
+    m.add_proof2(points["Q_CX"], points["Q_CY"])
+    chi, zeta = m.get_chi_zeta()
+    m.add_proof3(scalars["V_eval"], scalars["R_eval"], scalars["R_omegaX_eval"], scalars["R_omegaX_omegaY_eval"])
+    ch = {"thetas": thetas, "kappa0": kappa0, "chi": chi, "zeta": zeta, "kappa1": m.get_kappa1()}
+    ins = json.load(open(os.path.join(inst["synth"], "instance.json")))
+    a = [int(h, 16) for h in ins["a_pub_user"][:sp["l_user"]]] + [int(h, 16) for h in ins["a_pub_block"][:sp["l_free"] - sp["l_user"]]]
+    a_eval = prove_ref.interpolate([[v] for v in a], sp["l_free"], 1).eval(chi, zeta)          # Instance::gen_a_free_X, then eval
+    sections = crsmod.read_payload(os.path.join(crs_dir, "combined_sigma.tkcrs"))
+    crs_g1 = {k: np.asarray(crsmod.single_g1(sections, k)) for k in ("G", "x", "y", "lagrange_KL")}
+    recs = np.asarray(sections["g2"]).reshape(10, 192)
+    sigma2 = {name: g2.decode(recs[i]) for i, name in enumerate(crsmod.G2_POINTS)}
+    kappa2 = rnd.randrange(1, oracle.R_MOD)
+    assert prove_ref.verify_snark_pairing(points, scalars, ch, sp, crs_g1, pre_points, sigma2, a_eval, kappa2)
+    # the same files with one public input changed do not verify
+    assert not prove_ref.verify_snark_pairing(points, scalars, ch, sp, crs_g1, pre_points, sigma2, (a_eval + 1) % oracle.R_MOD, kappa2)
+
+
 def test_prove_cli_files_in_files_out(gpu, oracle, tmp_path):
     """process-level surface: `setup --fixed-tau` (setup/trusted-setup/src/main.rs:27-46) writes the CRS, `preprocess` and `prove`
     (preprocess/src/main.rs, prove/src/main.rs:8-25) read it: directories in, preprocess.json / proof.json out"""
