@@ -91,3 +91,15 @@ def test_generated_files_are_read_by_the_host_readers(tmp_path):
         assert (r.n_wires, r.n_constraints) == (sub.n_wires, len(sub.rows))
     m_i = sp["l_D"] - sp["l"]
     assert m_i & (m_i - 1) == 0 and all(0 <= e["row"] < m_i and 0 <= e["X"] < m_i for e in inst["permutation"])
+
+
+def test_validate_setup_shape_messages():
+    """the reference's panics of setup_shape / validate_setup_shape (libs/src/utils/mod.rs:21-46)"""
+    import pytest
+    from tkmk.prove import validate_setup_shape
+    good = {"l": 8, "l_D": 40, "n": 16, "s_max": 8, "l_free": 4}
+    assert validate_setup_shape(good) == 32
+    for change, msg in (({"n": 12}, "n is not a power of two."), ({"s_max": 6}, "s_max is not a power of two."),
+                        ({"l_D": 41}, "m_I is not a power of two."), ({"l_D": 7}, "Invalid setup params: l_D must be >= l.")):
+        with pytest.raises(ValueError, match=msg.replace(".", r"\.").replace(">", r"\>")):
+            validate_setup_shape(dict(good, **change))

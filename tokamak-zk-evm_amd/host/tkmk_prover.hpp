@@ -234,7 +234,10 @@ class Prover {
         p->sp = in.sp;
         const SetupParams &sp = in.sp;
         size_t m_i = sp.l_D - sp.l, n = sp.n, s_max = sp.s_max;
-        if (!is_pow2(m_i) || !is_pow2(n) || !is_pow2(s_max) || !is_pow2(sp.l_free)) throw Error("setup shape: n, s_max, l_D - l, l_free must be powers of two");
+        if (sp.l_D < sp.l) throw Error("Invalid setup params: l_D must be >= l.");   // setup_shape / validate_setup_shape (libs/src/utils/mod.rs:21-46)
+        if (!is_pow2(n)) throw Error("n is not a power of two.");
+        if (!is_pow2(s_max)) throw Error("s_max is not a power of two.");
+        if (!is_pow2(m_i)) throw Error("m_I is not a power of two.");
         p->m_i = m_i;
         p->sigma = &sigma;
         p->mixer = mixer;

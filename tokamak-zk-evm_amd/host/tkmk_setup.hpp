@@ -116,7 +116,11 @@ struct Sigma {
                      const std::vector<size_t> &n_consts, const G1Affine &g1, const g2h::Affine *g2_gen) {
         using namespace setup_detail;
         size_t n = sp.n, s_max = sp.s_max, l = sp.l, l_free = sp.l_free, m_i = sp.l_D - sp.l;
-        if (!is_pow2(n) || !is_pow2(s_max) || !is_pow2(m_i) || !is_pow2(l_free)) throw Error("setup shape: n, s_max, l_D - l, l_free must be powers of two");
+        if (sp.l_D < sp.l) throw Error("Invalid setup params: l_D must be >= l.");   // setup_shape / validate_setup_shape (libs/src/utils/mod.rs:21-46)
+        if (!is_pow2(n)) throw Error("n is not a power of two.");
+        if (!is_pow2(s_max)) throw Error("s_max is not a power of two.");
+        if (!is_pow2(m_i)) throw Error("m_I is not a power of two.");
+        if (l_free != 0 && !is_pow2(l_free)) throw Error("l is not a power of two.");      // validate_public_wire_size (:48-52)
         init_ntt_domain_for_size(std::max(std::max(n, l_free), std::max(m_i, s_max)));   // trusted_setup_ntt_domain_size (libs/src/utils/mod.rs:60-66)
         ScalarField gi = fr_inv(tau.gamma), di = fr_inv(tau.delta), ei = fr_inv(tau.eta);
         DeviceVec<ScalarField> k_dev = lagrange_bases(tau.x, m_i), l_dev = lagrange_bases(tau.y, s_max), m_dev = lagrange_bases(tau.x, l_free);

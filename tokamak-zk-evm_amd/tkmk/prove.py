@@ -153,11 +153,13 @@ def random_mixer(rng=None):
 
 
 def validate_setup_shape(sp):
-    """setup_shape / validate_setup_shape (libs/src/utils): the sizes every 2-D NTT relies on"""
+    """setup_shape + validate_setup_shape (libs/src/utils/mod.rs:21-46), with the reference's panic messages; -> m_I"""
+    if sp["l_D"] < sp["l"]:
+        raise ValueError("Invalid setup params: l_D must be >= l.")
     m_i = sp["l_D"] - sp["l"]
-    for name, v in (("n", sp["n"]), ("s_max", sp["s_max"]), ("l_D - l", m_i), ("l_free", sp["l_free"])):
+    for name, v in (("n", sp["n"]), ("s_max", sp["s_max"]), ("m_I", m_i)):
         if v <= 0 or v & (v - 1):
-            raise ValueError("%s must be a power of two" % name)
+            raise ValueError("%s is not a power of two." % name)
     return m_i
 
 

@@ -123,10 +123,10 @@ class Sigma:
     def gen(cls, setup_params, tau, qap_path, subcircuit_infos, g1_gen, g2_gen=None):
         sp = setup_params
         n, s_max, l, l_free, l_user, l_user_out, l_d, m_d = (sp[k] for k in ("n", "s_max", "l", "l_free", "l_user", "l_user_out", "l_D", "m_D"))
-        m_i = l_d - l
-        for name, v in (("n", n), ("s_max", s_max), ("l_D - l", m_i), ("l_free", l_free)):
-            if v <= 0 or v & (v - 1):
-                raise ValueError("%s must be a power of two" % name)
+        from tkmk.prove import validate_setup_shape
+        m_i = validate_setup_shape(sp)                    # main.rs:93-94
+        if l_free != 0 and l_free & (l_free - 1):        # validate_public_wire_size (libs/src/utils/mod.rs:48-52)
+            raise ValueError("l is not a power of two.")
         tkmk.init_ntt_domain_for_size(max(n, l_free, m_i, s_max))      # trusted_setup_ntt_domain_size (libs/src/utils/mod.rs:60-66)
         g = np.ascontiguousarray(g1_gen, np.uint8)
         pts = lambda scal_dev, count: tkmk.g1_batch_scalar_mul_device(scal_dev, g, count)   # noqa: E731
