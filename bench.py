@@ -13,6 +13,15 @@ bases P_i = [h_i]G.  Prints ONE JSON line (rank 0).
 value = "MSM field-adds/sec": group additions per second at the algorithmic count SURVEY.md §8d fixes for
 this config (ceil(255/16) = 16 bucket-accumulate adds per point, independent of the window width the
 kernel actually picks, so the figure is points/s x 16 and cannot be inflated by doing more work).
+
+Secondary objects on the same line (N = 1 only; each records {"error": ...} instead of costing the line if it fails):
+  cpu_baseline  the oracle's Pippenger on a 2^20-point sample of the same stream, on the box's host cores
+  bn254_msm     the same MSM kernels over BN254 (BASELINE.json configs[1] as worded)
+  ntt           BASELINE.json configs[2] (256 x 2^20 scalar-field NTTs) and the production _biNTT shapes
+  prove         BASELINE.json's "constraints/sec (prove step)": the whole prover (init + prove0..4) on synthetic satisfying circuits at the
+                reference's production shape (2^20 constraint slots) and at configs[3]'s 2^22 slots, the production shape through the native
+                binary on files, the proof's algorithmic bytes against the HBM peak, and a CPU estimate from the oracle's measured rates
+With --gpus N --prove-dist the production-shape proof is also timed with the commitments of each round spread over the ranks.
 """
 import argparse
 import json
