@@ -94,7 +94,9 @@ def seeded_mixer(seed):
 @pytest.mark.parametrize("seed,shape", [(11, dict(s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6)),
                                         (12, dict(s_max=8, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=6, bit_fraction=0.6)),
                                         (13, dict(s_max=16, n_gate_kinds=1, n_out=3, n_in=2, n_prv=2, k_pub=3)),
-                                        (14, dict(s_max=8, n_gate_kinds=2, used_placements=6, k_out=0, k_pub=3))])   # l_user_out = 0: an empty bufferPubOut
+                                        (14, dict(s_max=8, n_gate_kinds=2, used_placements=6, k_out=0, k_pub=3)),   # l_user_out = 0: an empty bufferPubOut
+                                        # n = 2: the 4-coefficient blinding polynomial overlaps its own shift by n (found by tools/prove_fuzz.py)
+                                        (15, dict(s_max=8, n_gate_kinds=2, n_out=1, n_in=2, n_prv=1, k_out=0, k_pub=2, l_extra=1, used_placements=7))])
 def test_prove_equals_reference_restatement_and_verifies(gpu, oracle, tmp_path, seed, shape):
     import prove_ref
     import synth_circuit
@@ -189,7 +191,8 @@ def _stage_crs_file(gpu, oracle, inst, crs_dir):
 
 
 @pytest.mark.parametrize("seed,shape", [(41, dict(s_max=8, n_gate_kinds=2)), (42, dict(s_max=8, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=6, bit_fraction=0.6)),
-                                        (43, dict(s_max=8, n_gate_kinds=2, used_placements=6, k_out=0, k_pub=3))])
+                                        (43, dict(s_max=8, n_gate_kinds=2, used_placements=6, k_out=0, k_pub=3)),
+                                        (44, dict(s_max=8, n_gate_kinds=2, n_out=1, n_in=2, n_prv=1, k_out=0, k_pub=2, l_extra=1, used_placements=7))])
 def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
     """tokamak-zk-evm_amd/bin/prove (host/prove_main.cpp over host/tkmk_prover.hpp, the C++ host side) writes the same proof.json as
     the Python prover for the same blinding scalars, and both equal the exponent restatement"""

@@ -22,7 +22,8 @@ def _crs(oracle, inst):
 
 @pytest.mark.parametrize("seed,shape", [(1, dict(s_max=8)), (2, dict(s_max=8, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=6, bit_fraction=0.6)),
                                         (3, dict(s_max=16, n_gate_kinds=1, n_out=3, n_in=2, n_prv=2, k_pub=3)),
-                                        (4, dict(s_max=8, n_gate_kinds=2, used_placements=6, k_out=0, k_pub=3))])   # l_user_out = 0: an empty bufferPubOut
+                                        (4, dict(s_max=8, n_gate_kinds=2, used_placements=6, k_out=0, k_pub=3)),   # l_user_out = 0: an empty bufferPubOut
+                                        (5, dict(s_max=8, n_gate_kinds=2, n_out=1, n_in=2, n_prv=1, k_out=0, k_pub=2, l_extra=1, used_placements=7))])   # n = 2
 def test_restated_prover_verifies(oracle, tmp_path, seed, shape):
     import prove_ref
     import synth_circuit

@@ -152,14 +152,14 @@ inline Poly sparse(const std::vector<std::pair<size_t, ScalarField>> &entries, s
 // lib.rs:48-68: (sum c_i T^i) * (T^exponent - 1) along one axis
 template <size_t K>
 inline Poly low_degree_times_vanishing(const std::array<ScalarField, K> &coeffs, size_t exponent, bool x_axis) {
-    if (exponent == 0 || K > exponent) throw Error("low_degree_times_vanishing: bad exponent");
+    if (exponent == 0) throw Error("low_degree_times_vanishing: exponent must be positive");   // assert!(exponent > 0)
     size_t size = next_pow2(exponent + K);
-    std::vector<std::pair<size_t, ScalarField>> e;
-    for (size_t i = 0; i < K; i++) {
-        e.push_back({i, fr_neg(coeffs[i])});
-        e.push_back({i + exponent, coeffs[i]});
+    std::vector<ScalarField> c(size);
+    for (size_t i = 0; i < K; i++) {   // accumulated: the two copies overlap when exponent < K
+        c[i] = fr_sub(c[i], coeffs[i]);
+        c[i + exponent] = fr_add(c[i + exponent], coeffs[i]);
     }
-    return x_axis ? sparse(e, size, 1) : sparse(e, 1, size);
+    return x_axis ? Poly::from_coeffs(c, size, 1) : Poly::from_coeffs(c, 1, size);
 }
 inline Poly vanishing(size_t size, bool x_axis) {   // lib.rs:849-894
     std::vector<std::pair<size_t, ScalarField>> e = {{0, fr_neg(fr_one())}, {size, fr_one()}};

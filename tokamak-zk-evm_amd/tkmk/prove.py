@@ -63,23 +63,23 @@ def poly_comb(*terms):
 
 def low_degree_x_times_vanishing(coeffs, exponent):
     """lib.rs:48-57: (sum c_i X^i) * (X^exponent - 1)"""
-    assert exponent > 0 and len(coeffs) <= exponent
+    assert exponent > 0
     x_size = 1 << (exponent + len(coeffs) - 1).bit_length()
     entries = {}
-    for i, c in enumerate(coeffs):
-        entries[i] = (R - c) % R
-        entries[i + exponent] = c % R
+    for i, c in enumerate(coeffs):                       # accumulated: the two copies overlap when exponent < len(coeffs)
+        entries[i] = (entries.get(i, 0) - c) % R
+        entries[i + exponent] = (entries.get(i + exponent, 0) + c) % R
     return _sparse(entries, x_size, 1)
 
 
 def low_degree_y_times_vanishing(coeffs, exponent):
     """lib.rs:59-68"""
-    assert exponent > 0 and len(coeffs) <= exponent
+    assert exponent > 0
     y_size = 1 << (exponent + len(coeffs) - 1).bit_length()
     entries = {}
-    for i, c in enumerate(coeffs):
-        entries[i] = (R - c) % R
-        entries[i + exponent] = c % R
+    for i, c in enumerate(coeffs):                       # accumulated: the two copies overlap when exponent < len(coeffs)
+        entries[i] = (entries.get(i, 0) - c) % R
+        entries[i + exponent] = (entries.get(i + exponent, 0) + c) % R
     return _sparse(entries, 1, y_size)
 
 
