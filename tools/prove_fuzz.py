@@ -1,9 +1,11 @@
 """Randomized differential run of the GPU prover against the big-int restatement (tests/prove_ref.py) over random circuit shapes:
 every proof point, evaluation and challenge must match, and the combined verifier equation must hold on the discrete logarithms.
-usage: python tools/prove_fuzz.py [CASES] [FIRST_SEED]      (test infrastructure: uses the oracle)"""
+usage: python tools/prove_fuzz.py [CASES] [FIRST_SEED] [native]      (test infrastructure: uses the oracle)
+With `native` the proof comes from tokamak-zk-evm_amd/bin/prove over files (CRS written by Sigma.write, blinding through TKMK_PROVE_MIXER)."""
 import json
 import os
 import random
+import subprocess
 import sys
 import tempfile
 
@@ -21,6 +23,7 @@ from tkmk.setup import Sigma  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+native = len(sys.argv) > 3 and sys.argv[3] == "native"
 pins = json.load(open(os.path.join(ROOT, "tests", "golden", "pins.json")))
 tau = {k: int(pins["tau_" + k], 16) for k in ("x", "y", "alpha", "gamma", "delta", "eta")}
 g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
@@ -38,11 +41,23 @@ for seed in range(first, first + cases):
     sp = inst["setup_params"]
     sigma = Sigma.gen(sp, tau, inst["qap"], inst["infos"], np.frombuffer(bytes(g), np.uint8), None)
     mixer = random_mixer(random.Random(seed))
-    prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, testing_mode=True, sigma=sigma.prover_view())
-    points, scalars, challenges, p4t, _ = run_rounds(prover, binding)
     crs = prove_ref.sigma_gen(inst, tau)
     dlogs, ref_scalars, ref_ch, ref_p4t, rp = prove_ref.run(inst, crs, mixer, g)
-    assert challenges == ref_ch and scalars == ref_scalars, (seed, shape)
+    if native:
+        sigma.write(os.path.join(d, "crs"))
+        os.makedirs(os.path.join(d, "out"))
+        hx = lambda v: [hx(e) for e in v] if isinstance(v, list) else "0x%x" % v      # noqa: E731
+        json.dump({k: hx(v) for k, v in mixer.items()}, open(os.path.join(d, "mixer.json"), "w"))
+        r = subprocess.run([os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "prove"), "--crs", os.path.join(d, "crs"), "--synthesizer-stat", inst["synth"],
+                            "--output", os.path.join(d, "out"), "--subcircuit-library", inst["qap"]], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, TKMK_PROVE_MIXER=os.path.join(d, "mixer.json")))
+        assert r.returncode == 0, (seed, shape, r.stderr)
+        points, scalars = proofio.recover_proof(json.load(open(os.path.join(d, "out", "proof.json"))))
+        assert scalars == ref_scalars, (seed, shape)
+    else:
+        prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, testing_mode=True, sigma=sigma.prover_view())
+        points, scalars, challenges, p4t, _ = run_rounds(prover, binding)
+        assert challenges == ref_ch and scalars == ref_scalars, (seed, shape)
     for name in proofio.PROOF_POINT_ORDER:
         assert (np.asarray(points[name]) == np.asarray(prove_ref.g1_of(dlogs[name], g))).all(), (seed, shape, name)
     pre = prove_ref.preprocess(rp, inst, crs)
