@@ -158,6 +158,29 @@ def test_prove_equals_reference_restatement_and_verifies(gpu, oracle, tmp_path, 
     assert back_scalars == scalars and all((np.asarray(back_points[k]) == np.asarray(points[k])).all() for k in points)
 
 
+def test_prove_equals_restatement_at_a_larger_shape(gpu, oracle, tmp_path):
+    """m_I = 128, n = 32, s_max = 32: the p_comb domain is 512 x 64, the commitment boxes up to 256 x 63 — the prover's NTTs and MSMs leave
+    the single-pass / tiny sizes of the other shapes (the big-int restatement needs ~15 s here; m_I = 256 was run once by hand)"""
+    import prove_ref
+    import synth_circuit
+    from tkmk import proofio
+    from tkmk.prove import Prover, run_rounds
+    rnd = random.Random(1)
+    inst = synth_circuit.build(str(tmp_path), rnd, s_max=32, n_gate_kinds=6, n_out=6, n_in=10, n_prv=24, k_out=2, k_pub=3, l_free=8, l_extra=3,
+                               used_placements=27, bit_fraction=0.5)
+    sp = inst["setup_params"]
+    assert (sp["l_D"] - sp["l"], sp["n"], sp["s_max"]) == (128, 32, 32)
+    sigma_obj, crs, g = stage_crs(gpu, oracle, inst)
+    mixer = seeded_mixer(1)
+    prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, testing_mode=True, sigma=sigma_obj.prover_view())
+    points, scalars, challenges, _, _ = run_rounds(prover, binding)
+    dlogs, ref_scalars, ref_ch, _, rp = prove_ref.run(inst, crs, mixer, g)
+    assert challenges == ref_ch and scalars == ref_scalars
+    for name in proofio.PROOF_POINT_ORDER:
+        assert (np.asarray(points[name]) == np.asarray(prove_ref.g1_of(dlogs[name], g))).all(), name
+    assert prove_ref.verify_snark(dlogs, ref_scalars, ref_ch, crs, sp, prove_ref.preprocess(rp, inst, crs), rp.a_free, 5)
+
+
 def test_testing_mode_rejects_bad_witness_and_bad_copy(gpu, oracle, tmp_path):
     """the reference panics in testing-mode when R1CS or the copy constraints fail (lib.rs:1513-1517, 980-993)"""
     import synth_circuit
