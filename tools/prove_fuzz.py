@@ -1,6 +1,6 @@
 """Randomized differential run of the GPU prover against the big-int restatement (tests/prove_ref.py) over random circuit shapes:
 every proof point, evaluation and challenge must match, and the combined verifier equation must hold on the discrete logarithms.
-usage: python tools/prove_fuzz.py [CASES] [FIRST_SEED] [native]      (test infrastructure: uses the oracle)
+usage: python tools/prove_fuzz.py [CASES] [FIRST_SEED] [native] [mid]      (test infrastructure: uses the oracle)
 With `native` the proof comes from tokamak-zk-evm_amd/bin/prove over files (CRS written by Sigma.write, blinding through TKMK_PROVE_MIXER)."""
 import json
 import os
@@ -23,7 +23,8 @@ from tkmk.setup import Sigma  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-native = len(sys.argv) > 3 and sys.argv[3] == "native"
+native = "native" in sys.argv[3:]
+mid = "mid" in sys.argv[3:]            # m_I = 64 .. 128 instead of 16 .. 64 (the restatement then needs 1 .. 15 s per case)
 pins = json.load(open(os.path.join(ROOT, "tests", "golden", "pins.json")))
 tau = {k: int(pins["tau_" + k], 16) for k in ("x", "y", "alpha", "gamma", "delta", "eta")}
 g = oracle.to_bytes([int(pins["fixed_tau_g1_x"], 16), int(pins["fixed_tau_g1_y"], 16)], 48)
@@ -36,6 +37,10 @@ for seed in range(first, first + cases):
     shape = dict(s_max=s_max, n_gate_kinds=rnd.choice([1, 2, 3]), n_out=rnd.choice([1, 2, 3]), n_in=rnd.choice([1, 2, 3]), n_prv=rnd.randrange(1, 13),
                  k_out=k_out, k_pub=k_pub, l_free=l_free, l_extra=rnd.choice([1, 2, 4, 5]), used_placements=rnd.randrange(5, s_max + 1),
                  bit_fraction=rnd.choice([0.0, 0.3, 0.9]))
+    if mid:
+        s_max = rnd.choice([16, 32])
+        shape.update(s_max=s_max, n_gate_kinds=rnd.choice([4, 5, 6]), n_out=rnd.choice([3, 4, 6]), n_in=rnd.choice([3, 5, 8]), n_prv=rnd.randrange(4, 28),
+                     used_placements=rnd.randrange(5, s_max + 1))
     d = tempfile.mkdtemp(prefix="tkmk_fuzz_")
     inst = synth_circuit.build(d, rnd, **shape)
     sp = inst["setup_params"]
