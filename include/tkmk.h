@@ -153,6 +153,38 @@ typedef struct {
 } tkmk_msm_job;
 tkmk_error tkmk_msm_multi(const tkmk_msm_job *jobs, int n_jobs, const tkmk_msm_config *cfg, tkmk_g1_projective *results);
 
+/* The same over VIEWS of device-resident tables, for the two shapes in which the reference builds MSM operands by copying:
+ *   encode_poly (libs/src/iotools/mod.rs:2061-2088; macro twin libs/src/group_structures/mod.rs:59-119) trims the coefficient
+ *     matrix to its degree box and copies the matching sub-grid of xy_powers, point by point, before every MSM:
+ *       scalar_cols / scalar_stride and base_cols / base_stride address the box inside the resident matrix / CRS table
+ *       (element k of the MSM = row k / cols, column k % cols of a stride-wide row-major table);
+ *   msm_g1_bases over per-wire CRS rows (libs/src/group_structures/mod.rs:127-143,266-300):
+ *       base_index[k] = row of the binding table that wire k commits against (device array of msm_size u32).
+ * bases_form says what `bases` holds: TKMK_BASES_PLAIN / _MONTGOMERY as in tkmk_msm_config, or TKMK_BASES_CONVERTED = a
+ * table that went through bls12_381_msm_convert_bases once (the CRS is fixed for its lifetime; the per-call conversion of
+ * bls12_381_msm is then skipped).  Scalars and bases must be on the device (cfg->are_*_on_device = true).
+ * base_table_len = number of records behind `bases` (0 = unchecked for strided views; required with base_index, where an
+ * entry >= base_table_len makes the call return TKMK_ERR_INVALID_ARGUMENT — the read is clamped on the device, never
+ * issued out of bounds).  results[j] is bit-identical to bls12_381_msm on the gathered operands. */
+#define TKMK_BASES_PLAIN 0
+#define TKMK_BASES_MONTGOMERY 1
+#define TKMK_BASES_CONVERTED 2
+typedef struct {
+    const tkmk_fr *scalars;
+    const tkmk_g1_affine *bases;
+    int msm_size;
+    uint32_t scalar_cols, scalar_stride;   /* 0, 0 = contiguous */
+    uint32_t base_cols, base_stride;       /* 0, 0 = contiguous */
+    const uint32_t *base_index;            /* NULL = none; takes precedence over base_cols */
+    uint64_t base_table_len;
+} tkmk_msm_job_ex;
+tkmk_error tkmk_msm_multi_ex(const tkmk_msm_job_ex *jobs, int n_jobs, const tkmk_msm_config *cfg, int bases_form,
+                             tkmk_g1_projective *results);
+/* bases (n points; host or device per cfg->are_points_on_device, plain or Montgomery per cfg->are_points_montgomery_form) ->
+ * the library's resident form for TKMK_BASES_CONVERTED, written to `out` (host or device per cfg->are_results_on_device;
+ * out == bases is allowed).  Only meaningful as the `bases` of a later tkmk_msm_multi_ex call. */
+tkmk_error bls12_381_msm_convert_bases(const tkmk_g1_affine *bases, uint64_t n, const tkmk_msm_config *cfg, tkmk_g1_affine *out);
+
 /* ---------------------------------------------------------------------------------------------
  * NTT — replaces icicle_core::ntt::{ntt, initialize_domain, release_domain, get_root_of_unity}
  * (extern "C" bls12_381_ntt, _ntt_init_domain, _ntt_release_domain, _get_root_of_unity) as called at
@@ -349,6 +381,39 @@ tkmk_error tkmk_poly_div_by_ruffini(const tkmk_fr *p_dev, uint32_t x_size, uint3
 tkmk_error tkmk_r1cs_eval_rows(const uint32_t *row_ptr_dev, const uint32_t *wire_dev, const tkmk_fr *coeff_dev, uint32_t n_rows,
                                uint32_t nnz, const tkmk_fr *variables_dev, uint32_t n_wires, uint32_t n_placements,
                                const uint32_t *out_slot_dev, uint32_t n, tkmk_fr *out_dev, tkmk_stream stream);
+
+/* The same for a whole subcircuit library and every placement of a proof at once.  The library (CSR of A / B / C of every
+ * subcircuit kind, read from <lib>/r1cs/subcircuit{id}.r1cs: SubcircuitR1CS::from_r1cs_sparse_only, libs/src/iotools/mod.rs:652-760)
+ * is circuit-static: it is built once and kept on the device next to the CRS.  row_ptr / wire / coeff: 3 * n_sub HOST arrays in
+ * the order [sub][A, B, C] (row_ptr[k]: n_rows[sub] + 1 entries; coeff plain Fr); wire indices are validated against n_wires.
+ * _eval: placement p instantiates kind placement_id_dev[p] on vars_dev[placement_var_offset_dev[p] ..] (offsets in elements);
+ * u / v / w are n x s_max evaluation matrices, element (row, placement), fully written — the layout from_rou_evals takes
+ * (read_R1CS_gen_uvwXY transposes its s_max x n rows into it, libs/src/iotools/mod.rs:1391-1418).  Device pointers. */
+typedef struct tkmk_r1cs_library tkmk_r1cs_library;
+tkmk_error tkmk_r1cs_library_create(uint32_t n_sub, const uint32_t *n_rows, const uint32_t *n_wires, const uint32_t *const *row_ptr,
+                                    const uint32_t *const *wire, const tkmk_fr *const *coeff, tkmk_r1cs_library **out);
+tkmk_error tkmk_r1cs_library_destroy(tkmk_r1cs_library *lib);
+tkmk_error tkmk_r1cs_library_eval(const tkmk_r1cs_library *lib, const tkmk_fr *vars_dev, const uint32_t *placement_id_dev,
+                                  const uint64_t *placement_var_offset_dev, uint32_t n_placements, uint32_t n, uint32_t s_max,
+                                  tkmk_fr *u_dev, tkmk_fr *v_dev, tkmk_fr *w_dev, tkmk_stream stream);
+/* Routes witness values by a static (local wire, row) list of one subcircuit kind, for the n_placements placements of that kind
+ * (variables at var_offset_dev[i], global placement index slot_dev[i]):
+ *   matrix_dev      (optional): matrix_dev[row * matrix_stride + slot] = value — gen_bXY's interface-wire matrix
+ *                               (libs/src/polynomial_structures/mod.rs:132-162; row = flattenMap[wire] - l)
+ *   scalars_out_dev / index_out_dev (optional, together): entry i * n_list + e = value / row * index_inner + (index_add_slot ? slot : 0)
+ *                               — the (scalar, CRS row) lists of encode_statement_common and encode_O_pub_free
+ *                               (libs/src/group_structures/mod.rs:184-229, 266-300), consumed by tkmk_msm_multi_ex as base_index */
+tkmk_error tkmk_witness_route(const tkmk_fr *vars_dev, const uint64_t *var_offset_dev, const uint32_t *slot_dev, uint32_t n_placements,
+                              const uint32_t *list_wire_dev, const uint32_t *list_row_dev, uint32_t n_list, tkmk_fr *matrix_dev,
+                              uint32_t matrix_stride, tkmk_fr *scalars_out_dev, uint32_t *index_out_dev, uint32_t index_inner,
+                              int index_add_slot, tkmk_stream stream);
+/* out_dev[dst_idx_dev[i]] = table_dev[src_idx_dev[i]], i < n; dst indices must be distinct — Permutation::to_poly's redirects
+ * s0[row][col] = w_x^X, s1[row][col] = w_y^Y (libs/src/iotools/mod.rs:438-448) */
+tkmk_error tkmk_fr_scatter_table(const tkmk_fr *table_dev, const uint32_t *src_idx_dev, const uint32_t *dst_idx_dev, uint64_t n,
+                                 tkmk_fr *out_dev, tkmk_stream stream);
+/* pinned host memory for staging (HostSlice buffers the reference uploads from are pageable; pinned staging reaches link rate) */
+tkmk_error tkmk_host_malloc(void **ptr, size_t bytes);
+tkmk_error tkmk_host_free(void *ptr);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart; the reference's `timing` feature wraps host spans:

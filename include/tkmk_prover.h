@@ -1,0 +1,54 @@
+/* tkmk_prover.h — C ABI of the resident prover (libtkmk_prover.so): the process/CLI boundary of `prove` and `preprocess`
+ *  as library calls, for a host that produces many proofs of one circuit.
+ *
+ * Replaces, per call:
+ *   tkmk_prover_open      the circuit-static part of Prover::init  (packages/backend/prove/src/lib.rs:675-835: setupParams.json,
+ *                         subcircuitInfo.json, r1cs/subcircuit{id}.r1cs) + SigmaHolder::load (prove/src/sigma_source.rs:22-47:
+ *                         <crs>/combined_sigma.rkyv; the flat <crs>/combined_sigma.tkcrs payload is accepted as a fast path)
+ *                         + check_device (libs/src/utils/mod.rs:78-110)
+ *   tkmk_prover_prove     main() of prove/src/main.rs:41-84: Prover::init on <synthesizer>/{placementVariables,permutation,
+ *                         instance}.json, prove0..prove4 with the Fiat-Shamir transcript, <output>/proof.json in the
+ *                         Solidity-verifier format (prove/src/lib.rs:452-513)
+ *   tkmk_prover_close     process exit
+ * A reference maintainer binds these three from Rust and keeps the `prove` argument surface.
+ * One context per process and GPU; calls on one context must not overlap.  There is no CPU fallback: without a gfx950
+ * device tkmk_prover_open returns TKMK_ERR_NO_DEVICE.  Errors: the tkmk_error code, text from tkmk_prover_last_error()
+ * (the reference panics with the same messages). */
+#ifndef TKMK_PROVER_H
+#define TKMK_PROVER_H
+#include "tkmk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tkmk_prover tkmk_prover;
+
+typedef struct {          /* seconds */
+    double parse_s;       /* the three synthesizer documents -> host arrays (all cores) */
+    double upload_s;      /* witness + index arrays -> HBM */
+    double build_s;       /* u, v, w, b, s0, s1, a_free on the device */
+    double binding_s;     /* A_free, O_pub_free, O_mid, O_prv */
+    double init_s;        /* Prover::init = the four above */
+    double prove_s[5];    /* prove0 .. prove4 */
+    double write_s;       /* proof.json */
+    double total_s;
+} tkmk_prove_timing;
+
+tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const char *crs_dir, tkmk_prover **out);
+/* output_dir may be NULL (no file is written); proof_json_out (optional) receives a malloc'ed copy of the document, to be
+ * released with tkmk_prover_free_string.  testing_mixer_json: NULL in production (blinding scalars from getrandom());
+ * a path to a JSON document with fixed blinding scalars makes the proof deterministic — for differential tests only,
+ * a proof made with known blinding scalars is not zero-knowledge. */
+tkmk_error tkmk_prover_prove(tkmk_prover *p, const char *synthesizer_dir, const char *output_dir, const char *testing_mixer_json,
+                             tkmk_prove_timing *timing, char **proof_json_out);
+tkmk_error tkmk_prover_close(tkmk_prover *p);
+void tkmk_prover_free_string(char *s);
+const char *tkmk_prover_last_error(void);   /* message of the last failed call on this thread */
+/* where the context's reference string came from: "combined_sigma.rkyv" or "combined_sigma.tkcrs" */
+const char *tkmk_prover_crs_source(const tkmk_prover *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -241,8 +241,12 @@ def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
         docs = json.load(open(pv_path))
         json.dump([{"variables": d["variables"], "note": "x", "subcircuitId": d["subcircuitId"], "k": 7} for d in docs], open(pv_path, "w"), indent=1)
     cmd = [binary, "--crs", crs_dir, "--synthesizer-stat", inst["synth"], "--output", out_dir, "--subcircuit-library", inst["qap"]]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TKMK_PROVE_MIXER=mixer_path))
+    r = subprocess.run(cmd + ["--testing-mixer", mixer_path], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
+    assert "NOT zero-knowledge" in r.stderr                       # the testing hook announces itself
+    # an inherited environment variable must not fix the blinding scalars (round-1 hook, removed): same command, fresh proof
+    r_env = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TKMK_PROVE_MIXER=mixer_path))
+    assert r_env.returncode == 0 and "NOT zero-knowledge" not in r_env.stderr
     native_points, native_scalars = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
 
     prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, sigma=sigma)

@@ -1,0 +1,218 @@
+"""gpu tier: the resident prover (libtkmk_prover.so, include/tkmk_prover.h, host/tkmk_service.hpp) and the MSM over views of
+resident tables (tkmk_msm_multi_ex) it is built on.
+
+  * tkmk_msm_multi_ex == bls12_381_msm on the gathered operands (oracle-checked), for strided boxes, index lists, all three
+    base forms, tiny sizes and the out-of-range refusal;
+  * the service's proof == the Python prover's (tkmk/prove.py) == the exponent restatement (tests/prove_ref.py), bit for bit, for
+    the same blinding scalars — i.e. the device-side init (CSR library, witness routing, table scatter) reproduces
+    Prover::init (packages/backend/prove/src/lib.rs:675-1206);
+  * the same from the reference's own CRS container, combined_sigma.rkyv (prove/src/sigma_source.rs:22-32), under every field
+    order the reader knows; preprocess from sigma_preprocess.rkyv (preprocess/src/main.rs:47-53)."""
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+# ------------------------------------------------------------------------------------------------ MSM over views
+def _aff(tkmk, proj):
+    return tkmk.projective_to_affine_bytes(proj)
+
+
+@pytest.mark.parametrize("form", ["plain", "montgomery", "converted"])
+def test_msm_multi_ex_strided_boxes(gpu, oracle, form):
+    """a tx x ty coefficient box of an xs x ys matrix against the matching sub-grid of a rows x cols table (encode_poly's shape)"""
+    tk = gpu
+    rows, cols = 40, 24                                             # the "CRS"
+    table = np.asarray(oracle.g1_random_bases(5, rows * cols))
+    table[96 * 7:96 * 8] = 0                                        # an infinity record inside the grid
+    xs, ys = 32, 16                                                 # the coefficient matrix
+    coeffs = np.asarray(oracle.fr_random(6, xs * ys))
+    coeffs[32 * 3:32 * 4] = 0
+    d_coeffs = tk.DeviceBuffer.from_host(coeffs)
+    if form == "montgomery":                                        # ICICLE's Montgomery form: x * 2^384 mod p, (0,0) stays infinity
+        mont = oracle.to_bytes([(x << 384) % oracle.P_MOD for x in oracle.to_ints(table, 48)], 48)
+        d_table = tk.DeviceBuffer.from_host(np.asarray(mont))
+        bf = tk.BASES_MONTGOMERY
+    elif form == "converted":
+        d_table = tk.msm_convert_bases(table)
+        bf = tk.BASES_CONVERTED
+    else:
+        d_table = tk.DeviceBuffer.from_host(table)
+        bf = tk.BASES_PLAIN
+    jobs, want = [], []
+    for tx, ty in ((32, 16), (17, 9), (1, 16), (5, 1), (2, 1), (1, 1)):
+        jobs.append(dict(scalars=d_coeffs, bases=d_table, n=tx * ty, scalar_view=(ty, ys), base_view=(ty, cols), table_len=rows * cols))
+        c = coeffs.reshape(xs, ys, 32)[:tx, :ty].reshape(-1)
+        b = table.reshape(rows, cols, 96)[:tx, :ty].reshape(-1)
+        want.append(np.asarray(oracle.g1_msm(np.ascontiguousarray(c), np.ascontiguousarray(b))))
+    got = _aff(tk, tk.msm_multi_ex(jobs, bases_form=bf))
+    for k, w in enumerate(want):
+        assert (got[96 * k:96 * (k + 1)] == w).all(), (form, k)
+    # a box that does not fit the table is refused before anything is launched
+    with pytest.raises(tk.TkmkError):
+        tk.msm_multi_ex([dict(scalars=d_coeffs, bases=d_table, n=rows * cols, scalar_view=None, base_view=(cols, cols + 1), table_len=rows * cols)], bases_form=bf)
+
+
+def test_msm_multi_ex_index_lists_and_sizes(gpu, oracle):
+    """gathered rows of a binding table (msm_g1_bases' shape): repeated rows, witness-like scalars, sizes across the sort variants"""
+    tk = gpu
+    rnd = np.random.default_rng(9)
+    table_pts = 5000
+    table = np.asarray(oracle.g1_random_bases(11, table_pts))
+    d_conv = tk.msm_convert_bases(table)
+    d_plain = tk.DeviceBuffer.from_host(table)
+    for n in (2, 3, 64, 1000, 70000, (1 << 18) + 5):
+        idx = rnd.integers(0, table_pts, n, dtype=np.uint32)
+        sc = np.asarray(oracle.fr_random(100 + n, n)).reshape(n, 32).copy()
+        sc[rnd.random(n) < 0.5] = 0
+        sc[rnd.random(n) < 0.3, 1:] = 0                              # small values
+        sc = sc.reshape(-1)
+        want = np.asarray(oracle.g1_msm(sc, np.ascontiguousarray(table.reshape(-1, 96)[idx].reshape(-1))))
+        d_sc, d_idx = tk.DeviceBuffer.from_host(sc), tk.DeviceBuffer.from_host(idx.view(np.uint8))
+        for bases, bf in ((d_conv, tk.BASES_CONVERTED), (d_plain, tk.BASES_PLAIN)):
+            got = _aff(tk, tk.msm_multi_ex([dict(scalars=d_sc, bases=bases, n=n, base_index=d_idx, table_len=table_pts)], bases_form=bf))
+            assert (got == want).all(), (n, bf)
+    # empty and one-point jobs next to a real one
+    sc = np.asarray(oracle.fr_random(3, 4))
+    d_sc = tk.DeviceBuffer.from_host(sc)
+    d_idx = tk.DeviceBuffer.from_host(np.array([4999, 0, 17, 17], np.uint32).view(np.uint8))
+    got = _aff(tk, tk.msm_multi_ex([dict(scalars=d_sc, bases=d_conv, n=0, table_len=table_pts),
+                                    dict(scalars=d_sc, bases=d_conv, n=1, base_index=d_idx, table_len=table_pts),
+                                    dict(scalars=d_sc, bases=d_conv, n=4, base_index=d_idx, table_len=table_pts)], bases_form=tk.BASES_CONVERTED))
+    rows = table.reshape(-1, 96)
+    assert not got[:96].any()
+    assert (got[96:192] == np.asarray(oracle.g1_msm(sc[:32], np.ascontiguousarray(rows[4999])))).all()
+    assert (got[192:] == np.asarray(oracle.g1_msm(sc, np.ascontiguousarray(rows[[4999, 0, 17, 17]].reshape(-1))))).all()
+    # an index past the table: an error, not a fault (the read is clamped on the device)
+    d_bad = tk.DeviceBuffer.from_host(np.array([1, table_pts, 2, 3], np.uint32).view(np.uint8))
+    with pytest.raises(tk.TkmkError):
+        tk.msm_multi_ex([dict(scalars=d_sc, bases=d_conv, n=4, base_index=d_bad, table_len=table_pts)], bases_form=tk.BASES_CONVERTED)
+
+
+# ------------------------------------------------------------------------------------------------ the resident prover
+def _mixer_file(tmp_path, mixer):
+    hx = lambda v: [hx(e) for e in v] if isinstance(v, list) else "0x%x" % v          # noqa: E731
+    path = str(tmp_path / "mixer.json")
+    json.dump({k: hx(v) for k, v in mixer.items()}, open(path, "w"))
+    return path
+
+
+SHAPES = [(51, dict(s_max=8, n_gate_kinds=2)),
+          (52, dict(s_max=8, n_gate_kinds=3, n_out=1, n_in=2, n_prv=11, used_placements=6, bit_fraction=0.6)),
+          (53, dict(s_max=16, n_gate_kinds=2, n_out=2, n_in=3, n_prv=9, used_placements=11, k_out=0, k_pub=3)),
+          (54, dict(s_max=8, n_gate_kinds=2, n_out=1, n_in=2, n_prv=1, k_out=0, k_pub=2, l_extra=1, used_placements=7))]
+
+
+@pytest.mark.parametrize("seed,shape", SHAPES)
+def test_service_equals_python_prover_and_restatement(gpu, oracle, tmp_path, seed, shape):
+    import prove_ref
+    import synth_circuit
+    from test_gpu_prove import _stage_crs_file, seeded_mixer
+    from tkmk import proofio, service
+    from tkmk.prove import Prover, run_rounds
+    inst = synth_circuit.build(str(tmp_path), random.Random(seed), **shape)
+    crs_dir, out_dir = str(tmp_path / "crs"), str(tmp_path / "out")
+    sigma, crs, g = _stage_crs_file(gpu, oracle, inst, crs_dir)
+    mixer = seeded_mixer(seed)
+    mixer_path = _mixer_file(tmp_path, mixer)
+    prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, sigma=sigma)
+    points, scalars, _, _, _ = run_rounds(prover, binding)
+    want_doc = proofio.format_proof(points, scalars)
+    with service.Prover(inst["qap"], crs_dir) as p:
+        assert p.crs_source == "combined_sigma.tkcrs"
+        for rep in range(2):                                          # the context is reusable: same inputs, same proof
+            doc, tm = p.prove(inst["synth"], out_dir, testing_mixer_json=mixer_path)
+            assert doc == want_doc
+            assert json.load(open(os.path.join(out_dir, "proof.json"))) == want_doc
+            assert tm["init_s"] > 0 and tm["rounds_s"] > 0 and abs(tm["total_s"] - (tm["init_s"] + tm["rounds_s"] + tm["write_s"])) < 0.05
+        fresh, _ = p.prove(inst["synth"], None)                       # production path: blinding from getrandom()
+        fp, _ = proofio.recover_proof(fresh)
+        assert (np.asarray(fp["A_free"]) == np.asarray(points["A_free"])).all() and not (np.asarray(fp["U"]) == np.asarray(points["U"])).all()
+        # a corrupted witness document is an error of that call; the context stays usable
+        pv = os.path.join(inst["synth"], "placementVariables.json")
+        good = open(pv).read()
+        open(pv, "w").write(good[:len(good) // 2])
+        with pytest.raises(service.ProverError) as e:
+            p.prove(inst["synth"], None)
+        assert "placementVariables.json" in str(e.value) or "Corrupted placement variables" in str(e.value)
+        open(pv, "w").write(good)
+        doc, _ = p.prove(inst["synth"], None, testing_mixer_json=mixer_path)
+        assert doc == want_doc
+    dlogs, ref_scalars, _, _, _ = prove_ref.run(inst, crs, mixer, g)
+    native_points, native_scalars = proofio.recover_proof(want_doc)
+    assert native_scalars == ref_scalars
+    for name in proofio.PROOF_POINT_ORDER:
+        assert (np.asarray(native_points[name]) == np.asarray(prove_ref.g1_of(dlogs[name], g))).all(), name
+
+
+@pytest.mark.parametrize("order", ["rustc_size_groups", "rustc_align_only", "declared"])
+def test_prove_and_preprocess_from_the_reference_archives(gpu, oracle, tmp_path, order):
+    """<crs>/combined_sigma.rkyv and <crs>/sigma_preprocess.rkyv instead of the flat payload: same proof.json / preprocess.json"""
+    import synth_circuit
+    from test_gpu_prove import _stage_crs_file, seeded_mixer
+    from tkmk import crs as crsmod
+    from tkmk import rkyv, service
+    inst = synth_circuit.build(str(tmp_path), random.Random(61), s_max=8, n_gate_kinds=2, used_placements=7)
+    sp = inst["setup_params"]
+    flat_dir, arch_dir, out_dir = str(tmp_path / "crs"), str(tmp_path / "crs_rkyv"), str(tmp_path / "out")
+    _stage_crs_file(gpu, oracle, inst, flat_dir)
+    sections = crsmod.read_payload(os.path.join(flat_dir, "combined_sigma.tkcrs"))
+    os.makedirs(arch_dir)
+    open(os.path.join(arch_dir, "combined_sigma.rkyv"), "wb").write(rkyv.encode_combined_sigma(sections, rkyv.rows_for(sp), order))
+    open(os.path.join(arch_dir, "sigma_preprocess.rkyv"), "wb").write(rkyv.encode_sigma_preprocess(sections["xy_powers"], sections["gamma_inv_o_inst"]))
+    mixer_path = _mixer_file(tmp_path, seeded_mixer(61))
+    with service.Prover(inst["qap"], flat_dir) as p:
+        want, _ = p.prove(inst["synth"], None, testing_mixer_json=mixer_path)
+    with service.Prover(inst["qap"], arch_dir) as p:
+        assert p.crs_source == "combined_sigma.rkyv"
+        got, _ = p.prove(inst["synth"], None, testing_mixer_json=mixer_path)
+    assert got == want
+    # the binaries on the archive directory
+    os.makedirs(out_dir)
+    bins = os.path.join(ROOT, "tokamak-zk-evm_amd", "bin")
+    args = ["--crs", arch_dir, "--synthesizer-stat", inst["synth"], "--output", out_dir, "--subcircuit-library", inst["qap"]]
+    r = subprocess.run([os.path.join(bins, "prove")] + args + ["--testing-mixer", mixer_path], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "combined_sigma.rkyv" in r.stdout and json.load(open(os.path.join(out_dir, "proof.json"))) == want
+    r = subprocess.run([os.path.join(bins, "preprocess")] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    pre_arch = json.load(open(os.path.join(out_dir, "preprocess.json")))
+    r = subprocess.run([os.path.join(bins, "preprocess")] + ["--crs", flat_dir] + args[2:], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert json.load(open(os.path.join(out_dir, "preprocess.json"))) == pre_arch
+    # an archive of another circuit is refused with the reason
+    open(os.path.join(arch_dir, "combined_sigma.rkyv"), "wb").write(rkyv.encode_combined_sigma(sections, rkyv.rows_for(sp), order)[:-16])
+    with pytest.raises(service.ProverError) as e:
+        service.Prover(inst["qap"], arch_dir)
+    assert "Invalid sigma archive" in str(e.value)
+
+
+def test_native_setup_writes_archives_the_prover_reads(gpu, tmp_path):
+    """bin/trusted-setup --fixed-tau writes combined_sigma.rkyv, sigma_preprocess.rkyv and combined_sigma.tkcrs; the three hold the
+    same sections, and the service proves from either container"""
+    import synth_circuit
+    from tkmk import crs as crsmod
+    from tkmk import rkyv
+    inst = synth_circuit.build(str(tmp_path), random.Random(71), s_max=8, n_gate_kinds=2, used_placements=6)
+    out = str(tmp_path / "crs")
+    os.makedirs(out)
+    r = subprocess.run([os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "trusted-setup"), "--subcircuit-library", inst["qap"], "--output", out, "--fixed-tau"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    flat = crsmod.read_payload(os.path.join(out, "combined_sigma.tkcrs"))
+    arch, rows, order = rkyv.decode_combined_sigma(open(os.path.join(out, "combined_sigma.rkyv"), "rb").read(), expect=rkyv.expect_for(inst["setup_params"]),
+                                                   want_details=True)
+    assert order == "rustc_size_groups" and rows == rkyv.rows_for(inst["setup_params"])
+    for name in crsmod.SECTION_NAMES:
+        assert bytes(arch[name]) == bytes(flat[name]), name
+    pre = rkyv.decode_sigma_preprocess(open(os.path.join(out, "sigma_preprocess.rkyv"), "rb").read())
+    assert bytes(pre["xy_powers"]) == bytes(flat["xy_powers"]) and bytes(pre["gamma_inv_o_inst"]) == bytes(flat["gamma_inv_o_inst"])

@@ -22,4 +22,7 @@
 #define TK_MSM_SYM_MSM bls12_381_msm
 #define TK_MSM_SYM_MULTI tkmk_msm_multi
 #define TK_MSM_SYM_PRECOMPUTE bls12_381_msm_precompute_bases
+#define TK_MSM_ABI_JOB_EX tkmk_msm_job_ex
+#define TK_MSM_SYM_MULTI_EX tkmk_msm_multi_ex
+#define TK_MSM_SYM_CONVERT bls12_381_msm_convert_bases
 #include "msm_impl.inc"

@@ -1,44 +1,16 @@
 // preprocess_main.cpp — native `preprocess` with the reference binary's argument surface (packages/backend/preprocess/src/main.rs:12-63):
 //   preprocess --crs DIR --synthesizer-stat DIR --output DIR --subcircuit-library DIR
-// reads <lib>/setupParams.json, <synth>/permutation.json, <synth>/instance.json, <crs>/combined_sigma.tkcrs (the flat TKCRS001 payload
-// the reference derives from its rkyv archive; the archive itself is not parsed), writes <out>/preprocess.json.  Exit code 0 on
-// success; any failure prints the reason and exits non-zero (the reference panics).  Needs an MI355X: no CPU fallback.
+// reads <lib>/setupParams.json, <synth>/permutation.json, <synth>/instance.json and the reference string <crs>/sigma_preprocess.rkyv
+// (the reference's archive: preprocess/src/main.rs:47-53; host/tkmk_rkyv.hpp) — or <crs>/combined_sigma.tkcrs / combined_sigma.rkyv
+// when that is what the directory holds; writes <out>/preprocess.json.  Exit code 0 on success; any failure prints the reason
+// and exits non-zero (the reference panics).  Needs an MI355X: no CPU fallback.
 #include <cstdio>
 #include <cstring>
 #include <string>
 
-#include "tkmk_json.hpp"
-#include "tkmk_protocol.hpp"
+#include "tkmk_crs_load.hpp"
 
 using namespace tkmk;
-
-// ScalarField::from_hex on a HexString (libs/src/iotools/mod.rs:126-146): optional 0x, big-endian digits, reduced mod r
-static ScalarField fr_from_hex(const std::string &h) {
-    size_t off = h.rfind("0x", 0) == 0 || h.rfind("0X", 0) == 0 ? 2 : 0;
-    std::string d = h.substr(off);
-    if (d.size() > 64) throw Error("hex scalar longer than 32 bytes");
-    if (d.size() % 2) d = "0" + d;
-    uint8_t le[32] = {};
-    size_t nb = d.size() / 2;
-    for (size_t i = 0; i < nb; i++) le[nb - 1 - i] = (uint8_t)std::stoi(d.substr(2 * i, 2), nullptr, 16);
-    static const uint32_t R[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
-    ScalarField v{};
-    std::memcpy(&v, le, 32);
-    auto geq = [&]() {
-        for (int i = 7; i >= 0; i--)
-            if (v.limbs[i] != R[i]) return v.limbs[i] > R[i];
-        return true;
-    };
-    while (geq()) {
-        uint64_t br = 0;
-        for (int i = 0; i < 8; i++) {
-            uint64_t t = (uint64_t)v.limbs[i] - R[i] - br;
-            v.limbs[i] = (uint32_t)t;
-            br = (t >> 63) & 1;
-        }
-    }
-    return v;
-}
 
 int main(int argc, char **argv) {
     std::string crs_dir, synth_dir, out_dir, lib_dir;
@@ -65,10 +37,26 @@ int main(int argc, char **argv) {
         SetupParams sp{jp.at("l").as_size(),   jp.at("l_user_out").as_size(), jp.at("l_user").as_size(), jp.at("l_free").as_size(),
                        jp.at("l_D").as_size(), jp.at("m_D").as_size(),        jp.at("n").as_size(),      jp.at("s_D").as_size(),
                        jp.at("s_max").as_size()};
-        CrsPayload crs = CrsPayload::read(crs_dir + "/combined_sigma.tkcrs");
+        // the reference reads <crs>/sigma_preprocess.rkyv (preprocess/src/main.rs:47-53: xy_powers + gamma_inv_o_inst only); the flat
+        // payload or the combined archive serve as well when that is what the directory holds
         size_t m_i = sp.l_D - sp.l, rs_x = std::max(2 * sp.n, 2 * m_i), rs_y = 2 * sp.s_max;
-        if (crs.points(CrsPayload::XyPowers) != rs_x * rs_y || crs.points(CrsPayload::GammaInvOInst) != sp.l)
-            throw Error("CRS sections do not match setupParams.json");
+        const G1Affine *xy_host = nullptr, *gamma_host = nullptr;
+        size_t xy_points = 0, gamma_points = 0;
+        CrsPayload crs;
+        std::shared_ptr<void> keep;
+        const std::string pre_archive = crs_dir + "/sigma_preprocess.rkyv";
+        if (!file_exists(crs_dir + "/combined_sigma.tkcrs") && file_exists(pre_archive)) {
+            auto m = map_file(pre_archive);
+            keep = m.second;
+            rkyv::PreprocessSigma ps = rkyv::decode_sigma_preprocess(m.first.data(), m.first.size());
+            xy_host = reinterpret_cast<const G1Affine *>(ps.xy_powers), xy_points = ps.xy_points;
+            gamma_host = reinterpret_cast<const G1Affine *>(ps.gamma_inv_o_inst), gamma_points = ps.gamma_points;
+        } else {
+            crs = load_combined_sigma(crs_dir, sp);
+            xy_host = crs.g1(CrsPayload::XyPowers), xy_points = crs.points(CrsPayload::XyPowers);
+            gamma_host = crs.g1(CrsPayload::GammaInvOInst), gamma_points = crs.points(CrsPayload::GammaInvOInst);
+        }
+        if (xy_points != rs_x * rs_y || gamma_points != sp.l) throw Error("CRS sections do not match setupParams.json");
         std::vector<Permutation> perm;
         const json::Value jperm = json::read_file(synth_dir + "/permutation.json");   // named: items() refers into it
         for (const json::Value &e : jperm.items())
@@ -76,8 +64,8 @@ int main(int argc, char **argv) {
         std::vector<ScalarField> a_fn;
         const json::Value jinst = json::read_file(synth_dir + "/instance.json");
         for (const json::Value &e : jinst.at("a_pub_function").items()) a_fn.push_back(fr_from_hex(e.as_string()));
-        Sigma1 sigma(crs.upload(CrsPayload::XyPowers), rs_x, rs_y);
-        DeviceVec<G1Affine> gamma = crs.upload(CrsPayload::GammaInvOInst);
+        Sigma1 sigma(DeviceVec<G1Affine>::from_host(xy_host, xy_points), rs_x, rs_y);
+        DeviceVec<G1Affine> gamma = DeviceVec<G1Affine>::from_host(gamma_host, gamma_points);
         Preprocess pre = Preprocess::gen(sigma, gamma, perm, a_fn, sp);
         std::string path = out_dir + "/preprocess.json";
         std::ofstream f(path);

@@ -1,0 +1,75 @@
+// prover_abi.cpp — libtkmk_prover.so: the C ABI of include/tkmk_prover.h over host/tkmk_service.hpp (ProverContext).
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/tkmk_prover.h"
+#include "tkmk_crs_load.hpp"
+#include "tkmk_service.hpp"
+
+using namespace tkmk;
+
+struct tkmk_prover {
+    std::unique_ptr<ProverContext> ctx;
+};
+
+static thread_local std::string g_last_error;
+
+template <class F>
+static tkmk_error guarded(F &&fn) {
+    try {
+        fn();
+        return TKMK_SUCCESS;
+    } catch (const Error &e) {
+        g_last_error = e.what();
+        return e.code == TKMK_SUCCESS ? TKMK_ERR_UNKNOWN : e.code;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return TKMK_ERR_INVALID_ARGUMENT;
+    }
+}
+
+#define TKP_API extern "C" __attribute__((visibility("default")))
+
+TKP_API tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const char *crs_dir, tkmk_prover **out) {
+    if (!subcircuit_library_dir || !crs_dir || !out) return TKMK_ERR_INVALID_POINTER;
+    return guarded([&] {
+        int ndev = 0;
+        if (tkmk_device_count(&ndev) != TKMK_SUCCESS || ndev < 1) throw Error(TKMK_ERR_NO_DEVICE, "tkmk_prover_open: no HIP device (the MI355X backend has no CPU fallback)");
+        std::string crs = crs_dir;
+        std::unique_ptr<tkmk_prover> p(new tkmk_prover());
+        p->ctx = ProverContext::open(subcircuit_library_dir, crs, [&](const SetupParams &sp, std::string &source) { return load_prover_sigma(crs, sp, source); });
+        *out = p.release();
+    });
+}
+
+TKP_API tkmk_error tkmk_prover_prove(tkmk_prover *p, const char *synthesizer_dir, const char *output_dir, const char *testing_mixer_json,
+                                     tkmk_prove_timing *timing, char **proof_json_out) {
+    if (!p || !synthesizer_dir) return TKMK_ERR_INVALID_POINTER;
+    if (proof_json_out) *proof_json_out = nullptr;
+    return guarded([&] {
+        Mixer mixer = testing_mixer_json ? mixer_from_json(json::read_file(testing_mixer_json)) : Mixer::random();
+        ProveTiming tm;
+        Proof proof = p->ctx->prove(synthesizer_dir, output_dir ? output_dir : "", mixer, &tm);
+        if (timing) {
+            timing->parse_s = tm.parse, timing->upload_s = tm.upload, timing->build_s = tm.build, timing->binding_s = tm.binding;
+            timing->init_s = tm.init, timing->write_s = tm.write, timing->total_s = tm.total;
+            for (int k = 0; k < 5; k++) timing->prove_s[k] = tm.prove[k];
+        }
+        if (proof_json_out) {
+            std::string doc = proof.to_json();
+            char *s = (char *)std::malloc(doc.size() + 1);
+            if (!s) throw Error("out of memory");
+            std::memcpy(s, doc.c_str(), doc.size() + 1);
+            *proof_json_out = s;
+        }
+    });
+}
+
+TKP_API tkmk_error tkmk_prover_close(tkmk_prover *p) {
+    if (!p) return TKMK_SUCCESS;
+    return guarded([&] { delete p; });
+}
+TKP_API void tkmk_prover_free_string(char *s) { std::free(s); }
+TKP_API const char *tkmk_prover_last_error(void) { return g_last_error.c_str(); }
+TKP_API const char *tkmk_prover_crs_source(const tkmk_prover *p) { return p ? p->ctx->crs_source.c_str() : ""; }

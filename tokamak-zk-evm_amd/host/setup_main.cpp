@@ -1,7 +1,10 @@
 // setup_main.cpp — native trusted setup with the reference binary's argument surface (packages/backend/setup/trusted-setup/src/main.rs:27-46):
-//   trusted-setup --subcircuit-library DIR --output DIR [--fixed-tau]
-// reads <lib>/setupParams.json, <lib>/subcircuitInfo.json, <lib>/r1cs/subcircuit{id}.r1cs; writes <out>/combined_sigma.tkcrs (the flat TKCRS001
-// payload the reference derives from its rkyv archive: tkmk/crs.py).  --fixed-tau uses the hardcoded testing generators and tau of the
+//   trusted-setup --subcircuit-library DIR --output DIR [--fixed-tau] [--format both|rkyv|tkcrs]
+// reads <lib>/setupParams.json, <lib>/subcircuitInfo.json, <lib>/r1cs/subcircuit{id}.r1cs; writes the reference's containers
+// <out>/combined_sigma.rkyv and <out>/sigma_preprocess.rkyv (write_final_crs_artifacts, libs/src/iotools/mod.rs:271-300; host/tkmk_rkyv.hpp)
+// and <out>/combined_sigma.tkcrs (the flat TKCRS001 payload the reference derives from its archive: tkmk/crs.py — the fast path of
+// `prove`).  --format picks one; a reference string past 2 GiB does not fit an rkyv archive (32-bit relative pointers) and is written
+// as .tkcrs only.  --fixed-tau uses the hardcoded testing generators and tau of the
 // reference (main.rs:68-80, libs/src/field_structures/mod.rs:43-64); otherwise tau is drawn from std::random_device and the generators are
 // random multiples of the standard ones.  Needs an MI355X: no CPU fallback.
 #include <chrono>
@@ -46,9 +49,11 @@ static G1Affine g1_from_hex(const std::string &x, const std::string &y) {
 int main(int argc, char **argv) {
     std::string out_dir, lib_dir;
     bool fixed_tau = false;
+    std::string format = "both";
     for (int i = 1; i < argc; i++) {
         std::string k = argv[i];
         if (k == "--fixed-tau") fixed_tau = true;
+        else if (k == "--format" && i + 1 < argc) format = argv[++i];
         else if (k == "--output" && i + 1 < argc) out_dir = argv[++i];
         else if (k == "--subcircuit-library" && i + 1 < argc) lib_dir = argv[++i];
         else {
@@ -56,8 +61,8 @@ int main(int argc, char **argv) {
             return 2;
         }
     }
-    if (out_dir.empty() || lib_dir.empty()) {
-        fprintf(stderr, "usage: trusted-setup --subcircuit-library DIR --output DIR [--fixed-tau]\n");
+    if (out_dir.empty() || lib_dir.empty() || (format != "both" && format != "rkyv" && format != "tkcrs")) {
+        fprintf(stderr, "usage: trusted-setup --subcircuit-library DIR --output DIR [--fixed-tau] [--format both|rkyv|tkcrs]\n");
         return 2;
     }
     try {
@@ -117,8 +122,20 @@ int main(int argc, char **argv) {
         Sigma sigma = Sigma::gen(sp, tau, lib_dir, infos, n_consts, g1, &h2);
         check(tkmk_device_synchronize(), "synchronize");
         double t1 = Prover_now();
-        std::string path = sigma.write(out_dir);
-        printf("The sigma generation time: %.6f seconds\ncombined_sigma.tkcrs written to %s (%.3f s)\n", t1 - t0, path.c_str(), Prover_now() - t0);
+        printf("The sigma generation time: %.6f seconds\n", t1 - t0);
+        bool fits = sigma.archive_bytes() < (1ull << 31);
+        if (format == "rkyv" && !fits) throw Error("this reference string does not fit an rkyv archive (32-bit relative pointers); use --format tkcrs");
+        if (format != "tkcrs" && fits) {
+            sigma.write_rkyv(out_dir, sp);
+            printf("combined_sigma.rkyv and sigma_preprocess.rkyv written to %s\n", out_dir.c_str());
+        } else if (format == "both") {
+            printf("reference string past 2 GiB: no rkyv archive (32-bit relative pointers), .tkcrs payload only\n");
+        }
+        if (format != "rkyv") {
+            std::string path = sigma.write(out_dir);
+            printf("combined_sigma.tkcrs written to %s\n", path.c_str());
+        }
+        printf("Total: %.3f s\n", Prover_now() - t0);
     } catch (const std::exception &ex) {
         fprintf(stderr, "trusted-setup: %s\n", ex.what());
         return 1;

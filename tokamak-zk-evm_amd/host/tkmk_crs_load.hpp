@@ -1,0 +1,54 @@
+// tkmk_crs_load.hpp — where `prove` / `preprocess` get the reference string from: <crs>/combined_sigma.rkyv resp.
+// <crs>/sigma_preprocess.rkyv, the reference's own archives (prove/src/sigma_source.rs:22-32, preprocess/src/main.rs:47-53), through
+// tkmk_rkyv.hpp; or, when present, the flat TKCRS001 payload <crs>/combined_sigma.tkcrs (the form the reference's decoder derives
+// from the archive: backend-wasm/tools/rkyv-decoder-wasm/src/lib.rs:118-140) as a fast path that needs no validation pass.
+#pragma once
+#include "tkmk_prover.hpp"
+#include "tkmk_rkyv.hpp"
+
+namespace tkmk {
+
+inline bool file_exists(const std::string &path) {
+    struct stat st;
+    return ::stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+// read-only mapping of a file -> (view, owner)
+inline std::pair<CrsPayload::View, std::shared_ptr<void>> map_file(const std::string &path) {
+    int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Error("cannot open " + path);
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || st.st_size <= 0) {
+        ::close(fd);
+        throw Error("cannot stat " + path);
+    }
+    size_t n = (size_t)st.st_size;
+    void *m = ::mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) throw Error("cannot map " + path);
+    return {CrsPayload::View{static_cast<const uint8_t *>(m), n}, std::shared_ptr<void>(m, [n](void *q) { ::munmap(q, n); })};
+}
+inline rkyv::Expect expect_for(const SetupParams &sp) {
+    size_t m_i = sp.l_D - sp.l;
+    rkyv::Expect ex;
+    ex.rs_y = 2 * sp.s_max;
+    ex.xy_powers = std::max(2 * sp.n, 2 * m_i) * ex.rs_y;
+    ex.gamma = sp.l, ex.eta = m_i * sp.s_max, ex.delta = (sp.m_D - sp.l_D) * sp.s_max;
+    return ex;
+}
+// the nine sections of the combined reference string, whichever container holds it
+inline CrsPayload load_combined_sigma(const std::string &crs_dir, const SetupParams &sp) {
+    const std::string flat = crs_dir + "/combined_sigma.tkcrs", archive = crs_dir + "/combined_sigma.rkyv";
+    if (file_exists(flat)) return CrsPayload::read(flat);
+    if (file_exists(archive)) {
+        auto m = map_file(archive);
+        return rkyv::decode_combined_sigma(m.first, m.second, expect_for(sp));
+    }
+    throw Error("No reference string is found. Run the Setup first (expected " + archive + ").");
+}
+inline std::unique_ptr<ProverSigma> load_prover_sigma(const std::string &crs_dir, const SetupParams &sp, std::string &source) {
+    CrsPayload crs = load_combined_sigma(crs_dir, sp);
+    source = crs.container;
+    return std::unique_ptr<ProverSigma>(new ProverSigma(ProverSigma::from_payload(crs, sp)));
+}
+
+}  // namespace tkmk

@@ -534,31 +534,39 @@ class PolyExpr {
 };
 
 // ---- Sigma1 with a device-resident xy_powers table: encode_poly (iotools/mod.rs:2033-2113) ----
+// The table is kept in the MSM's resident ("converted") form from construction on: the CRS is fixed for its lifetime, so the
+// per-call base conversion of bls12_381_msm is paid once here; and a commit reads the coefficient box and the matching CRS
+// sub-grid through strided VIEWS (tkmk_msm_multi_ex), where the reference copies both, point by point, before every MSM
+// (iotools/mod.rs:2061-2088).
 class Sigma1 {
     DeviceVec<G1Affine> xy_powers_;
     size_t rs_x_, rs_y_;
 
   public:
-    // xy_powers[i*rs_y + j] = [tau_x^i tau_y^j]G;  rs_x = max(2n, 2(l_D - l)), rs_y = 2 s_max
+    // xy_powers[i*rs_y + j] = [tau_x^i tau_y^j]G (plain affine records);  rs_x = max(2n, 2(l_D - l)), rs_y = 2 s_max
     Sigma1(DeviceVec<G1Affine> &&xy_powers, size_t rs_x_size, size_t rs_y_size) : xy_powers_(std::move(xy_powers)), rs_x_(rs_x_size), rs_y_(rs_y_size) {
         if (xy_powers_.len() != rs_x_ * rs_y_) throw Error("xy_powers has the wrong length");
+        tkmk_msm_config cfg = tkmk_msm_default_config();
+        cfg.are_points_on_device = cfg.are_results_on_device = true;
+        check(bls12_381_msm_convert_bases(xy_powers_.ptr(), xy_powers_.len(), &cfg, xy_powers_.ptr()), "msm::convert_bases");
     }
-  private:
-    struct Gathered {
-        DeviceVec<ScalarField> scalars;
-        DeviceVec<G1Affine> bases;
-        size_t n;
-    };
-    // compact coefficient box + matching CRS rows of one commit (empty for the zero polynomial)
-    std::unique_ptr<Gathered> gather(DensePolynomialExt &poly) const {
+    const DeviceVec<G1Affine> &converted_table() const { return xy_powers_; }
+    size_t rs_x() const { return rs_x_; }
+    size_t rs_y() const { return rs_y_; }
+    // the MSM job of one commit: coefficient box x CRS sub-grid, both as views (msm_size 0 for the zero polynomial)
+    tkmk_msm_job_ex job(DensePolynomialExt &poly) const {
         poly.optimize_size();
         size_t tx = (size_t)(poly.x_degree + 1), ty = (size_t)(poly.y_degree + 1);
         if (tx > rs_x_ || ty > rs_y_) throw Error("Insufficient length of sigma.sigma_1.xy_powers");
-        if (tx * ty == 0) return nullptr;
-        std::unique_ptr<Gathered> g(new Gathered{DeviceVec<ScalarField>(tx * ty), DeviceVec<G1Affine>(tx * ty), tx * ty});
-        check(tkmk_memcpy_2d_d2d(g->scalars.ptr(), 32 * ty, poly.poly.ptr(), 32 * poly.y_size, 32 * ty, tx), "encode_poly gather");
-        check(tkmk_memcpy_2d_d2d(g->bases.ptr(), 96 * ty, xy_powers_.ptr(), 96 * rs_y_, 96 * ty, tx), "encode_poly gather");
-        return g;
+        tkmk_msm_job_ex j{};
+        j.scalars = poly.poly.ptr();
+        j.bases = xy_powers_.ptr();
+        j.msm_size = (int)(tx * ty);
+        j.scalar_cols = (uint32_t)ty, j.scalar_stride = (uint32_t)poly.y_size;
+        j.base_cols = (uint32_t)ty, j.base_stride = (uint32_t)rs_y_;
+        j.base_index = nullptr;
+        j.base_table_len = xy_powers_.len();
+        return j;
     }
     static G1Affine to_affine(const tkmk_g1_projective &res) {
         G1Affine out{};
@@ -567,34 +575,27 @@ class Sigma1 {
         if (!inf) out.x = res.x, out.y = res.y;  // canonical (x, y, 1): dropping z is G1Affine::from(projective)
         return out;
     }
-
-  public:
-    // -> affine commitment; (0,0) = G1serde::zero()
-    G1Affine encode_poly(DensePolynomialExt &poly) const {
-        auto g = gather(poly);
-        if (!g) return G1Affine{};
+    static tkmk_msm_config device_cfg() {
         tkmk_msm_config cfg = tkmk_msm_default_config();
         cfg.are_scalars_on_device = cfg.are_points_on_device = true;
-        tkmk_g1_projective res;
-        check(bls12_381_msm(g->scalars.ptr(), g->bases.ptr(), (int)g->n, &cfg, &res), "msm::msm");
-        return to_affine(res);
+        return cfg;
     }
-    // commitments of independent polynomials in one pipelined call (tkmk_msm_multi)
-    std::vector<G1Affine> encode_polys(const std::vector<DensePolynomialExt *> &polys) const {
-        std::vector<std::unique_ptr<Gathered>> g;
-        std::vector<tkmk_msm_job> jobs;
-        for (DensePolynomialExt *p : polys) {
-            g.push_back(gather(*p));
-            if (g.back()) jobs.push_back({g.back()->scalars.ptr(), g.back()->bases.ptr(), (int)g.back()->n});
-        }
-        tkmk_msm_config cfg = tkmk_msm_default_config();
-        cfg.are_scalars_on_device = cfg.are_points_on_device = true;
+    // independent MSM jobs over converted tables in one pipelined call -> affine results; (0,0) = G1serde::zero()
+    static std::vector<G1Affine> run_jobs(const std::vector<tkmk_msm_job_ex> &jobs) {
+        tkmk_msm_config cfg = device_cfg();
         std::vector<tkmk_g1_projective> res(jobs.size());
-        check(tkmk_msm_multi(jobs.data(), (int)jobs.size(), &cfg, res.data()), "tkmk_msm_multi");
+        check(tkmk_msm_multi_ex(jobs.data(), (int)jobs.size(), &cfg, TKMK_BASES_CONVERTED, res.data()), "tkmk_msm_multi_ex");
         std::vector<G1Affine> out;
-        size_t k = 0;
-        for (auto &gi : g) out.push_back(gi ? to_affine(res[k++]) : G1Affine{});
+        for (auto &r : res) out.push_back(to_affine(r));
         return out;
+    }
+    // -> affine commitment
+    G1Affine encode_poly(DensePolynomialExt &poly) const { return run_jobs({job(poly)})[0]; }
+    // commitments of independent polynomials in one pipelined call
+    std::vector<G1Affine> encode_polys(const std::vector<DensePolynomialExt *> &polys) const {
+        std::vector<tkmk_msm_job_ex> jobs;
+        for (DensePolynomialExt *p : polys) jobs.push_back(job(*p));
+        return run_jobs(jobs);
     }
 };
 

@@ -247,7 +247,10 @@ struct CrsPayload {
     };
     View data;
     std::shared_ptr<void> keep;   // owns the buffer or the mapping
-    size_t offset[Count]{}, length[Count]{};
+    std::vector<std::shared_ptr<void>> keep_more;   // sections that had to be assembled (rkyv archives: the single points)
+    const uint8_t *section[Count]{};                // start of every section's records
+    size_t length[Count]{};
+    const char *container = "combined_sigma.tkcrs";
 
     static CrsPayload parse(std::vector<uint8_t> bytes) {
         auto owned = std::make_shared<std::vector<uint8_t>>(std::move(bytes));
@@ -274,7 +277,7 @@ struct CrsPayload {
         if (total != d.size()) throw Error("section lengths do not add up to the payload size");
         for (int i = 0; i < Count; i++) {
             if (c.length[i] % (i == G2Points ? 192 : 96)) throw Error("section is not a whole number of points");
-            c.offset[i] = off;
+            c.section[i] = d.data() + off;
             off += c.length[i];
         }
         if (c.length[G1Singles] != 6 * 96 || c.length[G2Points] != 10 * 192) throw Error("unexpected size of the single-point sections");
@@ -298,7 +301,8 @@ struct CrsPayload {
         return c;
     }
     size_t points(Section s) const { return length[s] / 96; }
-    const G1Affine *g1(Section s) const { return reinterpret_cast<const G1Affine *>(data.data() + offset[s]); }
+    const G1Affine *g1(Section s) const { return reinterpret_cast<const G1Affine *>(section[s]); }
+    const uint8_t *bytes(Section s) const { return section[s]; }
     DeviceVec<G1Affine> upload(Section s) const { return DeviceVec<G1Affine>::from_host(g1(s), points(s)); }
 };
 

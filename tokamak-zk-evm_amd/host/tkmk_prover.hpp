@@ -11,9 +11,12 @@
 #include <initializer_list>
 #include <map>
 #include <memory>
-#include <random>
+#include <sys/random.h>
+
+#include <cerrno>
 
 #include "tkmk_fr.hpp"
+#include "tkmk_json.hpp"
 #include "tkmk_protocol.hpp"
 #include "tkmk_witness.hpp"
 
@@ -24,16 +27,28 @@ struct Mixer {   // lib.rs:251-263
     std::array<ScalarField, 4> rW_X, rW_Y;   // 3 random values resized to 4 with a zero (lib.rs:1045-1060)
     std::array<ScalarField, 2> rB_X, rB_Y;
     ScalarField rR_X, rR_Y, rO_mid;
-    static Mixer random() {
-        std::random_device rd;
-        auto draw = [&]() {
+    // ScalarCfg::generate_random (lib.rs:1040-1080): uniform below r — 255 bits from the kernel's CSPRNG (getrandom), redrawn
+    // until the value is below r (rejection sampling: no modular bias; r is 0.906 of 2^255, so 1.1 draws on average)
+    static ScalarField random_scalar() {
+        for (;;) {
             uint8_t b[32];
-            for (int i = 0; i < 32; i += 4) {
-                uint32_t w = rd();
-                std::memcpy(b + i, &w, 4);
+            size_t got = 0;
+            while (got < sizeof b) {
+                ssize_t k = ::getrandom(b + got, sizeof b - got, 0);
+                if (k < 0) {
+                    if (errno == EINTR) continue;
+                    throw Error("getrandom failed: no entropy source for the blinding scalars");
+                }
+                got += (size_t)k;
             }
-            return fr_from_le_bytes_mod_r(b, 32);
-        };
+            b[31] &= 0x7f;
+            frh::U256 v;
+            std::memcpy(v.l, b, 32);
+            if (!frh::geq(v, frh::MOD)) return frh::store(v);
+        }
+    }
+    static Mixer random() {
+        auto draw = [] { return random_scalar(); };
         Mixer m;
         m.rU_X = draw(), m.rU_Y = draw(), m.rV_X = draw(), m.rV_Y = draw();
         m.rW_X = {draw(), draw(), draw(), ScalarField{}};
@@ -44,6 +59,22 @@ struct Mixer {   // lib.rs:251-263
         return m;
     }
 };
+// testing hook (not in the reference): blinding scalars from a JSON document {"rU_X": "0x..", ..., "rW_X": [4 values], "rB_X": [2 values], ...}
+// so that two implementations can be compared byte for byte.  Never used unless the caller asks for it explicitly
+// (bin/prove --testing-mixer FILE, tkmk_prover_prove's testing_mixer_json argument).
+inline Mixer mixer_from_json(const json::Value &j) {
+    auto one = [&](const char *k) { return fr_from_hex(j.at(k).as_string()); };
+    Mixer m;
+    m.rU_X = one("rU_X"), m.rU_Y = one("rU_Y"), m.rV_X = one("rV_X"), m.rV_Y = one("rV_Y");
+    m.rO_mid = one("rO_mid"), m.rR_X = one("rR_X"), m.rR_Y = one("rR_Y");
+    auto fill = [&](const char *k, ScalarField *dst, size_t n) {
+        const auto &items = j.at(k).items();
+        if (items.size() != n) throw Error(std::string("mixer field ") + k + " has the wrong length");
+        for (size_t i = 0; i < n; i++) dst[i] = fr_from_hex(items[i].as_string());
+    };
+    fill("rW_X", m.rW_X.data(), 4), fill("rW_Y", m.rW_Y.data(), 4), fill("rB_X", m.rB_X.data(), 2), fill("rB_Y", m.rB_Y.data(), 2);
+    return m;
+}
 struct Binding {
     G1Affine A_free, O_pub_free, O_mid, O_prv;
 };
@@ -92,6 +123,7 @@ struct ProverSigma {
     DeviceVec<G1Affine> gamma_inv_o_inst, eta_inv_li_o_inter_alpha4_kj, delta_inv_li_o_prv;
     std::vector<G1Affine> delta_inv_alphak_xh_tx, delta_inv_alpha4_xj_tx, delta_inv_alphak_yi_ty;   // 3x3, 2, 4x3
     G1Affine delta, eta;
+    bool binding_tables_converted = false;   // ProverContext keeps the three binding tables in the MSM's resident form
     static ProverSigma from_payload(const CrsPayload &crs, const SetupParams &sp) {
         size_t m_i = sp.l_D - sp.l, rs_x = std::max(2 * sp.n, 2 * m_i), rs_y = 2 * sp.s_max;
         auto want = [&](CrsPayload::Section s, size_t pts, const char *name) {
@@ -114,7 +146,8 @@ struct ProverSigma {
                            host(CrsPayload::DeltaInvAlpha4XjTx),
                            host(CrsPayload::DeltaInvAlphakYiTy),
                            singles[3],
-                           singles[4]};
+                           singles[4],
+                           false};
     }
 };
 
@@ -239,6 +272,7 @@ class Prover {
         if (!is_pow2(s_max)) throw Error("s_max is not a power of two.");
         if (!is_pow2(m_i)) throw Error("m_I is not a power of two.");
         p->m_i = m_i;
+        if (sigma.binding_tables_converted) throw Error("Prover::init takes plain binding tables; this reference string belongs to a ProverContext");
         p->sigma = &sigma;
         p->mixer = mixer;
         init_ntt_domain_for_size(4 * std::max(m_i, n) * 2 * s_max);   // prover_verifier_ntt_domain_size (libs/src/utils/mod.rs:51-58)

@@ -1,0 +1,373 @@
+// tkmk_service.hpp — the prover as a resident service: everything that does not change between proofs of one circuit is loaded
+// ONCE (ProverContext::open), and a proof is one call (ProverContext::prove) from the synthesizer's files to proof.json.
+//
+// The reference runs one process per proof (prove/src/main.rs:27-97) and pays for the circuit-static part every time inside
+// Prover::init (prove/src/lib.rs:675-1206): setupParams.json / subcircuitInfo.json, the .r1cs of every used subcircuit
+// (libs/src/iotools/mod.rs:1287-1420), the mmap + validation of combined_sigma.rkyv (prove/src/sigma_source.rs:22-32).  Here these
+// live in the context: the constraint library as device-resident CSR (tkmk_r1cs_library), the CRS in HBM in the MSM's resident
+// form, the static wire lists that route witness values to b(X,Y) and to the binding commitments, the identity part of s0 / s1,
+// and the NTT domain.  Per proof the host only parses the three synthesizer documents (placementVariables.json on all cores,
+// tkmk_fastparse.hpp) and uploads the witness once; every loop over placements x wires of the reference's init
+// (gen_bXY, read_R1CS_gen_uvwXY, encode_O_pub_free / O_mid / O_prv, Permutation::to_poly) is a device launch over that copy.
+// Results are those of Prover::init + prove0..prove4 of tkmk_prover.hpp on the same inputs and blinding scalars, bit for bit
+// (tests/test_gpu_service.py).  `bin/prove` is open + prove + exit on the same code.
+#pragma once
+#include <sys/stat.h>
+
+#include <fstream>
+
+#include "tkmk_fastparse.hpp"
+#include "tkmk_inputs.hpp"
+#include "tkmk_prover.hpp"
+
+namespace tkmk {
+
+struct ProveTiming {   // seconds
+    double parse = 0, upload = 0, build = 0, binding = 0, init = 0;
+    double prove[5] = {0, 0, 0, 0, 0};
+    double write = 0, total = 0;
+};
+
+class ProverContext {
+  public:
+    SetupParams sp{};
+    size_t m_i = 0;
+    std::vector<SubcircuitInfo> infos;
+    std::vector<size_t> n_consts;
+    std::string lib_dir;
+    unsigned threads = 1;
+    std::unique_ptr<ProverSigma> sigma;   // tables in the MSM's resident form (see open)
+    std::string crs_source;               // which container the CRS came from
+
+  private:
+    tkmk_r1cs_library *lib_ = nullptr;
+    // static (local wire, row) lists per subcircuit kind, concatenated; kind k owns [first[k], first[k + 1])
+    struct WireLists {
+        std::vector<uint32_t> first;
+        DeviceVec<uint32_t> wire, row;
+        uint32_t count(size_t k) const { return first[k + 1] - first[k]; }
+    };
+    WireLists iface_, prv_, pub_;
+    DeviceVec<ScalarField> s0_identity_, s1_identity_, xp_, yp_;   // w_x^row / w_y^col matrices and the two power tables
+    ScalarField *pinned_ = nullptr;                                 // witness staging
+    uint64_t pinned_cap_ = 0;
+    std::vector<uint32_t> n_wires_;
+
+    static WireLists make_lists(const std::vector<std::vector<std::pair<uint32_t, uint32_t>>> &per_kind) {
+        WireLists L;
+        std::vector<uint32_t> w, r;
+        L.first.push_back(0);
+        for (auto &v : per_kind) {
+            for (auto &e : v) w.push_back(e.first), r.push_back(e.second);
+            L.first.push_back((uint32_t)w.size());
+        }
+        if (w.empty()) w.push_back(0), r.push_back(0);
+        L.wire = DeviceVec<uint32_t>::from_host(w);
+        L.row = DeviceVec<uint32_t>::from_host(r);
+        return L;
+    }
+    ScalarField *staging(uint64_t elements) {
+        if (elements > pinned_cap_) {
+            if (pinned_) check(tkmk_host_free(pinned_), "host_free");
+            pinned_ = nullptr;
+            pinned_cap_ = elements + elements / 8 + 1024;
+            check(tkmk_host_malloc((void **)&pinned_, pinned_cap_ * sizeof(ScalarField)), "host_malloc");
+        }
+        return pinned_;
+    }
+
+  public:
+    ProverContext() = default;
+    ProverContext(const ProverContext &) = delete;
+    ProverContext &operator=(const ProverContext &) = delete;
+    ~ProverContext() {
+        if (lib_) tkmk_r1cs_library_destroy(lib_);
+        if (pinned_) tkmk_host_free(pinned_);
+    }
+
+    static SetupParams read_setup_params(const std::string &dir) {
+        json::Value jp = json::read_file(dir + "/setupParams.json");
+        return SetupParams{jp.at("l").as_size(),   jp.at("l_user_out").as_size(), jp.at("l_user").as_size(), jp.at("l_free").as_size(),
+                           jp.at("l_D").as_size(), jp.at("m_D").as_size(),        jp.at("n").as_size(),      jp.at("s_D").as_size(),
+                           jp.at("s_max").as_size()};
+    }
+
+    // circuit-static state: subcircuit library from <lib_dir>, reference string from <crs_dir> (combined_sigma.rkyv, or the flat
+    // combined_sigma.tkcrs payload when only that is present)
+    static std::unique_ptr<ProverContext> open(const std::string &lib_dir, const std::string &crs_dir,
+                                               const std::function<std::unique_ptr<ProverSigma>(const SetupParams &, std::string &)> &load_sigma) {
+        std::unique_ptr<ProverContext> c(new ProverContext());
+        c->lib_dir = lib_dir;
+        c->threads = host_threads();
+        c->sp = read_setup_params(lib_dir);
+        const SetupParams &sp = c->sp;
+        if (sp.l_D < sp.l) throw Error("Invalid setup params: l_D must be >= l.");   // setup_shape / validate_setup_shape (libs/src/utils/mod.rs:21-46)
+        c->m_i = sp.l_D - sp.l;
+        if (!is_pow2(sp.n)) throw Error("n is not a power of two.");
+        if (!is_pow2(sp.s_max)) throw Error("s_max is not a power of two.");
+        if (!is_pow2(c->m_i)) throw Error("m_I is not a power of two.");
+        {
+            const json::Value jinfo = json::read_file(lib_dir + "/subcircuitInfo.json");
+            for (const json::Value &e : jinfo.items()) {
+                SubcircuitInfo si;
+                si.id = e.at("id").as_size();
+                si.name = e.at("name").as_string();
+                si.Nwires = e.at("Nwires").as_size();
+                si.Out_idx = {e.at("Out_idx").items().at(0).as_size(), e.at("Out_idx").items().at(1).as_size()};
+                si.In_idx = {e.at("In_idx").items().at(0).as_size(), e.at("In_idx").items().at(1).as_size()};
+                for (const json::Value &g : e.at("flattenMap").items()) si.flattenMap.push_back(g.as_size());
+                c->infos.push_back(std::move(si));
+                c->n_consts.push_back(e.at("Nconsts").as_size());
+            }
+        }
+        init_ntt_domain_for_size(4 * std::max(c->m_i, sp.n) * 2 * sp.s_max);   // prover_verifier_ntt_domain_size (libs/src/utils/mod.rs:51-58)
+
+        // constraint library -> device CSR, and the static wire lists
+        const size_t K = c->infos.size();
+        std::vector<SubcircuitR1CS> r1cs(K);
+        std::vector<uint32_t> n_rows(K), n_wires(K);
+        std::vector<const uint32_t *> rp(3 * K), wr(3 * K);
+        std::vector<const tkmk_fr *> cf(3 * K);
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> iface(K), prv(K), pub(K);
+        for (size_t k = 0; k < K; k++) {
+            const SubcircuitInfo &info = c->infos[k];
+            if (info.flattenMap.size() != info.Nwires) throw Error("subcircuitInfo.json: flattenMap length differs from Nwires for subcircuit " + std::to_string(info.id));
+            R1csBinary b = R1csBinary::read(lib_dir + "/r1cs/subcircuit" + std::to_string(info.id) + ".r1cs");
+            r1cs[k] = SubcircuitR1CS::from_r1cs_sparse_only(b, sp, info, c->n_consts[k]);
+            n_rows[k] = r1cs[k].n_constraints, n_wires[k] = r1cs[k].n_wires;
+            for (int m = 0; m < 3; m++) rp[3 * k + m] = r1cs[k].row_ptr[m].data(), wr[3 * k + m] = r1cs[k].wire[m].data(), cf[3 * k + m] = r1cs[k].coeff[m].data();
+            for (size_t j = 0; j < info.Nwires; j++) {
+                size_t g = info.flattenMap[j];
+                if (g >= sp.m_D) throw Error("subcircuitInfo.json: flattenMap entry outside the global wire range");
+                if (g >= sp.l && g < sp.l_D) iface[k].push_back({(uint32_t)j, (uint32_t)(g - sp.l)});
+                else if (g >= sp.l_D) prv[k].push_back({(uint32_t)j, (uint32_t)(g - sp.l_D)});
+            }
+            const std::array<size_t, 2> *rng = nullptr;   // encode_O_pub_free (libs/src/group_structures/mod.rs:184-229)
+            if (info.name == "bufferPubOut") rng = &info.Out_idx;
+            else if (info.name == "bufferPubIn" || info.name == "bufferBlockIn") rng = &info.In_idx;
+            if (rng)
+                for (size_t j = (*rng)[0]; j < (*rng)[0] + (*rng)[1]; j++) {
+                    if (j >= info.Nwires) throw Error("subcircuitInfo.json: public wire range outside the subcircuit");
+                    if (info.flattenMap[j] >= sp.l) throw Error("subcircuitInfo.json: public wire mapped outside [0, l)");
+                    pub[k].push_back({(uint32_t)j, (uint32_t)info.flattenMap[j]});
+                }
+        }
+        check(tkmk_r1cs_library_create((uint32_t)K, n_rows.data(), n_wires.data(), rp.data(), wr.data(), cf.data(), &c->lib_), "tkmk_r1cs_library_create");
+        c->n_wires_ = n_wires;
+        c->iface_ = make_lists(iface), c->prv_ = make_lists(prv), c->pub_ = make_lists(pub);
+
+        // Permutation::to_poly's identity part (libs/src/iotools/mod.rs:419-437): s0[row][col] = w_x^row, s1[row][col] = w_y^col
+        {
+            const size_t m_i = c->m_i, s_max = sp.s_max;
+            std::vector<ScalarField> ones(m_i * s_max, fr_from_u32(1));
+            DeviceVec<ScalarField> base = DeviceVec<ScalarField>::from_host(ones);
+            ScalarField wx = root_of_unity(m_i), wy = root_of_unity(s_max), one = fr_from_u32(1);
+            c->s0_identity_ = DeviceVec<ScalarField>(m_i * s_max), c->s1_identity_ = DeviceVec<ScalarField>(m_i * s_max);
+            check(tkmk_poly_scale_coeffs(base.ptr(), (uint32_t)m_i, (uint32_t)s_max, &wx, &one, c->s0_identity_.ptr(), nullptr), "s0 powers");
+            check(tkmk_poly_scale_coeffs(base.ptr(), (uint32_t)m_i, (uint32_t)s_max, &one, &wy, c->s1_identity_.ptr(), nullptr), "s1 powers");
+            c->xp_ = DeviceVec<ScalarField>(m_i), c->yp_ = DeviceVec<ScalarField>(s_max);
+            check(tkmk_memcpy_2d_d2d(c->xp_.ptr(), 32, c->s0_identity_.ptr(), 32 * s_max, 32, m_i), "x powers");   // column 0 of s0
+            check(tkmk_memcpy_d2d(c->yp_.ptr(), c->s1_identity_.ptr(), 32 * s_max), "y powers");                   // row 0 of s1
+        }
+
+        c->sigma = load_sigma(sp, c->crs_source);
+        // binding tables -> resident form, in place (Sigma1 converts xy_powers itself)
+        tkmk_msm_config cfg = tkmk_msm_default_config();
+        cfg.are_points_on_device = cfg.are_results_on_device = true;
+        for (DeviceVec<G1Affine> *t : {&c->sigma->gamma_inv_o_inst, &c->sigma->eta_inv_li_o_inter_alpha4_kj, &c->sigma->delta_inv_li_o_prv})
+            check(bls12_381_msm_convert_bases(t->ptr(), t->len(), &cfg, t->ptr()), "msm::convert_bases");
+        c->sigma->binding_tables_converted = true;
+        check(tkmk_device_synchronize(), "synchronize");
+        return c;
+    }
+
+    // Prover::init (prove/src/lib.rs:675-1206) from the synthesizer's directory
+    std::pair<std::unique_ptr<Prover>, Binding> init(const std::string &synth_dir, const Mixer &mixer, ProveTiming &tm) {
+        using namespace prover_detail;
+        const double t0 = Prover::now();
+        const size_t n = sp.n, s_max = sp.s_max, K = infos.size();
+
+        // ---- the three per-proof documents
+        MappedFile pv_file(synth_dir + "/placementVariables.json");
+        WitnessLayout W = parse_placement_variables_fast(pv_file.data(), pv_file.size(), n_wires_, [&](uint64_t total) { return staging(total); }, threads);
+        const size_t P = W.id.size();
+        if (P > s_max) throw Error("placement_variables length exceeds s_max.");
+        MappedFile perm_file(synth_dir + "/permutation.json");
+        PermutationColumns perm = parse_permutation_fast(perm_file.data(), perm_file.size(), threads);
+        std::vector<ScalarField> a_pub_user, a_pub_block;
+        {
+            const json::Value jinst = json::read_file(synth_dir + "/instance.json");
+            a_pub_user = hex_list(jinst.at("a_pub_user"));
+            a_pub_block = hex_list(jinst.at("a_pub_block"));
+        }
+        // placements grouped by kind: slot list, variable offsets, position of each kind's run
+        std::vector<uint32_t> kind_first(K + 1, 0), slots(P ? P : 1);
+        std::vector<uint64_t> offs(P ? P : 1);
+        for (size_t q = 0; q < P; q++) kind_first[W.id[q] + 1]++;
+        for (size_t k = 0; k < K; k++) kind_first[k + 1] += kind_first[k];
+        {
+            std::vector<uint32_t> cur(kind_first.begin(), kind_first.end() - 1);
+            for (size_t q = 0; q < P; q++) {
+                uint32_t at = cur[W.id[q]]++;
+                slots[at] = (uint32_t)q, offs[at] = W.off[q];
+            }
+        }
+        // Permutation::to_poly's redirects: distinct destinations (the reference's serial loop lets the last entry win)
+        std::vector<uint32_t> dst, srcx, srcy;
+        {
+            const size_t cells = m_i * s_max;
+            std::vector<uint64_t> bitmap((cells + 63) / 64, 0);
+            bool dup = false;
+            dst.reserve(perm.size());
+            for (size_t e = 0; e < perm.size(); e++) {
+                if (perm.row[e] >= m_i || perm.col[e] >= s_max || perm.X[e] >= m_i || perm.Y[e] >= s_max) throw Error("permutation entry out of range");
+                uint32_t d = perm.row[e] * (uint32_t)s_max + perm.col[e];
+                if (bitmap[d >> 6] >> (d & 63) & 1) dup = true;
+                bitmap[d >> 6] |= 1ull << (d & 63);
+                dst.push_back(d);
+            }
+            srcx = perm.X, srcy = perm.Y;
+            if (dup) {   // keep the last writer of every cell
+                std::fill(bitmap.begin(), bitmap.end(), 0);
+                std::vector<uint32_t> d2, x2, y2;
+                for (size_t e = perm.size(); e-- > 0;) {
+                    uint32_t d = dst[e];
+                    if (bitmap[d >> 6] >> (d & 63) & 1) continue;
+                    bitmap[d >> 6] |= 1ull << (d & 63);
+                    d2.push_back(d), x2.push_back(srcx[e]), y2.push_back(srcy[e]);
+                }
+                dst.swap(d2), srcx.swap(x2), srcy.swap(y2);
+            }
+        }
+        tm.parse = Prover::now() - t0;
+
+        // ---- one upload of the witness and of the small index arrays
+        const double t1 = Prover::now();
+        DeviceVec<ScalarField> d_vars((size_t)W.total + 1);
+        if (W.total) check(tkmk_memcpy_h2d(d_vars.ptr(), pinned_, (size_t)W.total * sizeof(ScalarField)), "witness upload");
+        DeviceVec<uint32_t> d_id = DeviceVec<uint32_t>::from_host(W.id.empty() ? std::vector<uint32_t>{0} : W.id);
+        DeviceVec<uint64_t> d_off = DeviceVec<uint64_t>::from_host(W.off.empty() ? std::vector<uint64_t>{0} : W.off);
+        DeviceVec<uint32_t> d_slots = DeviceVec<uint32_t>::from_host(slots);
+        DeviceVec<uint64_t> d_offs = DeviceVec<uint64_t>::from_host(offs);
+        tm.upload = Prover::now() - t1;
+
+        // ---- polynomials
+        const double t2 = Prover::now();
+        std::unique_ptr<Prover> p(new Prover());
+        p->sp = sp, p->m_i = m_i, p->sigma = sigma.get(), p->mixer = mixer;
+        {   // read_R1CS_gen_uvwXY (libs/src/iotools/mod.rs:1287-1420)
+            DeviceVec<ScalarField> u(n * s_max), v(n * s_max), w(n * s_max);
+            check(tkmk_r1cs_library_eval(lib_, d_vars.ptr(), d_id.ptr(), d_off.ptr(), (uint32_t)P, (uint32_t)n, (uint32_t)s_max, u.ptr(), v.ptr(), w.ptr(), nullptr),
+                  "tkmk_r1cs_library_eval");
+            p->uXY = Poly::from_rou_evals(u, n, s_max), p->vXY = Poly::from_rou_evals(v, n, s_max), p->wXY = Poly::from_rou_evals(w, n, s_max);
+        }
+        // gen_bXY + the (scalar, CRS row) lists of O_mid / O_prv / O_pub_free, kind by kind
+        uint64_t n_mid = 0, n_prv = 0, n_pub = 0;
+        std::vector<uint64_t> mid_at(K), prv_at(K), pub_at(K);
+        for (size_t k = 0; k < K; k++) {
+            uint64_t cnt = kind_first[k + 1] - kind_first[k];
+            mid_at[k] = n_mid, prv_at[k] = n_prv, pub_at[k] = n_pub;
+            n_mid += cnt * iface_.count(k), n_prv += cnt * prv_.count(k), n_pub += cnt * pub_.count(k);
+        }
+        // nVar checks of encode_statement_common (libs/src/group_structures/mod.rs:231-264, 294-296)
+        {
+            std::vector<PlacementVariables> shape(P);
+            for (size_t q = 0; q < P; q++) shape[q].subcircuitId = W.id[q];
+            if (n_mid != count_o_mid_nvar(shape, infos) || n_prv != count_o_prv_nvar(shape, infos)) throw Error("nVar mismatch while encoding statement");
+        }
+        if (n_mid >= (1ull << 31) || n_prv >= (1ull << 31)) throw Error("binding commitment too large");
+        DeviceVec<ScalarField> b_ev(m_i * s_max), mid_sc(n_mid + 1), prv_sc(n_prv + 1), pub_sc(n_pub + 1);
+        DeviceVec<uint32_t> mid_ix(n_mid + 1), prv_ix(n_prv + 1), pub_ix(n_pub + 1);
+        check(tkmk_memset(b_ev.ptr(), 0, m_i * s_max * sizeof(ScalarField)), "memset");
+        for (size_t k = 0; k < K; k++) {
+            uint32_t cnt = kind_first[k + 1] - kind_first[k];
+            if (!cnt) continue;
+            const uint64_t *vo = d_offs.ptr() + kind_first[k];
+            const uint32_t *sl = d_slots.ptr() + kind_first[k];
+            check(tkmk_witness_route(d_vars.ptr(), vo, sl, cnt, iface_.wire.ptr() + iface_.first[k], iface_.row.ptr() + iface_.first[k], iface_.count(k), b_ev.ptr(),
+                                     (uint32_t)s_max, mid_sc.ptr() + mid_at[k], mid_ix.ptr() + mid_at[k], (uint32_t)s_max, 1, nullptr),
+                  "tkmk_witness_route");
+            check(tkmk_witness_route(d_vars.ptr(), vo, sl, cnt, prv_.wire.ptr() + prv_.first[k], prv_.row.ptr() + prv_.first[k], prv_.count(k), nullptr, 0,
+                                     prv_sc.ptr() + prv_at[k], prv_ix.ptr() + prv_at[k], (uint32_t)s_max, 1, nullptr),
+                  "tkmk_witness_route");
+            check(tkmk_witness_route(d_vars.ptr(), vo, sl, cnt, pub_.wire.ptr() + pub_.first[k], pub_.row.ptr() + pub_.first[k], pub_.count(k), nullptr, 0,
+                                     pub_sc.ptr() + pub_at[k], pub_ix.ptr() + pub_at[k], 1, 0, nullptr),
+                  "tkmk_witness_route");
+        }
+        p->bXY = Poly::from_rou_evals(b_ev, m_i, s_max);
+        p->rXY = Poly::zero();
+        p->a_free_X = gen_a_free_X(a_pub_user, a_pub_block, sp);
+        p->t_n = vanishing(n, true), p->t_mi = vanishing(m_i, true), p->t_smax = vanishing(s_max, false);
+        {   // Permutation::to_poly (libs/src/iotools/mod.rs:419-455)
+            DeviceVec<ScalarField> e0 = s0_identity_.clone(), e1 = s1_identity_.clone();
+            if (!dst.empty()) {
+                DeviceVec<uint32_t> d_dst = DeviceVec<uint32_t>::from_host(dst), d_x = DeviceVec<uint32_t>::from_host(srcx), d_y = DeviceVec<uint32_t>::from_host(srcy);
+                check(tkmk_fr_scatter_table(xp_.ptr(), d_x.ptr(), d_dst.ptr(), dst.size(), e0.ptr(), nullptr), "tkmk_fr_scatter_table");
+                check(tkmk_fr_scatter_table(yp_.ptr(), d_y.ptr(), d_dst.ptr(), dst.size(), e1.ptr(), nullptr), "tkmk_fr_scatter_table");
+                check(tkmk_device_synchronize(), "synchronize");   // the index buffers go out of scope here
+            }
+            p->s0XY = Poly::from_rou_evals(e0, m_i, s_max), p->s1XY = Poly::from_rou_evals(e1, m_i, s_max);
+        }
+        check(tkmk_device_synchronize(), "synchronize");
+        tm.build = Prover::now() - t2;
+
+        // ---- binding commitments (lib.rs:1086-1160): four MSMs over resident tables in one pipelined call
+        const double t3 = Prover::now();
+        const Mixer &mx = mixer;
+        Binding b;
+        auto indexed = [](const DeviceVec<ScalarField> &sc, const DeviceVec<uint32_t> &ix, uint64_t cnt, const DeviceVec<G1Affine> &table) {
+            tkmk_msm_job_ex j{};
+            j.scalars = sc.ptr(), j.bases = table.ptr(), j.msm_size = (int)cnt, j.base_index = ix.ptr(), j.base_table_len = table.len();
+            return j;
+        };
+        std::vector<G1Affine> cm = Sigma1::run_jobs({sigma->sigma1.job(p->a_free_X), indexed(pub_sc, pub_ix, n_pub, sigma->gamma_inv_o_inst),
+                                                     indexed(mid_sc, mid_ix, n_mid, sigma->eta_inv_li_o_inter_alpha4_kj),
+                                                     indexed(prv_sc, prv_ix, n_prv, sigma->delta_inv_li_o_prv)});
+        b.A_free = cm[0], b.O_pub_free = cm[1];
+        const G1Affine &O_mid_core = cm[2], &O_prv_core = cm[3];
+        const auto &xh = sigma->delta_inv_alphak_xh_tx, &xj = sigma->delta_inv_alpha4_xj_tx, &yi = sigma->delta_inv_alphak_yi_ty;
+        ScalarField zero{};
+        std::vector<std::pair<ScalarField, G1Affine>> mid = {{fr_one(), O_mid_core}, {mx.rO_mid, sigma->delta}};
+        while (mid.size() < 16) mid.push_back({zero, O_mid_core});
+        std::vector<std::pair<ScalarField, G1Affine>> prv = {   // lib.rs:1146-1160
+            {fr_one(), O_prv_core}, {fr_neg(mx.rO_mid), sigma->eta},
+            {mx.rU_X, xh[0]}, {mx.rV_X, xh[3]}, {mx.rW_X[0], xh[6]}, {mx.rW_X[1], xh[7]}, {mx.rW_X[2], xh[8]},
+            {mx.rB_X[0], xj[0]}, {mx.rB_X[1], xj[1]},
+            {mx.rU_Y, yi[0]}, {mx.rV_Y, yi[3]}, {mx.rW_Y[0], yi[6]}, {mx.rW_Y[1], yi[7]}, {mx.rW_Y[2], yi[8]},
+            {mx.rB_Y[0], yi[9]}, {mx.rB_Y[1], yi[10]}};
+        auto both = g1_lincombs({mid, prv});
+        b.O_mid = both[0], b.O_prv = both[1];
+        tm.binding = Prover::now() - t3;
+        tm.init = Prover::now() - t0;
+        p->timing["init.parse"] = tm.parse, p->timing["init.upload"] = tm.upload, p->timing["init.build"] = tm.build;
+        p->timing["init.binding"] = tm.binding, p->timing["init.total"] = tm.init;
+        return {std::move(p), b};
+    }
+
+    // main() of prove/src/main.rs:27-97 after check_device: init, five rounds, <out_dir>/proof.json
+    Proof prove(const std::string &synth_dir, const std::string &out_dir, const Mixer &mixer, ProveTiming *timing = nullptr) {
+        ProveTiming tm;
+        const double t0 = Prover::now();
+        auto pb = init(synth_dir, mixer, tm);
+        std::map<std::string, double> times;
+        Proof proof = run_rounds(*pb.first, pb.second, &times);
+        int k = 0;
+        for (const char *name : {"prove0", "prove1", "prove2", "prove3", "prove4"}) tm.prove[k++] = times[name];
+        const double tw = Prover::now();
+        if (!out_dir.empty()) {
+            ::mkdir(out_dir.c_str(), 0777);
+            std::string path = out_dir + "/proof.json";
+            std::ofstream f(path);
+            if (!f) throw Error("cannot write " + path);
+            f << proof.to_json();
+            f.close();
+            if (!f) throw Error("cannot write " + path);
+        }
+        tm.write = Prover::now() - tw;
+        tm.total = Prover::now() - t0;
+        if (timing) *timing = tm;
+        return proof;
+    }
+};
+
+}  // namespace tkmk

@@ -11,6 +11,7 @@
 
 #include "tkmk_g2.hpp"
 #include "tkmk_protocol.hpp"
+#include "tkmk_rkyv.hpp"
 #include "tkmk_witness.hpp"
 
 namespace tkmk {
@@ -200,6 +201,35 @@ struct Sigma {
         for (const auto &p : g2) f.write(reinterpret_cast<const char *>(p.data()), 192);
         if (!f) throw Error("short write on " + path);
         return path;
+    }
+    // bytes of the two archives the reference's setup writes (write_final_crs_artifacts, libs/src/iotools/mod.rs:271-300) with 32-bit
+    // relative pointers: past 2 GiB rkyv itself cannot represent them
+    uint64_t archive_bytes() const {
+        return 96ull * (xy_powers.len() + gamma_inv_o_inst.len() + eta_inv_li_o_inter_alpha4_kj.len() + delta_inv_li_o_prv.len() + 29) + 10 * 192 + 65536;
+    }
+    // <out_dir>/combined_sigma.rkyv and <out_dir>/sigma_preprocess.rkyv, the containers the reference's `prove` / `preprocess` open
+    void write_rkyv(const std::string &out_dir, const SetupParams &sp) const {
+        if (archive_bytes() >= (1ull << 31)) throw Error("this reference string does not fit an rkyv archive (32-bit relative pointers); use the .tkcrs payload");
+        std::vector<G1Affine> h_xy = xy_powers.to_host(), h_gamma = gamma_inv_o_inst.to_host(), h_eta = eta_inv_li_o_inter_alpha4_kj.to_host();
+        std::vector<G1Affine> h_delta = delta_inv_li_o_prv.len() ? delta_inv_li_o_prv.to_host() : std::vector<G1Affine>();
+        std::vector<uint8_t> g2_bytes;
+        for (const auto &p : g2) g2_bytes.insert(g2_bytes.end(), p.begin(), p.end());
+        auto b = [](const std::vector<G1Affine> &v) { return reinterpret_cast<const uint8_t *>(v.data()); };
+        const size_t m_i = sp.l_D - sp.l;
+        rkyv::SigmaTables t{b(singles), b(h_xy), h_xy.size(), b(h_gamma), h_gamma.size(),
+                            b(h_eta), std::vector<size_t>(m_i, sp.s_max),
+                            b(h_delta), std::vector<size_t>(sp.m_D - sp.l_D, sp.s_max),
+                            b(delta_inv_alphak_xh_tx), {3, 3, 3}, b(delta_inv_alpha4_xj_tx), delta_inv_alpha4_xj_tx.size(),
+                            b(delta_inv_alphak_yi_ty), {3, 3, 3, 3}, g2_bytes.data()};
+        auto put = [&](const std::string &name, const std::vector<uint8_t> &bytes) {
+            std::string path = out_dir + "/" + name;
+            std::ofstream f(path, std::ios::binary);
+            f.write(reinterpret_cast<const char *>(bytes.data()), (std::streamsize)bytes.size());
+            f.close();
+            if (!f) throw Error("cannot write " + path);
+        };
+        put("combined_sigma.rkyv", rkyv::encode_combined_sigma(t));
+        put("sigma_preprocess.rkyv", rkyv::encode_sigma_preprocess(b(h_xy), h_xy.size(), b(h_gamma), h_gamma.size()));
     }
 };
 

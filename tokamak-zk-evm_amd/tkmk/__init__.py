@@ -93,6 +93,8 @@ SYMBOLS = [
     "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench", "tkmk_diag_field_mul", "tkmk_poly_find_degree",
     "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_expr_eval", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
     "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini", "tkmk_r1cs_eval_rows",
+    "tkmk_msm_multi_ex", "bls12_381_msm_convert_bases", "tkmk_r1cs_library_create", "tkmk_r1cs_library_destroy", "tkmk_r1cs_library_eval",
+    "tkmk_witness_route", "tkmk_fr_scatter_table", "tkmk_host_malloc", "tkmk_host_free",
 ]
 
 
@@ -437,6 +439,48 @@ def msm_multi(jobs, c=0, bitsize=0, stream=None, curve="bls12_381", precompute_f
         arr[k] = MsmJob(_p(j[0]).value, _p(j[1]).value, int(n))
     out = np.empty(aff // 2 * 3 * len(jobs), np.uint8)
     _check(getattr(lib(), sym)(arr, len(jobs), ctypes.byref(cfg), _p(out)), sym)
+    return out
+
+
+class MsmJobEx(ctypes.Structure):
+    _fields_ = [("scalars", ctypes.c_void_p), ("bases", ctypes.c_void_p), ("msm_size", ctypes.c_int),
+                ("scalar_cols", ctypes.c_uint32), ("scalar_stride", ctypes.c_uint32), ("base_cols", ctypes.c_uint32),
+                ("base_stride", ctypes.c_uint32), ("base_index", ctypes.c_void_p), ("base_table_len", ctypes.c_uint64)]
+
+
+BASES_PLAIN, BASES_MONTGOMERY, BASES_CONVERTED = 0, 1, 2
+
+
+def msm_convert_bases(bases, n=None, points_montgomery=False, out=None):
+    """bases (host array or DeviceBuffer of 96-byte affine records) -> DeviceBuffer in the MSM's resident form (BASES_CONVERTED);
+    out=bases converts a DeviceBuffer in place"""
+    n = _len(bases) * 32 // 96 if n is None else n
+    cfg = lib().tkmk_msm_default_config()
+    cfg.are_points_on_device = _on_dev(bases)
+    cfg.are_points_montgomery_form = points_montgomery
+    cfg.are_results_on_device = True
+    out = DeviceBuffer(96 * n) if out is None else out
+    _check(lib().bls12_381_msm_convert_bases(_p(bases), ctypes.c_uint64(n), ctypes.byref(cfg), _p(out)), "bls12_381_msm_convert_bases")
+    return out
+
+
+def msm_multi_ex(jobs, bases_form=BASES_PLAIN, c=0, bitsize=0, stream=None):
+    """jobs = [dict(scalars=DeviceBuffer, bases=DeviceBuffer, n=points, scalar_view=(cols, stride) | None,
+    base_view=(cols, stride) | None, base_index=DeviceBuffer of u32 | None, table_len=records behind bases)];
+    returns len(jobs) projective results on the host (tkmk_msm_multi_ex: MSMs over views of resident tables)"""
+    cfg = lib().tkmk_msm_default_config()
+    cfg.are_scalars_on_device = cfg.are_points_on_device = True
+    cfg.c, cfg.bitsize, cfg.stream_handle = c, bitsize, stream
+    if not jobs:
+        return np.empty(0, np.uint8)
+    arr = (MsmJobEx * len(jobs))()
+    for k, j in enumerate(jobs):
+        sv, bv, ix = j.get("scalar_view") or (0, 0), j.get("base_view") or (0, 0), j.get("base_index")
+        STATS["msm_points"] += int(j["n"])
+        arr[k] = MsmJobEx(_p(j["scalars"]).value, _p(j["bases"]).value, int(j["n"]), sv[0], sv[1], bv[0], bv[1],
+                          None if ix is None else _p(ix).value, int(j.get("table_len", 0)))
+    out = np.empty(144 * len(jobs), np.uint8)
+    _check(lib().tkmk_msm_multi_ex(arr, len(jobs), ctypes.byref(cfg), int(bases_form), _p(out)), "tkmk_msm_multi_ex")
     return out
 
 

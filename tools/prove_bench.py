@@ -153,7 +153,7 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
                "--subcircuit-library", inst["qap"]]
         os.makedirs(os.path.join(tmp, "out"))
         if compare:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, TKMK_PROVE_MIXER=os.path.join(tmp, "mixer.json")))
+            r = subprocess.run(cmd + ["--testing-mixer", os.path.join(tmp, "mixer.json")], capture_output=True, text=True, timeout=900)
             if r.returncode != 0:
                 raise RuntimeError(r.stderr)
             same = json.load(open(os.path.join(tmp, "out", "proof.json"))) == want
@@ -166,7 +166,7 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
             wall = time.perf_counter() - t0
             if r.returncode != 0:
                 raise RuntimeError(r.stderr)
-            rec = {m.group(1): float(m.group(2)) for m in re.finditer(r"^(\S+)\s+([0-9.]+) s$", r.stdout, re.M)}
+            rec = {m.group(1): float(m.group(2)) for m in re.finditer(r"^(\S+)\s+([0-9.]+) s\b", r.stdout, re.M)}
             rec["total"] = float(re.search(r"Total elapsed time: ([0-9.]+)s", r.stdout).group(1))
             rec["rounds"] = round(sum(rec["prove%d" % k] for k in range(5)), 4)
             rec["process_wall"] = round(wall, 3)

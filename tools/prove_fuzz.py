@@ -1,7 +1,7 @@
 """Randomized differential run of the GPU prover against the big-int restatement (tests/prove_ref.py) over random circuit shapes:
 every proof point, evaluation and challenge must match, and the combined verifier equation must hold on the discrete logarithms.
 usage: python tools/prove_fuzz.py [CASES] [FIRST_SEED] [native] [mid]      (test infrastructure: uses the oracle)
-With `native` the proof comes from tokamak-zk-evm_amd/bin/prove over files (CRS written by Sigma.write, blinding through TKMK_PROVE_MIXER)."""
+With `native` the proof comes from tokamak-zk-evm_amd/bin/prove over files (CRS written by Sigma.write, blinding through --testing-mixer)."""
 import json
 import os
 import random
@@ -54,8 +54,8 @@ for seed in range(first, first + cases):
         hx = lambda v: [hx(e) for e in v] if isinstance(v, list) else "0x%x" % v      # noqa: E731
         json.dump({k: hx(v) for k, v in mixer.items()}, open(os.path.join(d, "mixer.json"), "w"))
         r = subprocess.run([os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "prove"), "--crs", os.path.join(d, "crs"), "--synthesizer-stat", inst["synth"],
-                            "--output", os.path.join(d, "out"), "--subcircuit-library", inst["qap"]], capture_output=True, text=True, timeout=300,
-                           env=dict(os.environ, TKMK_PROVE_MIXER=os.path.join(d, "mixer.json")))
+                            "--output", os.path.join(d, "out"), "--subcircuit-library", inst["qap"], "--testing-mixer", os.path.join(d, "mixer.json")],
+                           capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (seed, shape, r.stderr)
         points, scalars = proofio.recover_proof(json.load(open(os.path.join(d, "out", "proof.json"))))
         assert scalars == ref_scalars, (seed, shape)
