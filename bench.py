@@ -1,37 +1,50 @@
 #!/usr/bin/env python3
 """bench.py — headline measurement of the hot path on MI355X (one process per GPU).
 
-A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
-  N = 1 : BASELINE.json configs[1] — one 2^24-point G1 Pippenger MSM.  (Curve: BLS12-381, the only curve
-          the reference uses — SURVEY.md §0.2; BASELINE.json's "BN254" has no reference counterpart.)
-  N > 1 : the same per-GPU shard on every rank (weak scaling, SURVEY.md §8e: the MSM shards by points),
-          partial results exchanged with ONE RCCL all_gather of 144-byte points, then summed by a
-          world_size-point MSM with unit scalars on every rank.
-Inputs are generated on the device from a seed: scalars = splitmix64 stream mod r,
-bases P_i = [h_i]G.  Prints ONE JSON line (rank 0).
+METRIC (BASELINE.json): constraints/sec for the full prove step on the 2^22-constraint synthesized circuit.
 
-value = "MSM field-adds/sec": group additions per second at the algorithmic count SURVEY.md §8d fixes for
-this config (ceil(255/16) = 16 bucket-accumulate adds per point, independent of the window width the
-kernel actually picks, so the figure is points/s x 16 and cannot be inflated by doing more work).
+A "step" is ONE FULL PROOF of BASELINE.json configs[3] — Prover::init + prove0..prove4 + proof.json, the timed region of the
+reference's own binary after check_device (packages/backend/prove/src/main.rs:41-84; its timing harness:
+prove/optimization/tests/timing.rs:101-125) — through the resident native prover (libtkmk_prover.so: include/tkmk_prover.h,
+host/tkmk_service.hpp, C++ over the C ABI of libtkmk_hip.so).  Nothing inside the step is Python: one ctypes call per proof.
+  workload  : n = 4096, m_I = 4096, s_max = 1024 (2^22 constraint slots, every placement used; SURVEY.md section 8d cfg 4), synthetic
+              satisfying circuit in the reference's file formats (tools/synth_circuit.py), fixed-tau CRS generated on the device
+  per step  : reads <synth>/placementVariables.json (~115 MB of hex), permutation.json, instance.json from files; fresh random
+              blinding scalars; writes proof.json
+  resident  : what does not change between proofs of one circuit — the CRS in HBM (in the MSM's resident form), the subcircuit
+              library as device CSR, the NTT domain — loaded once by tkmk_prover_open, untimed (the contract's "inputs already
+              resident in HBM"); DESIGN.md section 5 gives the cold-start figures (process start, CRS load) separately
+  N > 1     : every rank proves on its own GPU (independent proofs: weak scaling, no data-path collective; rank 0 stages the
+              files, all ranks read them); the collective is only the timing barrier / max.  --msm-sharded adds BASELINE.json
+              configs[4]'s shape as a secondary: a point-sharded MSM with one RCCL all_gather of the 144-byte partial results.
+value = constraint slots proved per second by the whole job = 2^22 * N * steps / max-over-ranks elapsed.
 
-Secondary objects on the same line (N = 1 only; each records {"error": ...} instead of costing the line if it fails):
-  cpu_baseline  the oracle's Pippenger on a 2^20-point sample of the same stream, on the box's host cores
-  bn254_msm     the same MSM kernels over BN254 (BASELINE.json configs[1] as worded)
-  ntt           BASELINE.json configs[2] (256 x 2^20 scalar-field NTTs) and the production _biNTT shapes
-  prove         BASELINE.json's "constraints/sec (prove step)": the whole prover (init + prove0..4) on synthetic satisfying circuits at the
-                reference's production shape (2^20 constraint slots) and at configs[3]'s 2^22 slots, the production shape through the native
-                binary on files, the proof's algorithmic bytes against the HBM peak, and a CPU estimate from the oracle's measured rates
-With --gpus N --prove-dist the production-shape proof is also timed with the commitments of each round spread over the ranks.
+roofline (same JSON line): the dominant kernel of a proof, k_accumulate_chunks (bucket accumulation of every MSM): HIP events on
+the launch streams over the timed region (tkmk_profile_*: recorded without synchronising), algorithmic bytes = 128 B per committed
+point (scalar + base read once) / summed launch time, against 8 TB/s; `traffic` from the committed
+rocprofv3 PMC summary (profiles/traffic.json).  The kernel is integer-VALU bound by construction; valu_roofline gives the
+fraction of the measured v_mad_u64_u32 rate.
+cpu_baseline: the oracle (a C port — the reference's Rust + ICICLE CPU prover cannot be built offline) on a bounded sample: one
+2^20-point MSM and one 1024 x 1024 bivariate NTT on the box's host cores, checked against the GPU, scaled by the proof's counted
+MSM points / NTT elements: a LOWER bound on CPU prove time (polynomial bookkeeping and host glue come on top), labelled as such.
+
+Secondary objects (N = 1; each records {"error": ...} instead of costing the line if it fails):
+  production_2p20  the reference's production shape (s_max = 256, 166 placements; published walls 45.70 s CPU / 21.08 s CUDA)
+  msm_2p24         BASELINE.json configs[1]: 2^24-point G1 MSM, BLS12-381 and (as worded) BN254
+  ntt              BASELINE.json configs[2]: 256 x 2^20 scalar-field NTTs, and the production _biNTT
 """
 import argparse
 import json
 import os
+import shutil
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tokamak-zk-evm_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np  # noqa: E402
 
@@ -40,6 +53,7 @@ MAD_PEAK_PER_S = 3.2e13          # measured v_mad_u64_u32 issue rate, lane-ops/s
 MADS_PER_BUCKET_ADD = 7 * 392 + 196 + 2 * 301   # madd-2008-s on 14 x 29-bit limbs: 8 products (two share one reduction) + 2 squares (csrc/ffu.h, ec_u.h)
 ADDS_PER_POINT = 16              # SURVEY.md §8d cfg 2: N * ceil(b/c) at c = 16, b = 255
 ALG_BYTES_PER_POINT = 32 + 96    # each scalar and base read once
+ALG_BYTES_PER_NTT_ELEMENT = 64   # read once, written once
 SEED = 0x746F6B616D616B00
 
 
@@ -48,19 +62,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--logn", type=int, default=24, help="log2 of points per GPU (default: BASELINE configs[1])")
-    ap.add_argument("--cpu-sample-logn", type=int, default=20)
+    ap.add_argument("--s-max", type=int, default=1024, help="1024 = BASELINE.json configs[3] (2^22 constraint slots); 256 = the reference's production shape")
+    ap.add_argument("--placements", type=int, default=None, help="used placements (default: all s_max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ntt", action="store_true", help="skip the secondary NTT measurements (BASELINE.json configs[2], _biNTT)")
-    ap.add_argument("--no-bn254", action="store_true", help="skip the secondary BN254 G1 MSM measurement (BASELINE.json configs[1] as worded)")
-    ap.add_argument("--no-prove", action="store_true",
-                    help="skip the full-prove measurements (BASELINE.json configs[3] and the reference's production shape)")
-    ap.add_argument("--prove-dist", action="store_true",
-                    help="N > 1 only: also time the production-shape prove with each round's commitments spread over the ranks")
+    ap.add_argument("--no-secondary", action="store_true", help="skip production_2p20 / msm_2p24 / ntt")
+    ap.add_argument("--msm-sharded", action="store_true", help="N > 1: also time the point-sharded MSM of BASELINE.json configs[4] (2^25 points per rank)")
+    ap.add_argument("--msm-sharded-logn", type=int, default=25)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --dist-backend gloo)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="rehearsal only: initialise the process group and run the partial-result exchange even with one rank")
+    ap.add_argument("--workdir", default=None, help="where the staged files go (default: a fresh temporary directory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,30 +81,22 @@ def main():
 
     import torch
     import tkmk
-    from tkmk import sharding
+    from tkmk import service
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     dev = 0 if args.share_gpu0 else local_rank
     torch.cuda.set_device(dev)
     tkmk.set_device(dev)
     dist = None
-    if world > 1 or args.force_dist:
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")     # only reached without a launcher (--force-dist rehearsal)
+        os.environ.setdefault("MASTER_PORT", "29500")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     comm_device = "cuda" if args.dist_backend == "nccl" else "cpu"
-
-    n = 1 << args.logn
-    # --- synthetic inputs, generated in HBM (untimed) ---
-    scalars = tkmk.fr_random_device(SEED + 2 + 16 * rank, n)
-    h = tkmk.fr_random_device(SEED + 3 + 16 * rank, n)
-    g = np.frombuffer(bytes(_generator()), np.uint8).copy()
-    bases = tkmk.g1_batch_scalar_mul_device(h, g, n)
-    h.free()
 
     def barrier():
         if dist is not None:
@@ -102,117 +104,137 @@ def main():
         torch.cuda.synchronize()
         tkmk.synchronize()
 
-    def step():
-        return sharding.msm_sharded(tkmk, dist, scalars, bases, device=comm_device)   # 144-byte canonical projective
-
-    for _ in range(args.warmup):
-        step()
-    if args.force_dist and world == 1:   # one-rank rehearsal of the exchange msm_sharded performs for N > 1
-        part = tkmk.msm(scalars, bases)
-        assert (sharding.combine_partials(tkmk, sharding.gather_partials(dist, part, comm_device)) == part).all()
-    tkmk.profile_enable(True)
-    tkmk.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tkmk.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    prove_dist = None
-    if dist is not None and world > 1 and args.prove_dist:      # every rank takes part: replicated rounds, commitments by owner
-        scalars.free()
-        bases.free()
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import prove_bench
-        r = prove_bench.run(s_max=256, placements=166, repeat=3, dist=dist, comm_device=comm_device)
-        prove_dist = {"workload": r["workload"] + ", commitments of each round spread over %d ranks" % world, "wall_s": r["seconds"]["total"],
-                      "init_s": r["seconds"]["init"], "rounds_s": r["seconds"]["rounds"], "constraints_per_s": r["constraint_slots_per_s"],
-                      "per_round_s": {k: r["seconds"][k] for k in ("prove0", "prove1", "prove2", "prove3", "prove4")}}
-
-    acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
-    sections = {}
-    for name in ("convert_bases", "digits", "hist", "scan", "scatter", "accumulate", "combine", "reduce_segments",
-                 "reduce_windows"):
-        ms, cnt = tkmk.profile_get("msm." + name)
-        if cnt:
-            sections[name] = round(ms / cnt, 4)
-
+    # --- stage the files every rank reads (untimed): rank 0 generates the circuit, its witness and the CRS ---
+    import prove_bench
+    files = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        points_per_s = n * world * args.steps / elapsed
-        value = points_per_s * ADDS_PER_POINT
-        # dominant kernel: k_accumulate (one launch per MSM of n points)
-        # one big launch per step (for N > 1 the world-point combine MSM adds a negligible second one)
-        kernel_ms = acc_ms / args.steps if acc_cnt else float("nan")
-        alg_bytes = n * ALG_BYTES_PER_POINT
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = _traffic_from_profiles(args.logn)
-        out = {
-            "metric": "MSM field-adds/sec",
-            "value": value,
-            "unit": "group-adds/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32 limbs (381-bit Fq / 255-bit Fr modular integer arithmetic)",
-            "data": "synthetic",
-            "config": {"workload": "2^%d-point BLS12-381 G1 Pippenger MSM per GPU (BASELINE.json configs[1]), inputs resident in HBM"
-                                   % args.logn,
-                       "points_per_gpu": n, "sharding": "points" if world > 1 else "none"},
-            "points_per_s": points_per_s,
-            "roofline": {"bound": "hbm", "kernel": "k_accumulate_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "integer-VALU bound by construction (SURVEY.md §8d): ~375 int mul-adds per algorithmic byte"},
-            "kernel_ms": sections,
-            # the bound that actually applies: 32x32->64 integer multiply-add issue in k_accumulate_chunks
-            "valu_roofline": {"kernel": "k_accumulate_chunks", "unit": "v_mad_u64_u32 lane-ops/s",
-                              "achieved": n * ADDS_PER_POINT * MADS_PER_BUCKET_ADD / (kernel_ms * 1e-3),
-                              "peak": MAD_PEAK_PER_S,
-                              "frac": n * ADDS_PER_POINT * MADS_PER_BUCKET_ADD / (kernel_ms * 1e-3) / MAD_PEAK_PER_S},
-        }
-        if prove_dist is not None:
-            out["prove_dist"] = prove_dist
-        if world > 1:      # the CPU baseline and the secondary figures are N = 1 material; keep the scaling runs lean
-            args.no_cpu_baseline = args.no_bn254 = args.no_ntt = args.no_prove = True
-        def leg(key, fn):
-            """a secondary figure must never cost the headline line: its failure is recorded under its key instead"""
-            try:
-                out[key] = fn()
-            except Exception as e:      # noqa: BLE001
-                out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        files = prove_bench.stage_files(s_max=args.s_max, placements=args.placements, tmp=args.workdir)
+    if dist is not None:
+        box = [files]
+        dist.broadcast_object_list(box, src=0)
+        files = box[0]
+    slots = files["constraint_slots"]
+    try:
+        t = time.perf_counter()
+        prover = service.Prover(files["qap"], files["crs"])            # circuit-static state -> HBM, once
+        open_s = time.perf_counter() - t
+        out_dir = os.path.join(files["tmp"], "out_rank%d" % rank)
 
-        if not args.no_cpu_baseline:
-            leg("cpu_baseline", lambda: _cpu_baseline(tkmk, args.cpu_sample_logn))
-        if (not args.no_bn254 or not args.no_ntt) and prove_dist is None:
-            scalars.free()
-            bases.free()
-        if not args.no_bn254:
-            leg("bn254_msm", lambda: _bn254_secondary(tkmk, args.logn))
-        if not args.no_ntt:
-            leg("ntt", lambda: _ntt_secondary(tkmk))
-        if not args.no_prove:
-            leg("prove", lambda: _prove_secondary(tkmk))
-            prod, cpu = out["prove"].get("production_2p20", {}), out.get("cpu_baseline", {})
-            if "msm_points" in prod and "points_per_s" in cpu:
+        def step():
+            return prover.prove(files["synth"], out_dir, want_json=False)[1]
+
+        for _ in range(args.warmup):
+            step()
+        tkmk.profile_enable(True)
+        tkmk.profile_reset()
+        tkmk.native_stats_reset()
+        barrier()
+        t0 = time.perf_counter()
+        timings = [step() for _ in range(args.steps)]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        tkmk.profile_enable(False)
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        stats = tkmk.native_stats()
+        sections = {}
+        for name in ("convert_bases", "digits", "hist", "scan", "scatter", "accumulate", "combine", "reduce_segments", "reduce_windows"):
+            ms, cnt = tkmk.profile_get("msm." + name)
+            if cnt:
+                sections[name] = {"ms_per_proof": round(ms / args.steps, 3), "launches_per_proof": cnt / args.steps}
+        ntt_ms = sum(tkmk.profile_get("ntt.pass%d" % k)[0] for k in range(8))
+        acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
+        prover.close()
+
+        msm_sharded = None
+        if dist is not None and world > 1 and args.msm_sharded:         # every rank takes part
+            msm_sharded = _msm_sharded_leg(tkmk, dist, comm_device, rank, world, args.msm_sharded_logn, barrier, torch)
+
+        if rank == 0:
+            med = {k: statistics.median(t_[k] for t_ in timings) for k in timings[0]}
+            points_per_proof = stats["msm.points"] / args.steps
+            out = {
+                "metric": "constraints/sec (prove step)",
+                "value": slots * world * args.steps / elapsed,
+                "unit": "constraints/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "u32 limbs (255-bit Fr / 381-bit Fq modular integer arithmetic)",
+                "data": "synthetic",
+                "config": {"workload": "full prove (Prover::init + prove0..prove4 + proof.json) per GPU, BASELINE.json configs[3]: " + files["workload"] +
+                                       "; synthesizer documents read from files every step, CRS + subcircuit library resident in HBM",
+                           "constraint_slots_per_proof": slots, "r1cs_rows_per_proof": files["r1cs_rows"], "proofs_per_step": world,
+                           "host_side": "native C++ (libtkmk_prover.so over the C ABI of libtkmk_hip.so)",
+                           "sharding": "independent proofs per GPU" if world > 1 else "none"},
+                "r1cs_rows_per_s": files["r1cs_rows"] * world * args.steps / elapsed,
+                "per_proof_s": {k: round(v, 5) for k, v in med.items()},
+                "init_fraction": round(med["init_s"] / med["total_s"], 3),
+                "open_context_s": round(open_s, 3),
+                "staged_files": {k: files[k] for k in ("crs_payload_bytes", "placement_variables_json_bytes", "permutation_json_bytes", "generate_s",
+                                                       "sigma_gen_s", "crs_write_s")},
+                "work_per_proof": {"msm_points": points_per_proof, "msm_calls": stats["msm.calls"] / args.steps,
+                                   "ntt_elements": stats["ntt.elements"] / args.steps, "ntt_calls": stats["ntt.calls"] / args.steps,
+                                   "algorithmic_bytes": ALG_BYTES_PER_POINT * points_per_proof + ALG_BYTES_PER_NTT_ELEMENT * stats["ntt.elements"] / args.steps},
+                "kernel_ms_per_proof": dict(sections, ntt_passes=round(ntt_ms / args.steps, 3)),
+            }
+            if acc_cnt:
+                avg_ms = acc_ms / acc_cnt
+                alg = ALG_BYTES_PER_POINT * stats["msm.points"] / acc_cnt      # per launch: one launch per MSM
+                achieved = alg / (avg_ms * 1e-3) / 1e9
+                mads = stats["msm.points"] * ADDS_PER_POINT * MADS_PER_BUCKET_ADD / (acc_ms * 1e-3)
+                out["roofline"] = {"bound": "hbm", "kernel": "k_accumulate_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles("prove_accumulate_configs3" if args.s_max == 1024 else None),
+                                   "avg_launch_ms": avg_ms, "launches": acc_cnt, "launches_per_proof": acc_cnt / args.steps,
+                                   "algorithmic_bytes_per_launch": alg, "share_of_step": (acc_ms / args.steps) / (elapsed / args.steps * 1e3),
+                                   "note": "integer-VALU bound by construction (SURVEY.md §8d: ~375 int mul-adds per algorithmic byte); launches of "
+                                           "concurrent streams overlap, so the summed launch time can exceed its share of the wall"}
+                out["valu_roofline"] = {"kernel": "k_accumulate_chunks", "unit": "v_mad_u64_u32 lane-ops/s", "achieved": mads, "peak": MAD_PEAK_PER_S,
+                                        "frac": mads / MAD_PEAK_PER_S}
+            out["hbm_roofline_whole_step"] = {"achieved_GBps": out["work_per_proof"]["algorithmic_bytes"] / (elapsed / args.steps) / 1e9, "peak_GBps": HBM_PEAK_GBS}
+            if msm_sharded is not None:
+                out["msm_sharded"] = msm_sharded
+
+            def leg(key, fn):
+                """a secondary figure must never cost the headline line: its failure is recorded under its key instead"""
                 try:
-                    out["prove"]["cpu_estimate"] = _prove_cpu_estimate(tkmk, prod, cpu)
+                    out[key] = fn()
                 except Exception as e:      # noqa: BLE001
-                    out["prove"]["cpu_estimate"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        out["result_x_lo"] = int.from_bytes(bytes(result[:8]), "little")
-        print(json.dumps(out), flush=True)
+                    out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+            tkmk.release_scratch()
+            if world == 1 and not args.no_cpu_baseline:
+                leg("cpu_baseline", lambda: _cpu_baseline(tkmk, out["work_per_proof"], slots, elapsed / args.steps))
+            if world == 1 and not args.no_secondary:
+                leg("production_2p20", lambda: _production_leg(prove_bench))
+                tkmk.release_scratch()
+                leg("msm_2p24", lambda: _msm_leg(tkmk))
+                tkmk.release_scratch()
+                leg("ntt", lambda: _ntt_secondary(tkmk))
+            print(json.dumps(out), flush=True)
+    finally:
+        if dist is not None:
+            dist.barrier()
+        if rank == 0 and args.workdir is None:
+            shutil.rmtree(files["tmp"], ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _traffic_from_profiles(key):
+    """HBM bytes per k_accumulate_chunks launch from the committed rocprofv3 PMC summary (profiles/traffic.json), or None"""
+    if key is None:
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def _generator():
@@ -222,153 +244,6 @@ def _generator():
     y = [1187375073, 212476713, 2726857444, 3493644100, 738505709, 14358731, 3587181302, 4243972245, 1948093156,
          2694721773, 3819610353, 146011265]
     return b"".join(int(v).to_bytes(4, "little") for v in x + y)
-
-
-def _bn254_secondary(tkmk, logn):
-    """BASELINE.json configs[1] as worded ("2^24-point BN254 G1 Pippenger MSM"): the same kernels instantiated over the
-    254-bit fields (csrc/msm_bn254.hip).  Secondary because the reference has no BN254 path."""
-    n = 1 << logn
-    s = tkmk.fr_random_device(SEED + 5, n, curve="bn254")
-    h = tkmk.fr_random_device(SEED + 6, n, curve="bn254")
-    g = np.zeros(64, np.uint8)
-    g[0], g[32] = 1, 2
-    b = tkmk.g1_batch_scalar_mul_device(h, g, n, curve="bn254")
-    h.free()
-    tkmk.msm(s, b, curve="bn254")
-    tkmk.profile_enable(True)
-    tkmk.profile_reset()
-    tkmk.synchronize()
-    steps = 3
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tkmk.msm(s, b, curve="bn254")
-    tkmk.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    tkmk.profile_enable(False)
-    acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
-    s.free()
-    b.free()
-    return {"workload": "2^%d-point BN254 G1 Pippenger MSM, inputs resident in HBM" % logn, "ms_per_msm": dt * 1e3,
-            "points_per_s": n / dt, "group_adds_per_s": n / dt * ADDS_PER_POINT,
-            "accumulate_kernel_ms": acc_ms / acc_cnt if acc_cnt else None,
-            "hbm_frac_of_peak": (n * (32 + 64) / (acc_ms / acc_cnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if acc_cnt else None}
-
-
-def _traffic_from_profiles(logn):
-    """HBM bytes per k_accumulate_chunks launch from the committed rocprofv3 PMC summary (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        t = json.load(open(path))
-        key = "msm_accumulate_2^%d" % logn
-        return t.get(key, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
-
-
-def _ntt_secondary(tkmk):
-    """Secondary, outside the timed region: BASELINE.json configs[2] (256 independent 2^20-point NTTs, resident) and the
-    reference's largest production _biNTT (16384 x 512).  Algorithmic bytes = 64 B per element."""
-    res = {}
-    try:
-        tkmk.init_ntt_domain_for_size(1 << 23)
-        for name, n, batch, bi in (("rows_256x2^20", 1 << 20, 256, None), ("bintt_16384x512", None, None, (16384, 512))):
-            elems = n * batch if bi is None else bi[0] * bi[1]
-            a = tkmk.fr_random_device(SEED + 5, elems)
-            o = tkmk.DeviceBuffer(32 * elems)
-            fn = (lambda: tkmk.ntt(a, n, batch=batch, out=o)) if bi is None else (lambda: tkmk.bintt(a, bi[0], bi[1], out=o))
-            fn()
-            tkmk.synchronize()
-            reps = 3
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            tkmk.synchronize()
-            dt = (time.perf_counter() - t0) / reps
-            # per-pass kernel times from HIP events on the launch stream (a separate, profiled repetition)
-            tkmk.profile_enable(True)
-            tkmk.profile_reset()
-            fn()
-            tkmk.profile_enable(False)
-            passes = []
-            for k in range(8):
-                ms, cnt = tkmk.profile_get("ntt.pass%d" % k)
-                if cnt:
-                    passes.append(ms / cnt)
-            moved = 64 * elems * len(passes)                   # every pass reads and writes each element once
-            res[name] = {"ms": dt * 1e3, "elements_per_s": elems / dt, "algorithmic_GBps": 64 * elems / dt / 1e9,
-                         "hbm_frac": 64 * elems / dt / 1e9 / HBM_PEAK_GBS, "passes_ms": [round(x, 4) for x in passes],
-                         "moved_GBps": (moved / (sum(passes) * 1e-3) / 1e9) if passes else None,
-                         "moved_hbm_frac": (moved / (sum(passes) * 1e-3) / 1e9 / HBM_PEAK_GBS) if passes else None,
-                         "bound": "integer VALU (Fr products): see DESIGN.md section 4"}
-            a.free()
-            o.free()
-    except Exception as e:  # secondary figure: never fail the headline line
-        res["error"] = str(e)
-    return res
-
-
-def _prove_secondary(tkmk):
-    """BASELINE.json's "constraints/sec (prove step)": the whole prover (tkmk/prove.py: init + prove0..prove4, every
-    polynomial and commitment on the device) on synthetic satisfying circuits (tools/synth_circuit.py, fixed-tau CRS), at
-    the reference's production shape with its placement count (2^20 constraint slots; reference walls 45.70 s CPU / 21.08 s
-    CUDA on other hardware) and at configs[3]'s 2^22 slots (s_max = 1024, every placement used).
-    constraints_per_s = constraint slots / (init + rounds) wall, host glue included."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import prove_bench
-    tkmk.release_scratch()            # the arenas of the 2^24-point MSM / 16 GiB NTT legs go back to the driver first
-    out = {}
-    for key, kw in (("production_2p20", dict(s_max=256, placements=166, repeat=4)), ("configs3_2p22", dict(s_max=1024, repeat=2))):
-        try:
-            r = prove_bench.run(**kw)
-        except Exception as e:      # noqa: BLE001
-            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
-            continue
-        out[key] = {"workload": r["workload"], "constraints_per_s": r["constraint_slots_per_s"], "r1cs_rows_per_s": r["r1cs_rows_per_s"],
-                    "wall_s": r["seconds"]["total"], "init_s": r["seconds"]["init"], "rounds_s": r["seconds"]["rounds"],
-                    "per_round_s": {k: r["seconds"][k] for k in ("prove0", "prove1", "prove2", "prove3", "prove4")},
-                    "constraint_slots": r["constraint_slots"], "r1cs_rows": r["r1cs_rows"],
-                    "msm_points": r["seconds"]["msm_points"], "ntt_elements": r["seconds"]["ntt_elements"], "hbm_roofline": r["hbm_roofline"]}
-        tkmk.release_scratch()
-    # the same production-shape proof through the native binary (C++ host side): files in the reference's formats in, proof.json
-    # out, a fresh process per run, CRS payload and JSON inputs loaded inside the timed total
-    try:
-        r = prove_bench.run_native(s_max=256, placements=166, repeat=2)
-    except Exception as e:      # noqa: BLE001
-        out["native_production_2p20"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        out["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md §1)"}
-        return out
-    out["native_production_2p20"] = {"workload": r["workload"], "constraints_per_s": r["constraint_slots_per_s"],
-                                     "constraints_per_s_init_plus_rounds": r["constraint_slots_per_s_init_plus_rounds"],
-                                     "wall_s": r["seconds"]["total"], "seconds": r["seconds"], "sigma_gen_s": r["sigma_gen_s"],
-                                     "crs_payload_bytes": r["crs_payload_bytes"], "placement_variables_json_bytes": r["placement_variables_json_bytes"]}
-    tkmk.release_scratch()
-    out["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, 166 placements, other hardware (BASELINE.md §1)"}
-    return out
-
-
-def _prove_cpu_estimate(tkmk, prod, msm_baseline):
-    """What the MSM + NTT share of the production-shape proof costs on this box's host cores with the oracle's C port (the reference's
-    Rust + ICICLE CPU prover cannot be built offline; its own published run is 45.7 s on ~8 threads of other hardware).  Not a
-    measured proof: the proof's counted work (points committed, NTT elements) times the oracle's measured rates — the MSM rate
-    from cpu_baseline's sample, the NTT rate from one 1024 x 1024 bivariate transform timed here and checked against the GPU.
-    A lower bound for a CPU prover (polynomial bookkeeping, divisions and host glue come on top)."""
-    import oracle
-    threads = msm_baseline["cores"]
-    xs = ys = 1024
-    a = tkmk.fr_random_device(SEED + 9, xs * ys)
-    ah = a.to_host()
-    oracle.bintt(ah[:32 * 64 * 64], 64, 64)
-    t0 = time.perf_counter()
-    want = oracle.bintt(ah, xs, ys)
-    dt = time.perf_counter() - t0
-    ok = bool((np.asarray(tkmk.bintt(a, xs, ys).to_host()) == np.asarray(want)).all())
-    ntt_rate = xs * ys / dt
-    msm_s = prod["msm_points"] / msm_baseline["points_per_s"]
-    ntt_s = prod["ntt_elements"] / ntt_rate
-    return {"kind": "port, extrapolated from bounded samples (MSM + NTT share only)", "cores": threads, "msm_points_per_s": msm_baseline["points_per_s"],
-            "ntt_elements_per_s": ntt_rate, "ntt_sample": "one 1024 x 1024 bivariate NTT, %.3f s, matches the GPU: %s" % (dt, ok),
-            "msm_s": msm_s, "ntt_s": ntt_s, "seconds": msm_s + ntt_s, "gpu_wall_s": prod["wall_s"],
-            "constraints_per_s": prod["constraint_slots"] / (msm_s + ntt_s)}
 
 
 def _usable_cpus(omp_threads):
@@ -388,24 +263,149 @@ def _usable_cpus(omp_threads):
     return max(1, n)
 
 
-def _cpu_baseline(tkmk, sample_logn):
-    """The oracle's Pippenger (a C port; the reference's Rust+ICICLE CPU path cannot be built offline) on a
-    bounded sample of the same workload, all host threads, checked against the GPU on that sample."""
+def _cpu_baseline(tkmk, work, slots, gpu_step_s):
+    """The oracle (a C port; the reference's Rust + ICICLE CPU prover cannot be built offline — its own published run is 45.7 s for a
+    2^20-slot proof on ~8 threads of other hardware) on a bounded sample of the step's work, on this box's host cores: one 2^20-point
+    MSM and one 1024 x 1024 bivariate NTT from the benchmark's seeded streams, each checked against the GPU, then the proof's counted
+    MSM points and NTT elements divided by those rates.  A LOWER bound on a CPU prover's time for the step (polynomial bookkeeping,
+    divisions and host glue come on top), i.e. an upper bound on its constraints/s."""
     import oracle
-    m = 1 << sample_logn
+    threads = _usable_cpus(oracle.num_threads())
+    m = 1 << 20
     s = tkmk.fr_random_device(SEED + 2, m)
     hh = tkmk.fr_random_device(SEED + 3, m)
     g = np.frombuffer(bytes(_generator()), np.uint8).copy()
     b = tkmk.g1_batch_scalar_mul_device(hh, g, m)
     sh, bh = s.to_host(), b.to_host()
-    threads = _usable_cpus(oracle.num_threads())
     t0 = time.perf_counter()
     want = oracle.g1_msm(sh, bh, threads=threads)
+    msm_dt = time.perf_counter() - t0
+    msm_ok = bool((tkmk.projective_to_affine_bytes(tkmk.msm(s, b)) == want).all())
+    xs = ys = 1024
+    tkmk.init_ntt_domain_for_size(xs * ys)
+    a = tkmk.fr_random_device(SEED + 9, xs * ys)
+    ah = a.to_host()
+    oracle.bintt(ah[:32 * 64 * 64], 64, 64)
+    t0 = time.perf_counter()
+    want = oracle.bintt(ah, xs, ys)
+    ntt_dt = time.perf_counter() - t0
+    ntt_ok = bool((np.asarray(tkmk.bintt(a, xs, ys).to_host()) == np.asarray(want)).all())
+    msm_rate, ntt_rate = m / msm_dt, xs * ys / ntt_dt
+    msm_s, ntt_s = work["msm_points"] / msm_rate, work["ntt_elements"] / ntt_rate
+    return {"value": slots / (msm_s + ntt_s), "unit": "constraints/s", "cores": threads, "kind": "port",
+            "sample": "one 2^20-point MSM (%.2f s) + one 1024 x 1024 bivariate NTT (%.3f s) of the seeded streams on %d host threads; the step's "
+                      "counted MSM points and NTT elements at those rates (MSM + NTT share only: a lower bound on CPU time)" % (msm_dt, ntt_dt, threads),
+            "msm_points_per_s": msm_rate, "ntt_elements_per_s": ntt_rate, "matches_gpu": msm_ok and ntt_ok,
+            "estimated_step_s": msm_s + ntt_s, "gpu_step_s": gpu_step_s,
+            "reference_published_wall_s": {"cpu": 45.70, "cuda": 21.08, "note": "2^20-slot production shape, 166 placements, other hardware (BASELINE.md §1)"}}
+
+
+def _production_leg(prove_bench):
+    """the reference's production shape (n = 4096, m_I = 4096, s_max = 256, 166 placements: the run behind the published 45.70 s CPU /
+    21.08 s CUDA walls) through the same resident prover"""
+    r = prove_bench.run_service(s_max=256, placements=166, repeat=5, warmup=1)
+    return {"workload": r["workload"], "constraints_per_s": r["constraint_slots_per_s"], "r1cs_rows_per_s": r["r1cs_rows_per_s"],
+            "per_proof_s": r["median"], "init_fraction": r["init_fraction"], "open_context_s": r["open_context_s"],
+            "reference_wall_s": {"cpu": 45.70, "cuda": 21.08, "note": "other hardware (BASELINE.md §1)"}}
+
+
+def _msm_leg(tkmk):
+    """BASELINE.json configs[1]: one 2^24-point G1 Pippenger MSM with scalars and bases resident in HBM, on the reference's curve
+    (BLS12-381) and on the curve the config names (BN254; no reference counterpart)"""
+    res = {}
+    n = 1 << 24
+    for curve, gen in (("bls12_381", np.frombuffer(bytes(_generator()), np.uint8).copy()), ("bn254", None)):
+        if gen is None:
+            gen = np.zeros(64, np.uint8)
+            gen[0], gen[32] = 1, 2
+        s = tkmk.fr_random_device(SEED + 2, n, curve=curve)
+        h = tkmk.fr_random_device(SEED + 3, n, curve=curve)
+        b = tkmk.g1_batch_scalar_mul_device(h, gen, n, curve=curve)
+        h.free()
+        tkmk.msm(s, b, curve=curve)
+        tkmk.profile_enable(True)
+        tkmk.profile_reset()
+        tkmk.synchronize()
+        steps = 5
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tkmk.msm(s, b, curve=curve)
+        tkmk.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        tkmk.profile_enable(False)
+        acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
+        s.free()
+        b.free()
+        bytes_pt = 32 + (96 if curve == "bls12_381" else 64)
+        res[curve] = {"workload": "2^24-point %s G1 Pippenger MSM, inputs resident in HBM" % curve, "ms_per_msm": dt * 1e3, "points_per_s": n / dt,
+                      "group_adds_per_s": n / dt * ADDS_PER_POINT, "accumulate_kernel_ms": acc_ms / acc_cnt if acc_cnt else None,
+                      "hbm_frac_of_peak": (n * bytes_pt / (acc_ms / acc_cnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if acc_cnt else None}
+        tkmk.release_scratch()
+    return res
+
+
+def _ntt_secondary(tkmk):
+    """BASELINE.json configs[2] (256 independent 2^20-point NTTs, resident) and the reference's largest production _biNTT
+    (16384 x 512).  Algorithmic bytes = 64 B per element."""
+    res = {}
+    tkmk.init_ntt_domain_for_size(1 << 23)
+    for name, n, batch, bi in (("rows_256x2^20", 1 << 20, 256, None), ("bintt_16384x512", None, None, (16384, 512))):
+        elems = n * batch if bi is None else bi[0] * bi[1]
+        a = tkmk.fr_random_device(SEED + 5, elems)
+        o = tkmk.DeviceBuffer(32 * elems)
+        fn = (lambda: tkmk.ntt(a, n, batch=batch, out=o)) if bi is None else (lambda: tkmk.bintt(a, bi[0], bi[1], out=o))
+        fn()
+        tkmk.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        tkmk.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        tkmk.profile_enable(True)
+        tkmk.profile_reset()
+        fn()
+        tkmk.profile_enable(False)
+        passes = []
+        for k in range(8):
+            ms, cnt = tkmk.profile_get("ntt.pass%d" % k)
+            if cnt:
+                passes.append(ms / cnt)
+        moved = 64 * elems * len(passes)                   # every pass reads and writes each element once
+        res[name] = {"ms": dt * 1e3, "elements_per_s": elems / dt, "algorithmic_GBps": 64 * elems / dt / 1e9,
+                     "hbm_frac": 64 * elems / dt / 1e9 / HBM_PEAK_GBS, "passes_ms": [round(x, 4) for x in passes],
+                     "moved_GBps": (moved / (sum(passes) * 1e-3) / 1e9) if passes else None,
+                     "bound": "integer VALU (Fr products): see DESIGN.md section 4"}
+        a.free()
+        o.free()
+    return res
+
+
+def _msm_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch):
+    """BASELINE.json configs[4]'s shape: every rank holds 2^logn points of one MSM (generated in HBM from the seed), runs the full
+    single-GPU pipeline on its shard, the 144-byte partial results meet in ONE all_gather (RCCL over xGMI) and every rank adds them"""
+    from tkmk import sharding
+    n = 1 << logn
+    scalars = tkmk.fr_random_device(SEED + 2 + 16 * rank, n)
+    h = tkmk.fr_random_device(SEED + 3 + 16 * rank, n)
+    g = np.frombuffer(bytes(_generator()), np.uint8).copy()
+    bases = tkmk.g1_batch_scalar_mul_device(h, g, n)
+    h.free()
+    sharding.msm_sharded(tkmk, dist, scalars, bases, device=comm_device)
+    barrier()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = sharding.msm_sharded(tkmk, dist, scalars, bases, device=comm_device)
+    barrier()
     dt = time.perf_counter() - t0
-    got = tkmk.projective_to_affine_bytes(tkmk.msm(s, b))
-    return {"value": m / dt * ADDS_PER_POINT, "unit": "group-adds/s", "cores": threads, "kind": "port",
-            "sample": "one 2^%d-point MSM (first 2^%d points of the benchmark stream), %.2f s" % (sample_logn, sample_logn, dt),
-            "points_per_s": m / dt, "matches_gpu": bool((got == want).all())}
+    tt = torch.tensor([dt], dtype=torch.float64, device=comm_device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item()) / steps
+    scalars.free()
+    bases.free()
+    return {"workload": "2^%d-point BLS12-381 G1 MSM, 2^%d points per rank, one all_gather of 144-byte partial results" % (logn + (world - 1).bit_length(), logn),
+            "ms_per_msm": dt * 1e3, "points_per_s": n * world / dt, "result_x_lo": int.from_bytes(bytes(res[:8]), "little")}
 
 
 if __name__ == "__main__":

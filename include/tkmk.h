@@ -217,6 +217,8 @@ tkmk_error bls12_381_get_root_of_unity(uint64_t max_size, tkmk_fr *rou_out);
 /* primitive_root must have order 2^k; builds twiddles for sizes up to 2^k. Fails if a domain exists. */
 tkmk_error bls12_381_ntt_init_domain(const tkmk_fr *primitive_root, const tkmk_ntt_init_domain_config *cfg);
 tkmk_error bls12_381_ntt_release_domain(void);
+/* size of the current domain, 0 = none (the domain is process-global: every host side in the process asks here before growing it) */
+tkmk_error bls12_381_ntt_domain_size(uint64_t *size);
 /* size = length n of ONE vector (power of two, <= domain); total elements = n * batch_size.
  * input may equal output (in place). */
 tkmk_error bls12_381_ntt(const tkmk_fr *input, int size, tkmk_ntt_dir dir, const tkmk_ntt_config *cfg,
@@ -294,6 +296,7 @@ tkmk_error tkmk_bn254_msm_multi(const tkmk_bn254_msm_job *jobs, int n_jobs, cons
 tkmk_error bn254_get_root_of_unity(uint64_t max_size, tkmk_bn254_fr *rou_out);
 tkmk_error bn254_ntt_init_domain(const tkmk_bn254_fr *primitive_root, const tkmk_ntt_init_domain_config *cfg);
 tkmk_error bn254_ntt_release_domain(void);
+tkmk_error bn254_ntt_domain_size(uint64_t *size);
 tkmk_error bn254_ntt(const tkmk_bn254_fr *input, int size, tkmk_ntt_dir dir, const tkmk_ntt_config *cfg,   /* cfg->coset_gen: 8 limbs */
                      tkmk_bn254_fr *output);
 tkmk_error tkmk_bn254_bintt(const tkmk_bn254_fr *input, size_t x_size, size_t y_size, tkmk_ntt_dir dir,
@@ -419,11 +422,16 @@ tkmk_error tkmk_host_free(void *ptr);
  * Measurement hooks (no reference counterpart; the reference's `timing` feature wraps host spans:
  * libs/src/lib.rs:11-141).  When enabled, launchers bracket each kernel with HIP events recorded on the
  * launch stream; names: "msm.digits|hist|scan|scatter|accumulate|reduce_segments|reduce_windows|
- * convert_bases", "ntt.pass<k>".  Enabling it adds one stream synchronisation per call.
+ * convert_bases", "ntt.pass<k>".  Recording does not wait for anything (the pipelined MSM entry keeps its overlap);
+ * tkmk_profile_get waits for the recorded events and returns the section's summed time and launch count.
+ * tkmk_stats_*: what the library was asked to do since the last reset — "msm.points", "msm.calls", "ntt.elements",
+ * "ntt.calls" — for the algorithmic-byte figures of the roofline report (128 B per point, 64 B per element).
  * --------------------------------------------------------------------------------------------- */
 tkmk_error tkmk_profile_enable(int on);
 tkmk_error tkmk_profile_reset(void);
 tkmk_error tkmk_profile_get(const char *name, double *sum_ms, int *count);
+tkmk_error tkmk_stats_reset(void);
+tkmk_error tkmk_stats_get(const char *name, uint64_t *value);
 /* arithmetic micro-benchmarks (kind 0 Fr mul, 1 Fq mul, 2 v_mad_u64_u32, 3 G1 mixed add, 4 Fr add+sub, 5 Fq sqr) */
 tkmk_error tkmk_diag_bench(int kind, uint32_t iters, uint32_t blocks, int reps, float *ms_out);
 /* out[i] = a[i]*b[i] through the device Montgomery product; field 0 = Fr (32 B), 1 = Fq (48 B); device pointers */

@@ -1,0 +1,62 @@
+"""Test infrastructure: what a verifier does with the prover's FILES alone (packages/backend/verify/verify-rust/src/lib.rs:54-117,
+248-289): recover the 19 points and 4 evaluations from proof.json, the three preprocess points from preprocess.json, replay the
+Fiat-Shamir transcript for the challenges, interpolate a_pub from instance.json, and evaluate the combined verification
+equation with actual pairings (tests/pairing_ref.py) against the G1 singles and Sigma2 of the CRS container.  No prover state, no
+discrete logarithm; independent of the circuit size except for the 128-point interpolation of the public input.
+Used by tests/test_gpu_prove.py (small shapes), tests/test_gpu_fullsize.py (production shape and BASELINE configs[3]) and
+tools/prove_bench.py --check."""
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def crs_sections(crs_dir, setup_params=None):
+    from tkmk import crs as crsmod
+    from tkmk import rkyv
+    flat = os.path.join(crs_dir, "combined_sigma.tkcrs")
+    if os.path.exists(flat):
+        return crsmod.read_payload(flat)
+    buf = np.fromfile(os.path.join(crs_dir, "combined_sigma.rkyv"), np.uint8)
+    return rkyv.decode_combined_sigma(buf, expect=None if setup_params is None else rkyv.expect_for(setup_params))
+
+
+def verify(qap_dir, synth_dir, crs_dir, out_dir, tamper_public_input=False, seed=5):
+    """-> True iff <out_dir>/proof.json verifies against <out_dir>/preprocess.json (made with bin/preprocess when absent), the public
+    inputs of <synth_dir>/instance.json and the CRS in <crs_dir>"""
+    import prove_ref
+    from tkmk import crs as crsmod
+    from tkmk import g2, proofio
+    from tkmk.transcript import TranscriptManager
+    sp = json.load(open(os.path.join(qap_dir, "setupParams.json")))
+    if not os.path.exists(os.path.join(out_dir, "preprocess.json")):
+        r = subprocess.run([os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "preprocess"), "--crs", crs_dir, "--synthesizer-stat", synth_dir, "--output", out_dir,
+                            "--subcircuit-library", qap_dir], capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            raise RuntimeError("bin/preprocess failed: " + r.stderr)
+    points, scalars = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
+    pre_points = proofio.recover_preprocess(json.load(open(os.path.join(out_dir, "preprocess.json"))))
+    m = TranscriptManager()                                  # Verifier::collect_challenges
+    m.add_proof0(*(points[k] for k in ("U", "V", "W", "Q_AX", "Q_AY", "B")))
+    thetas = m.get_thetas()
+    m.add_proof1(points["R"])
+    kappa0 = m.get_kappa0()
+    m.add_proof2(points["Q_CX"], points["Q_CY"])
+    chi, zeta = m.get_chi_zeta()
+    m.add_proof3(scalars["V_eval"], scalars["R_eval"], scalars["R_omegaX_eval"], scalars["R_omegaX_omegaY_eval"])
+    ch = {"thetas": thetas, "kappa0": kappa0, "chi": chi, "zeta": zeta, "kappa1": m.get_kappa1()}
+    ins = json.load(open(os.path.join(synth_dir, "instance.json")))
+    a = [int(h, 16) for h in ins["a_pub_user"][:sp["l_user"]]] + [int(h, 16) for h in ins["a_pub_block"][:sp["l_free"] - sp["l_user"]]]
+    a_eval = prove_ref.interpolate([[v] for v in a], sp["l_free"], 1).eval(chi, zeta)          # Instance::gen_a_free_X, then eval
+    if tamper_public_input:
+        a_eval = (a_eval + 1) % prove_ref.R
+    sections = crs_sections(crs_dir, sp)
+    crs_g1 = {k: np.asarray(crsmod.single_g1(sections, k)) for k in ("G", "x", "y", "lagrange_KL")}
+    recs = np.asarray(sections["g2"]).reshape(10, 192)
+    sigma2 = {name: g2.decode(recs[i]) for i, name in enumerate(crsmod.G2_POINTS)}
+    kappa2 = random.Random(seed).randrange(1, prove_ref.R)
+    return bool(prove_ref.verify_snark_pairing(points, scalars, ch, sp, crs_g1, pre_points, sigma2, a_eval, kappa2))

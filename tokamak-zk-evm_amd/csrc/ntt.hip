@@ -15,6 +15,7 @@
 #define TK_NTT_SYM_ROOT bls12_381_get_root_of_unity
 #define TK_NTT_SYM_INIT bls12_381_ntt_init_domain
 #define TK_NTT_SYM_RELEASE bls12_381_ntt_release_domain
+#define TK_NTT_SYM_DOMAIN_SIZE bls12_381_ntt_domain_size
 #define TK_NTT_SYM_NTT bls12_381_ntt
 #define TK_NTT_SYM_BINTT tkmk_bintt
 #include "ntt_impl.inc"

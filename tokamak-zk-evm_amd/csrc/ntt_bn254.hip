@@ -15,6 +15,7 @@
 #define TK_NTT_SYM_ROOT bn254_get_root_of_unity
 #define TK_NTT_SYM_INIT bn254_ntt_init_domain
 #define TK_NTT_SYM_RELEASE bn254_ntt_release_domain
+#define TK_NTT_SYM_DOMAIN_SIZE bn254_ntt_domain_size
 #define TK_NTT_SYM_NTT bn254_ntt
 #define TK_NTT_SYM_BINTT tkmk_bn254_bintt
 #include "ntt_impl.inc"

@@ -3,6 +3,7 @@
 // (e.g. packages/backend/libs/src/bivariate_polynomial/mod.rs:446-457, libs/src/utils/mod.rs:78-110).
 #include <stdlib.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -441,9 +442,13 @@ TK_API const char *tkmk_error_string(tkmk_error e) {
 TK_API int tkmk_is_hip_build(void) { return 1; }
 
 // ---- event profiler ----
+// Sections are bracketed by events recorded on the launch stream; nothing waits for them when they are recorded (a
+// synchronisation inside the pipelined MSM entry would serialise exactly the overlap being measured).  finish() parks the
+// events; tkmk_profile_get / _collect drain them after the device has gone idle.
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
 static std::map<std::string, std::pair<double, int>> g_prof;  // name -> (sum ms, count)
+static std::vector<std::vector<std::pair<std::string, hipEvent_t>>> g_prof_pending;
 
 tk_prof::tk_prof(hipStream_t stream) : s(stream), on(g_prof_on) {
     if (on) mark("");
@@ -460,15 +465,23 @@ void tk_prof::mark(const char *name) {
 }
 void tk_prof::finish() {
     if (!on || ev.size() < 2) return;
-    (void)hipEventSynchronize(ev.back().second);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (size_t i = 1; i < ev.size(); i++) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ev[i - 1].second, ev[i].second) != hipSuccess) continue;
-        auto &slot = g_prof[ev[i].first];
-        slot.first += ms;
-        slot.second += 1;
+    g_prof_pending.push_back(std::move(ev));
+    ev.clear();
+}
+static void prof_drain_locked() {
+    for (auto &list : g_prof_pending) {
+        if (!list.empty()) (void)hipEventSynchronize(list.back().second);
+        for (size_t i = 1; i < list.size(); i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, list[i - 1].second, list[i].second) != hipSuccess) continue;
+            auto &slot = g_prof[list[i].first];
+            slot.first += ms;
+            slot.second += 1;
+        }
+        for (auto &e : list) (void)hipEventDestroy(e.second);
     }
+    g_prof_pending.clear();
 }
 TK_API tkmk_error tkmk_profile_enable(int on) {
     g_prof_on = on != 0;
@@ -476,14 +489,37 @@ TK_API tkmk_error tkmk_profile_enable(int on) {
 }
 TK_API tkmk_error tkmk_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain_locked();
     g_prof.clear();
     return TKMK_SUCCESS;
 }
 TK_API tkmk_error tkmk_profile_get(const char *name, double *sum_ms, int *count) {
     if (!name || !sum_ms || !count) return TKMK_ERR_INVALID_POINTER;
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain_locked();
     auto it = g_prof.find(name);
     *sum_ms = it == g_prof.end() ? 0.0 : it->second.first;
     *count = it == g_prof.end() ? 0 : it->second.second;
     return TKMK_SUCCESS;
+}
+
+// ---- work counters: what the library was asked to do since the last reset (bench.py turns them into algorithmic bytes:
+// 128 B per MSM point, 64 B per NTT element) ----
+static std::atomic<uint64_t> g_stat[TK_STAT_COUNT];
+void tk_stat_add(int which, uint64_t v) {
+    if (which >= 0 && which < TK_STAT_COUNT) g_stat[which].fetch_add(v, std::memory_order_relaxed);
+}
+TK_API tkmk_error tkmk_stats_reset(void) {
+    for (auto &c : g_stat) c.store(0);
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_stats_get(const char *name, uint64_t *value) {
+    if (!name || !value) return TKMK_ERR_INVALID_POINTER;
+    static const char *names[TK_STAT_COUNT] = {"msm.points", "msm.calls", "ntt.elements", "ntt.calls"};
+    for (int i = 0; i < TK_STAT_COUNT; i++)
+        if (std::string(name) == names[i]) {
+            *value = g_stat[i].load();
+            return TKMK_SUCCESS;
+        }
+    return TKMK_ERR_INVALID_ARGUMENT;
 }

@@ -95,21 +95,17 @@ class DeviceVec {
 };
 
 // ---- NTT domain: global and grow-only, like init_ntt_domain_for_size (mod.rs:33-55) ----
-inline size_t &ntt_domain_size_cell() {
-    static size_t size = 0;
-    return size;
-}
 inline void init_ntt_domain_for_size(size_t size) {
     if (size == 0) throw Error("NTT domain size must be non-zero.");
     if (size & (size - 1)) throw Error("NTT domain size must be a power of two.");
-    size_t &cur = ntt_domain_size_cell();
+    uint64_t cur = 0;   // the library's own record (the domain is process-global; another host side may have grown it)
+    check(bls12_381_ntt_domain_size(&cur), "ntt::domain_size");
     if (cur >= size) return;
     if (cur) check(bls12_381_ntt_release_domain(), "ntt::release_domain");
     ScalarField root;
     check(bls12_381_get_root_of_unity(size, &root), "ntt::get_root_of_unity");
     tkmk_ntt_init_domain_config cfg{nullptr, false, nullptr};
     check(bls12_381_ntt_init_domain(&root, &cfg), "ntt::initialize_domain");
-    cur = size;
 }
 
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }

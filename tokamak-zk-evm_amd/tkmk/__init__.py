@@ -94,7 +94,8 @@ SYMBOLS = [
     "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_expr_eval", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
     "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini", "tkmk_r1cs_eval_rows",
     "tkmk_msm_multi_ex", "bls12_381_msm_convert_bases", "tkmk_r1cs_library_create", "tkmk_r1cs_library_destroy", "tkmk_r1cs_library_eval",
-    "tkmk_witness_route", "tkmk_fr_scatter_table", "tkmk_host_malloc", "tkmk_host_free",
+    "tkmk_witness_route", "tkmk_fr_scatter_table", "tkmk_host_malloc", "tkmk_host_free", "tkmk_stats_reset", "tkmk_stats_get",
+    "bls12_381_ntt_domain_size", "bn254_ntt_domain_size",
 ]
 
 
@@ -218,16 +219,23 @@ def init_ntt_domain_for_size(size, curve="bls12_381"):
     """grow-only global domain (one per scalar field), like init_ntt_domain_for_size (bivariate_polynomial/mod.rs:33-55)"""
     if size <= 0 or size & (size - 1):
         raise ValueError("NTT domain size must be a non-zero power of two")
-    have = _domain_size.get(curve)
-    if have is not None and have >= size:
+    have = ntt_domain_size(curve)              # the library's own record: another host side in this process may have grown it
+    if have >= size:
         return
-    if have is not None:
+    if have:
         release_ntt_domain(curve)
     root = get_root_of_unity(size, curve)
     cfg = NTTInitDomainConfig(None, False, None)
     sym = _NTT_SYMS[curve][1]
     _check(getattr(lib(), sym)(_p(root), ctypes.byref(cfg)), sym)
     _domain_size[curve] = size
+
+
+def ntt_domain_size(curve="bls12_381"):
+    v = ctypes.c_uint64()
+    sym = "bls12_381_ntt_domain_size" if curve == "bls12_381" else "bn254_ntt_domain_size"
+    _check(getattr(lib(), sym)(ctypes.byref(v)), sym)
+    return v.value
 
 
 def release_ntt_domain(curve="bls12_381"):
@@ -530,6 +538,20 @@ def profile_get(name):
     ms, cnt = ctypes.c_double(), ctypes.c_int()
     _check(lib().tkmk_profile_get(name.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "tkmk_profile_get")
     return ms.value, cnt.value
+
+
+def native_stats_reset():
+    _check(lib().tkmk_stats_reset(), "tkmk_stats_reset")
+
+
+def native_stats():
+    """work the library was asked to do since the last reset, counted inside the library (whichever host side called it)"""
+    out = {}
+    for name in ("msm.points", "msm.calls", "ntt.elements", "ntt.calls"):
+        v = ctypes.c_uint64()
+        _check(lib().tkmk_stats_get(name.encode(), ctypes.byref(v)), "tkmk_stats_get")
+        out[name] = v.value
+    return out
 
 
 def diag_field_mul(field, a, b):

@@ -184,8 +184,84 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
         "equals_python_prover": same}
 
 
+def stage_files(s_max=256, placements=None, pool=24, n_prv=3000, seed=0x746F6B616D616B04, tmp=None):
+    """everything `prove` reads, as files in the reference's formats: <tmp>/qap (subcircuit library), <tmp>/synth (the synthesizer's
+    three documents), <tmp>/crs/combined_sigma.tkcrs (the fixed-tau trusted setup of that circuit, generated on the device by
+    tkmk/setup.py).  -> dict(dirs, setup params, counts); the caller removes `tmp`"""
+    import synth_circuit
+    import tkmk
+    t = time.perf_counter()
+    inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=13, n_out=80, n_in=170, n_prv=n_prv, k_out=65, k_pub=20,
+                                  l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements, bit_fraction=0.6)
+    tmp = tempfile.mkdtemp(prefix="tkmk_prove_files_") if tmp is None else tmp
+    synth_circuit.write(inst, tmp)
+    gen_s = time.perf_counter() - t
+    t = time.perf_counter()
+    sigma_obj, _ = stage_crs(tkmk, inst)
+    tkmk.synchronize()
+    sigma_s = time.perf_counter() - t
+    t = time.perf_counter()
+    sigma_obj.write(os.path.join(tmp, "crs"))
+    del sigma_obj
+    tkmk.release_scratch()
+    sp = inst["setup_params"]
+    return {"tmp": tmp, "qap": inst["qap"], "synth": inst["synth"], "crs": os.path.join(tmp, "crs"), "setup_params": sp,
+            "constraint_slots": sp["n"] * sp["s_max"], "r1cs_rows": inst["r1cs_rows"], "placements": len(inst["placement_variables"]),
+            "generate_s": round(gen_s, 2), "sigma_gen_s": round(sigma_s, 2), "crs_write_s": round(time.perf_counter() - t, 2),
+            "crs_payload_bytes": os.path.getsize(os.path.join(tmp, "crs", "combined_sigma.tkcrs")),
+            "placement_variables_json_bytes": os.path.getsize(os.path.join(inst["synth"], "placementVariables.json")),
+            "permutation_json_bytes": os.path.getsize(os.path.join(inst["synth"], "permutation.json")),
+            "workload": "synthetic circuit n=%d m_I=%d s_max=%d, %d placements, %d real R1CS rows" % (
+                sp["n"], sp["l_D"] - sp["l"], sp["s_max"], len(inst["placement_variables"]), inst["r1cs_rows"])}
+
+
+def run_service(s_max=256, placements=None, pool=24, n_prv=3000, repeat=5, warmup=1, seed=0x746F6B616D616B04, check=False):
+    """the same workload through the resident prover (libtkmk_prover.so: host/tkmk_service.hpp): context opened once, then `repeat`
+    proofs from the synthesizer's files to proof.json; per-stage seconds are the library's own (median over the repeats)"""
+    import shutil
+    import statistics
+    import tkmk
+    from tkmk import service
+    files = stage_files(s_max, placements, pool, n_prv, seed)
+    try:
+        t = time.perf_counter()
+        p = service.Prover(files["qap"], files["crs"])
+        open_s = time.perf_counter() - t
+        out_dir = os.path.join(files["tmp"], "out")
+        runs = []
+        for rep in range(warmup + repeat):
+            tkmk.native_stats_reset()
+            t0 = time.perf_counter()
+            doc, tm = p.prove(files["synth"], out_dir, want_json=check and rep == 0)
+            tm["wall_s"] = time.perf_counter() - t0
+            tm.update(tkmk.native_stats())
+            if rep >= warmup:
+                runs.append(tm)
+        verified = None
+        if check:
+            verified = _verify_from_files(files, out_dir)
+        p.close()
+    finally:
+        shutil.rmtree(files["tmp"], ignore_errors=True)
+    med = {k: statistics.median(r[k] for r in runs) for k in runs[0]}
+    slots = files["constraint_slots"]
+    return {"workload": "resident prover (files in, proof.json out): " + files["workload"], "constraint_slots": slots, "r1cs_rows": files["r1cs_rows"],
+            "median": {k: round(v, 5) if isinstance(v, float) else v for k, v in med.items()}, "runs": runs, "open_context_s": round(open_s, 3),
+            "constraint_slots_per_s": round(slots / med["wall_s"]), "r1cs_rows_per_s": round(files["r1cs_rows"] / med["wall_s"]),
+            "init_fraction": round(med["init_s"] / med["wall_s"], 3), "verified_with_pairings": verified,
+            "files": {k: files[k] for k in ("crs_payload_bytes", "placement_variables_json_bytes", "permutation_json_bytes", "sigma_gen_s", "crs_write_s")}}
+
+
+def _verify_from_files(files, out_dir):
+    """the proof the service wrote, checked from public files alone with real pairings (tests/prove_ref.verify_snark_pairing)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import verify_files
+    return verify_files.verify(files["qap"], files["synth"], files["crs"], out_dir)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--service", action="store_true", help="time the resident prover (libtkmk_prover.so) on files")
     ap.add_argument("--native", action="store_true", help="time tokamak-zk-evm_amd/bin/prove on files instead of the Python prover")
     ap.add_argument("--compare", action="store_true", help="with --native: also check the binary's proof.json against the Python prover's")
     ap.add_argument("--s-max", type=int, default=256)
@@ -199,7 +275,9 @@ def main():
     args = ap.parse_args()
     import tkmk
     tkmk.set_device(0)
-    if args.native:
+    if args.service:
+        out = run_service(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, 1, args.seed, args.check)
+    elif args.native:
         out = run_native(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.seed, args.compare)
     else:
         out = run(args.s_max, args.placements, args.pool, args.n_prv, args.repeat, args.check, args.seed, args.profile_host)
