@@ -57,6 +57,17 @@ typedef struct { tkmk_fq x, y; } tkmk_g1_affine;          /* G1Affine  (96 B)  *
 typedef struct { tkmk_fq x, y, z; } tkmk_g1_projective;   /* G1Projective (144 B) */
 typedef void *tkmk_stream;                                /* IcicleStream handle (a hipStream_t) */
 
+/* THE ONE DECLARED CONVENTION THAT IS AN INFERENCE, NOT A PIN ("parity unpinned"): the generator g of the
+ * scalar field's two-adic subgroup, omega_{2^32} = g^((r-1)/2^32).  bls12_381_get_root_of_unity, the oracle, the Python
+ * restatements and the setup all derive their root of unity from THIS constant.  The reference takes the root from ICICLE
+ * (ntt::get_root_of_unity, libs/src/bivariate_polynomial/mod.rs:47-52; not in the tree).  5 = ffjavascript's rule (smallest
+ * quadratic non-residue), which the reference's browser prover / verifier use on the native prover's outputs;
+ * 7 = arkworks / zkcrypto's constant.  Both generate the subgroup and pass every self-consistency test; they order the domain
+ * differently, so a wrong choice is silent within this repository and fatal against a reference-made CRS.  If ICICLE's constant
+ * turns out to be 7^((r-1)/2^32): change this line (tests/test_root_convention.py proves the switch green), or set the
+ * environment variable TKMK_FR_ROOT_GENERATOR=7 for a process (the same variable is honoured by the oracle and the Python refs). */
+#define TKMK_BLS12_381_FR_ROOT_GENERATOR 5
+
 /* ---------------------------------------------------------------------------------------------
  * Device runtime — replaces icicle_runtime::{memory::DeviceVec, stream::IcicleStream, Device}
  * used at ~40 sites, e.g. libs/src/bivariate_polynomial/mod.rs:446-457,1661-1662;

@@ -5,6 +5,7 @@
  * Build: gcc -O2 -fopenmp -fPIC -shared (oracle/Makefile).
  */
 #include "tk_oracle.h"
+#include "../include/tkmk.h" /* only for TKMK_BLS12_381_FR_ROOT_GENERATOR: the one declared convention both sides must share */
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -186,7 +187,7 @@ static const u64 BNQ_MOD[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb
 
 static fq_t g1_CURVE_B;  /* curve constant 4 (Montgomery) */
 static bnq_t bn_CURVE_B; /* curve constant 3 (Montgomery) */
-static fr_t FR_ROOT32;   /* w_{2^32} = 5^((r-1)/2^32) (Montgomery) */
+static fr_t FR_ROOT32;   /* w_{2^32} = g^((r-1)/2^32) (Montgomery), g = TKMK_BLS12_381_FR_ROOT_GENERATOR (include/tkmk.h) */
 static bnr_t BNR_ROOT28; /* BN254: w_{2^28} = 5^((r-1)/2^28) (Montgomery) */
 
 static void tko_init(void) {
@@ -219,9 +220,16 @@ static void tko_init(void) {
             /* root of unity before publishing fr_ready */
             memcpy(fr_P.l, FR_MOD, sizeof fr_P.l);
             fr_init(FR_MOD);
+            /* the generator of the two-adic subgroup is the ONE declared convention of include/tkmk.h (an inference, not a pin:
+             * see the note there); the same environment variable as in the product selects another non-residue for a process */
             fr_t five;
             memset(&five, 0, sizeof five);
-            five.l[0] = 5;
+            five.l[0] = TKMK_BLS12_381_FR_ROOT_GENERATOR;
+            {
+                const char *env = getenv("TKMK_FR_ROOT_GENERATOR");
+                int v = env ? atoi(env) : 0;
+                if (v >= 2 && v < 65536) five.l[0] = (u64)v;
+            }
             fr_to_mont(&five, &five);
             /* (r-1) >> 32 */
             u64 e[4];

@@ -57,12 +57,12 @@ void hc_g1_scalar_mul(const uint8_t *k, const uint8_t *p, uint8_t *o) {
 #include "ntt_plan.h"
 
 extern "C" int hc_ntt(const uint8_t *in, uint32_t logn, uint64_t batch, int columns, int inverse, const uint8_t *coset,
-                      uint8_t *out, uint32_t max_logR, uint32_t log_tile, uint32_t logN) {
+                      uint8_t *out, uint32_t max_logR, uint32_t log_tile, uint32_t logN, const uint8_t *root32) {
     if (logN < logn || max_logR > log_tile) return -1;
     uint64_t N = 1ull << logN, n = 1ull << logn, total = n * batch;
     // domain
     fr_t w;
-    for (int i = 0; i < 8; i++) w.l[i] = bls12_381_fr_params::ROOT[i];
+    load<Fr>(w, root32);   // w_{2^32}, plain: the caller's (declared) root of unity, as bls12_381_ntt_init_domain takes it
     w = Fr::to_mont(w);
     for (uint32_t i = logN; i < 32; i++) w = Fr::sqr(w);
     std::vector<fr_t> tw(N);

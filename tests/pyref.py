@@ -5,7 +5,21 @@ on field ops, the G1 group law, the NTT definition and the MSM definition.
 """
 R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
-ROOT32 = pow(5, (R - 1) >> 32, R)
+
+
+def root_generator():
+    """the declared convention of include/tkmk.h (TKMK_BLS12_381_FR_ROOT_GENERATOR: an inference, not a pin), or the process-wide
+    override TKMK_FR_ROOT_GENERATOR that the product and the oracle honour as well"""
+    import os
+    import re
+    env = os.environ.get("TKMK_FR_ROOT_GENERATOR")
+    if env and 2 <= int(env) < 65536:
+        return int(env)
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tkmk.h")).read()
+    return int(re.search(r"#define\s+TKMK_BLS12_381_FR_ROOT_GENERATOR\s+(\d+)", hdr).group(1))
+
+
+ROOT32 = pow(root_generator(), (R - 1) >> 32, R)
 
 
 def root_of_unity(n):

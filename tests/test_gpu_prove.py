@@ -244,10 +244,12 @@ def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
     r = subprocess.run(cmd + ["--testing-mixer", mixer_path], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     assert "NOT zero-knowledge" in r.stderr                       # the testing hook announces itself
+    native_points, native_scalars = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
     # an inherited environment variable must not fix the blinding scalars (round-1 hook, removed): same command, fresh proof
     r_env = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TKMK_PROVE_MIXER=mixer_path))
     assert r_env.returncode == 0 and "NOT zero-knowledge" not in r_env.stderr
-    native_points, native_scalars = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
+    env_points, _ = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
+    assert not (np.asarray(env_points["U"]) == np.asarray(native_points["U"])).all()
 
     prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, sigma=sigma)
     points, scalars, _, _, _ = run_rounds(prover, binding)

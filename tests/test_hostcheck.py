@@ -78,8 +78,9 @@ def test_g1_templates(hc, oracle):
 
 def _hc_ntt(hc, x, logn, batch, columns, inverse, coset, max_logR, log_tile, logN):
     out = np.empty_like(x)
+    import oracle
     rc = hc.hc_ntt(_p(x), logn, ctypes.c_uint64(batch), int(columns), int(inverse), _p(coset) if coset is not None else None,
-                   _p(out), max_logR, log_tile, logN)
+                   _p(out), max_logR, log_tile, logN, _p(oracle.root_of_unity(1 << 32)))
     assert rc > 0
     return out, rc
 

@@ -1,6 +1,7 @@
 // ntt.hip — BLS12-381 scalar-field instantiation of the NTT (ntt_impl.inc) behind bls12_381_ntt*, tkmk_bintt: the field of
 // the reference (every committed .r1cs carries this prime; packages/backend/libs/src/bivariate_polynomial/mod.rs:33-55,1422-1478).
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <map>
 #include <mutex>
@@ -18,4 +19,6 @@
 #define TK_NTT_SYM_DOMAIN_SIZE bls12_381_ntt_domain_size
 #define TK_NTT_SYM_NTT bls12_381_ntt
 #define TK_NTT_SYM_BINTT tkmk_bintt
+#define TK_NTT_ROOT_GENERATOR TKMK_BLS12_381_FR_ROOT_GENERATOR
+#define TK_NTT_ROOT_GENERATOR_ENV "TKMK_FR_ROOT_GENERATOR"
 #include "ntt_impl.inc"

@@ -2,6 +2,7 @@
 // reference has no BN254 path; BASELINE.json's configs[0] names a BN254 scalar-field NTT, so the same
 // kernels are instantiated over the 254-bit field (two-adicity 28, w_{2^28} = 5^((r-1)/2^28) as the library's own root).
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <map>
 #include <mutex>
@@ -18,4 +19,5 @@
 #define TK_NTT_SYM_DOMAIN_SIZE bn254_ntt_domain_size
 #define TK_NTT_SYM_NTT bn254_ntt
 #define TK_NTT_SYM_BINTT tkmk_bn254_bintt
+#define TK_NTT_ROOT_GENERATOR 5
 #include "ntt_impl.inc"

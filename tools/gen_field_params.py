@@ -188,10 +188,7 @@ def main():
         if "two_adicity" in f:
             s = f["two_adicity"]
             assert (p - 1) % (1 << s) == 0 and pow(f["qnr"], (p - 1) // 2, p) == p - 1
-            w = pow(f["qnr"], (p - 1) >> s, p)
-            out.append("    static constexpr int TWO_ADICITY = %d;" % s)
-            out.append("    // w_{2^%d} = %d^((p-1)/2^%d), plain form" % (s, f["qnr"], s))
-            out.append("    static constexpr uint32_t ROOT[%d] = {%s};" % (n, limbs(w, n)))
+            out.append("    static constexpr int TWO_ADICITY = %d;   // the 2^%d-th root of unity is derived at run time from the declared generator (csrc/ntt_impl.inc)" % (s, s))
         out.extend(gen_unsat(name, p, f.get("wu", WU_DEFAULT), f.get("lu")))
         out.append("#if defined(__HIP_DEVICE_COMPILE__)")
         out.append("    // r = a*b/2^(32N) in [0, 2p): product-scanning Montgomery product, 1 v_mad_u64_u32 + 1 v_addc_co_u32")
