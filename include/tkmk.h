@@ -243,6 +243,13 @@ tkmk_error bls12_381_ntt(const tkmk_fr *input, int size, tkmk_ntt_dir dir, const
 tkmk_error tkmk_bintt(const tkmk_fr *input, size_t x_size, size_t y_size, tkmk_ntt_dir dir,
                       const tkmk_fr *coset_x, const tkmk_fr *coset_y, bool on_device,
                       tkmk_stream stream, tkmk_fr *output);
+/* Forward _biNTT of the zero-padded extension of a compact in_x x in_y coefficient matrix to x_size x y_size (powers of two,
+ * in_x <= x_size, in_y <= y_size) without materialising the padding — replaces `resize` + `_biNTT` in to_rou_evals, _mul and the
+ * fused evaluator's leaves (libs/src/bivariate_polynomial/mod.rs:1646-1674, 1920-1960, 459-502): the row pass runs over the
+ * in_x existing rows only and the column pass reads the absent rows as zeros.  Same result as tkmk_bintt on the resized
+ * matrix, bit for bit.  Device pointers; output must not alias input. */
+tkmk_error tkmk_bintt_padded(const tkmk_fr *input, size_t in_x, size_t in_y, size_t x_size, size_t y_size, const tkmk_fr *coset_x,
+                             const tkmk_fr *coset_y, tkmk_stream stream, tkmk_fr *output);
 
 /* ---------------------------------------------------------------------------------------------
  * Vector ops — replaces icicle_core::vec_ops::VecOps<ScalarField> (extern "C" bls12_381_vector_add, …)
@@ -382,6 +389,14 @@ tkmk_error tkmk_poly_eval(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y
  * quo_x is x_size x y_size, quo_y is c x y_size */
 tkmk_error tkmk_poly_div_by_vanishing_opt(const tkmk_fr *p_dev, uint32_t x_size, uint32_t y_size, uint32_t c, uint32_t d,
                                           tkmk_fr *quo_x_dev, tkmk_fr *quo_y_dev, tkmk_stream stream);
+/* Fused linear combination — poly_comb! (prove/src/lib.rs:30-38) and the operator chains the prover builds from `&a * &scalar`,
+ * `&a + &b`, `&a - &b` and mul_monomial (libs/src/bivariate_polynomial/mod.rs:532-1281, 1820-1844), which in the reference cost one
+ * pass and one temporary per operator: out (out_xs x out_ys, fully written) = sum_t coeffs[t] * X^off_x[t] Y^off_y[t] * polys[t],
+ * one pass, every operand read once.  polys[t]: x_sizes[t] x y_sizes[t] coefficient matrix on the device; coeffs: host scalars;
+ * off_x / off_y may be NULL; every shifted operand must fit into out; out must not alias an operand. */
+tkmk_error tkmk_poly_lincomb(uint32_t n_terms, const tkmk_fr *coeffs_host, const tkmk_fr *const *polys_dev, const uint32_t *x_sizes,
+                             const uint32_t *y_sizes, const uint32_t *off_x, const uint32_t *off_y, tkmk_fr *out_dev, uint32_t out_xs,
+                             uint32_t out_ys, tkmk_stream stream);
 /* div_by_ruffini (mod.rs:2412-2477): P = Q_X (X - x) + Q_Y (Y - y) + r; q_x is x_size x y_size, q_y has y_size elements */
 tkmk_error tkmk_poly_div_by_ruffini(const tkmk_fr *p_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, const tkmk_fr *y,
                                     tkmk_fr *q_x_dev, tkmk_fr *q_y_dev, tkmk_fr *r_host, tkmk_stream stream);

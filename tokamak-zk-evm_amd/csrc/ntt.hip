@@ -19,6 +19,7 @@
 #define TK_NTT_SYM_DOMAIN_SIZE bls12_381_ntt_domain_size
 #define TK_NTT_SYM_NTT bls12_381_ntt
 #define TK_NTT_SYM_BINTT tkmk_bintt
+#define TK_NTT_SYM_BINTT_PADDED tkmk_bintt_padded
 #define TK_NTT_ROOT_GENERATOR TKMK_BLS12_381_FR_ROOT_GENERATOR
 #define TK_NTT_ROOT_GENERATOR_ENV "TKMK_FR_ROOT_GENERATOR"
 #include "ntt_impl.inc"

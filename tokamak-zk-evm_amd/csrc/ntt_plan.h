@@ -36,6 +36,11 @@ struct ntt_pass_t {
     uint32_t logN;     // twiddle domain
     uint32_t groups;   // columns layout: ceil(batch / T)
     uint64_t tiles;    // grid size
+    // zero-padded input (first pass of a job only; 0 = the input is a full vector): positions >= in_len read as zero
+    // without touching memory, and with in_compact the vectors are stored 2^in_logn apart instead of 2^logn (row layout)
+    uint64_t in_len;
+    uint32_t in_logn;
+    uint32_t in_compact;
 };
 
 struct ntt_line_t {
@@ -113,6 +118,9 @@ static inline ntt_pass_t ntt_make_pass(uint32_t logn, uint64_t batch, bool colum
     p.last = k == passes - 1;
     p.batch = batch;
     p.logN = logN;
+    p.in_len = 0;
+    p.in_logn = logn;
+    p.in_compact = 0;
     uint64_t T = 1ull << p.logT, J = 1ull << (logn - logR[k]);
     if (columns) {
         p.groups = (uint32_t)((batch + T - 1) / T);

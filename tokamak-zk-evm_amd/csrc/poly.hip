@@ -51,6 +51,36 @@ __global__ __launch_bounds__(256) void k_place(const fr_t *__restrict__ src, uin
     }
 }
 
+// ---- fused linear combination: out = sum_t c_t * shift(p_t, ox_t, oy_t), every operand read once, out written once ----
+// The reference's poly_comb! (prove/src/lib.rs:30-38) and the operator chains around it (&a * &s, &a + &b, mul_monomial:
+// libs/src/bivariate_polynomial/mod.rs:532-1281, 1820-1844) cost one full pass and one temporary of the OUTPUT size per operator;
+// a 6-term combination is ~35 passes over 2^22..2^25 elements.  Here it is one pass.
+#define LC_MAX_TERMS 16
+struct lincomb_args_t {
+    const fr_t *p[LC_MAX_TERMS];
+    fr_t c[LC_MAX_TERMS];                     // Montgomery form (plain * Montgomery -> plain)
+    uint32_t xs[LC_MAX_TERMS], ys[LC_MAX_TERMS], ox[LC_MAX_TERMS], oy[LC_MAX_TERMS];
+    uint8_t kind[LC_MAX_TERMS];               // 0: c * p, 1: + p, 2: - p  (unit coefficients skip the product)
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void k_lincomb(lincomb_args_t a, fr_t *__restrict__ out, uint32_t dx, uint32_t dy) {
+    uint64_t total = (uint64_t)dx * dy;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t i = (uint32_t)(e / dy), j = (uint32_t)(e - (uint64_t)i * dy);
+        fr_t acc = Fr::zero();
+        for (uint32_t t = 0; t < a.n; t++) {
+            uint32_t ii = i - a.ox[t], jj = j - a.oy[t];      // unsigned wrap makes "below the offset" fail the range test too
+            if (ii < a.xs[t] && jj < a.ys[t]) {
+                fr_t v = Fr::canon(tk_load(a.p[t] + (uint64_t)ii * a.ys[t] + jj));
+                if (a.kind[t] == 1) acc = Fr::add(acc, v);
+                else if (a.kind[t] == 2) acc = Fr::sub(acc, v);
+                else acc = Fr::add(acc, Fr::mul(v, a.c[t]));
+            }
+        }
+        tk_store(out + e, acc);
+    }
+}
+
 // pw[i] = g^i (Montgomery), i < n
 __global__ __launch_bounds__(256) void k_powers(fr_t *__restrict__ out, fr_t g, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,6 +313,63 @@ TK_API tkmk_error tkmk_poly_place(const tkmk_fr *src_dev, uint32_t sx, uint32_t 
     hipLaunchKernelGGL(k_place, stream_grid((uint64_t)dx * dy), 256, 0, s, (const fr_t *)src_dev, sx, sy, (fr_t *)dst_dev, dx, dy, off_x,
                        off_y);
     TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
+
+// out (out_xs x out_ys, fully written) = sum_t coeffs[t] * X^off_x[t] Y^off_y[t] * polys[t]; polys[t] is an x_sizes[t] x y_sizes[t]
+// coefficient matrix; a shifted operand must fit: x_sizes[t] + off_x[t] <= out_xs (same for y).  coeffs are HOST scalars (plain);
+// off_x / off_y may be NULL (no shifts).  `out` must not alias an operand.  More than LC_MAX_TERMS terms are folded in groups.
+TK_API tkmk_error tkmk_poly_lincomb(uint32_t n_terms, const tkmk_fr *coeffs_host, const tkmk_fr *const *polys_dev, const uint32_t *x_sizes,
+                                    const uint32_t *y_sizes, const uint32_t *off_x, const uint32_t *off_y, tkmk_fr *out_dev, uint32_t out_xs,
+                                    uint32_t out_ys, tkmk_stream stream) {
+    if (!out_dev || (n_terms && (!coeffs_host || !polys_dev || !x_sizes || !y_sizes))) return TKMK_ERR_INVALID_POINTER;
+    if (!out_xs || !out_ys) return TKMK_ERR_INVALID_ARGUMENT;
+    for (uint32_t t = 0; t < n_terms; t++) {
+        if (!polys_dev[t]) return TKMK_ERR_INVALID_POINTER;
+        if (polys_dev[t] == out_dev) return TKMK_ERR_INVALID_ARGUMENT;
+        uint64_t ox = off_x ? off_x[t] : 0, oy = off_y ? off_y[t] : 0;
+        if (!x_sizes[t] || !y_sizes[t] || x_sizes[t] + ox > out_xs || y_sizes[t] + oy > out_ys) return TKMK_ERR_INVALID_ARGUMENT;
+    }
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    if (n_terms == 0) {
+        TK_HIP(hipMemsetAsync(out_dev, 0, (size_t)out_xs * out_ys * sizeof(fr_t), s));
+        return TKMK_SUCCESS;
+    }
+    fr_t one = Fr::zero(), minus_one;
+    one.l[0] = 1;
+    minus_one = Fr::from_mont(Fr::neg(Fr::to_mont(one)));
+    tk_frame frame(s);
+    tk_scratch partial;   // only when the terms do not fit one launch
+    const fr_t *carry = nullptr;
+    for (uint32_t first = 0; first < n_terms;) {
+        lincomb_args_t a;
+        a.n = 0;
+        if (carry) {      // the sum so far re-enters as a unit-coefficient term
+            a.p[0] = carry, a.xs[0] = out_xs, a.ys[0] = out_ys, a.ox[0] = a.oy[0] = 0, a.kind[0] = 1, a.c[0] = Fr::zero();
+            a.n = 1;
+        }
+        while (first < n_terms && a.n < LC_MAX_TERMS) {
+            fr_t c = Fr::canon(fr_in(coeffs_host + first));
+            uint32_t k = a.n++;
+            a.p[k] = (const fr_t *)polys_dev[first];
+            a.xs[k] = x_sizes[first], a.ys[k] = y_sizes[first];
+            a.ox[k] = off_x ? off_x[first] : 0, a.oy[k] = off_y ? off_y[first] : 0;
+            a.kind[k] = Fr::eq(c, one) ? 1 : Fr::eq(c, minus_one) ? 2 : 0;
+            a.c[k] = Fr::to_mont(c);
+            first++;
+        }
+        fr_t *dst = (fr_t *)out_dev;
+        if (first < n_terms) {   // more groups follow: accumulate in scratch, alternate so that no launch reads what it writes
+            tk_scratch nxt;
+            TK_TRY(nxt.alloc((size_t)out_xs * out_ys * sizeof(fr_t), s));
+            dst = nxt.as<fr_t>();
+            partial = nxt;
+        }
+        hipLaunchKernelGGL(k_lincomb, stream_grid((uint64_t)out_xs * out_ys), 256, 0, s, a, dst, out_xs, out_ys);
+        TK_HIP(hipGetLastError());
+        carry = dst;
+    }
     return TKMK_SUCCESS;
 }
 

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -163,6 +164,19 @@ class DensePolynomialExt {
         if (evals.len() < x_size * y_size) throw Error("Insufficient buffer length for to_rou_evals");
         check(tkmk_bintt(poly.ptr(), x_size, y_size, TKMK_NTT_FORWARD, coset_x, coset_y, true, nullptr, evals.ptr()), "_biNTT");
     }
+    // evaluations of this polynomial on the xs x ys domain: `resize` + forward _biNTT of the reference (mod.rs:1646-1674, 1920-1960),
+    // without materialising the zero padding when the matrix is smaller than the domain (tkmk_bintt_padded)
+    DeviceVec<ScalarField> evals_on(size_t xs, size_t ys) const {
+        if (x_size <= xs && y_size <= ys) {
+            DeviceVec<ScalarField> out(xs * ys);
+            check(tkmk_bintt_padded(poly.ptr(), x_size, y_size, xs, ys, nullptr, nullptr, nullptr, out.ptr()), "_biNTT");
+            return out;
+        }
+        DensePolynomialExt r = clone();   // larger than the domain in one direction: resize drops the (zero) excess first
+        r.resize(xs, ys);
+        check(tkmk_bintt(r.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, r.poly.ptr()), "_biNTT");
+        return std::move(r.poly);
+    }
     DensePolynomialExt clone() const { return DensePolynomialExt(poly.clone(), x_size, y_size, x_degree, y_degree); }
     std::vector<ScalarField> copy_coeffs() const { return poly.to_host(); }
     ScalarField get_coeff(uint64_t ix, uint64_t iy) const {
@@ -258,6 +272,31 @@ class DensePolynomialExt {
         check(bls12_381_scalar_mul_vec(&s, out.poly.ptr(), out.poly.len(), &c, out.poly.ptr()), "scalar_mul");
         return from_coeffs(std::move(out.poly), out.x_size, out.y_size);
     }
+    // sum_t c_t * X^ox_t Y^oy_t * p_t in ONE pass (tkmk_poly_lincomb): poly_comb! and the `&a * &s`, `&a + &b`, mul_monomial chains
+    // around it (prove/src/lib.rs:30-124), which cost one pass and one temporary per operator when evaluated step by step
+    struct Term {
+        ScalarField c;
+        const DensePolynomialExt *p;
+        uint32_t ox = 0, oy = 0;
+        Term(const ScalarField &c_, const DensePolynomialExt *p_, uint32_t ox_ = 0, uint32_t oy_ = 0) : c(c_), p(p_), ox(ox_), oy(oy_) {}
+    };
+    static DensePolynomialExt lincomb(const std::vector<Term> &terms) {
+        if (terms.empty()) return zero();
+        size_t nx = 1, ny = 1;
+        std::vector<ScalarField> c;
+        std::vector<const tkmk_fr *> ptr;
+        std::vector<uint32_t> xs, ys, ox, oy;
+        for (const Term &t : terms) {
+            nx = std::max(nx, next_pow2(t.p->x_size + t.ox)), ny = std::max(ny, next_pow2(t.p->y_size + t.oy));
+            c.push_back(t.c), ptr.push_back(t.p->poly.ptr());
+            xs.push_back((uint32_t)t.p->x_size), ys.push_back((uint32_t)t.p->y_size), ox.push_back(t.ox), oy.push_back(t.oy);
+        }
+        DeviceVec<ScalarField> out(nx * ny);
+        check(tkmk_poly_lincomb((uint32_t)terms.size(), c.data(), ptr.data(), xs.data(), ys.data(), ox.data(), oy.data(), out.ptr(), (uint32_t)nx, (uint32_t)ny,
+                                nullptr),
+              "tkmk_poly_lincomb");
+        return from_coeffs(std::move(out), nx, ny);
+    }
     // _mul (mod.rs:1846-1996)
     friend DensePolynomialExt operator*(const DensePolynomialExt &a, const DensePolynomialExt &b) {
         auto [lx, ly] = a.find_degree();
@@ -270,15 +309,11 @@ class DensePolynomialExt {
             return one * b.get_coeff(0, 0);
         }
         size_t tx = (size_t)(lx + rx + 1), ty = (size_t)(ly + ry + 1);
-        DensePolynomialExt l = a.clone(), r = b.clone();
-        l.resize(tx, ty);
-        r.resize(tx, ty);
-        size_t xs = l.x_size, ys = l.y_size;
-        check(tkmk_bintt(l.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, l.poly.ptr()), "_biNTT");
-        check(tkmk_bintt(r.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, r.poly.ptr()), "_biNTT");
+        auto [xs, ys] = find_size_as_twopower(tx, ty);
+        DeviceVec<ScalarField> le = a.evals_on(xs, ys), re = b.evals_on(xs, ys);
         tkmk_vecops_config c = dev_cfg();
-        check(bls12_381_vector_mul(l.poly.ptr(), r.poly.ptr(), l.poly.len(), &c, l.poly.ptr()), "mul");
-        return from_rou_evals(l.poly, xs, ys);
+        check(bls12_381_vector_mul(le.ptr(), re.ptr(), le.len(), &c, le.ptr()), "mul");
+        return from_rou_evals(le, xs, ys);
     }
 
     // div_by_vanishing_opt (mod.rs:2284-2410)
@@ -418,10 +453,7 @@ class PolyExpr {
     static std::shared_ptr<DeviceVec<ScalarField>> leaf_evals(const DensePolynomialExt *leaf, size_t xs, size_t ys, LeafCache &cache) {
         auto it = cache.find(leaf);
         if (it == cache.end()) {
-            DensePolynomialExt r = leaf->clone();
-            r.resize(xs, ys);
-            check(tkmk_bintt(r.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, r.poly.ptr()), "_biNTT");
-            it = cache.emplace(leaf, std::make_shared<DeviceVec<ScalarField>>(std::move(r.poly))).first;
+            it = cache.emplace(leaf, std::make_shared<DeviceVec<ScalarField>>(leaf->evals_on(xs, ys))).first;
         }
         return it->second;
     }

@@ -164,19 +164,10 @@ struct ProverInputs {   // the documents Prover::init reads (lib.rs:679-835)
 namespace prover_detail {
 
 using Poly = DensePolynomialExt;
-using Term = std::pair<ScalarField, const Poly *>;
+using Term = Poly::Term;   // {coefficient, polynomial, X shift, Y shift}
 
-// poly_comb! (lib.rs:30-38)
-inline Poly poly_comb(std::initializer_list<Term> terms) {
-    Poly acc;
-    bool first = true;
-    for (const Term &t : terms) {
-        Poly p = *t.second * t.first;
-        if (first) acc = std::move(p), first = false;
-        else acc = acc + p;
-    }
-    return acc;
-}
+// poly_comb! (lib.rs:30-38): sum of c_i * p_i — one fused pass over the operands (tkmk_poly_lincomb)
+inline Poly poly_comb(std::initializer_list<Term> terms) { return Poly::lincomb(std::vector<Term>(terms)); }
 inline Poly sparse(const std::vector<std::pair<size_t, ScalarField>> &entries, size_t xs, size_t ys) {
     std::vector<ScalarField> c(xs * ys);
     for (auto &e : entries) c.at(e.first) = e.second;
@@ -205,23 +196,27 @@ inline Poly unit_evals(size_t size, size_t index, bool x_axis) {   // the Lagran
     return x_axis ? Poly::from_rou_evals(d, size, 1) : Poly::from_rou_evals(d, 1, size);
 }
 // &poly + &scalar / &poly - &scalar (bivariate_polynomial/mod.rs:1042-1116, 1189-1262): only coefficient (0,0) changes
+inline void add_const_in_place(Poly &p, const ScalarField &s) {
+    ScalarField c0 = fr_add(p.get_coeff(0, 0), s);
+    check(tkmk_memcpy_h2d(p.poly.ptr(), &c0, sizeof c0), "memcpy_h2d");
+}
 inline Poly add_const(const Poly &p, const ScalarField &s) {
     Poly out = p.clone();
-    ScalarField c0 = fr_add(out.get_coeff(0, 0), s);
-    check(tkmk_memcpy_h2d(out.poly.ptr(), &c0, sizeof c0), "memcpy_h2d");
+    add_const_in_place(out, s);
     return out;
 }
 inline Poly sub_const(const Poly &p, const ScalarField &s) { return add_const(p, fr_neg(s)); }
-inline Poly mul_by_x_minus_one(const Poly &p) { return p.mul_monomial(1, 0) - p; }
-inline Poly mul_by_one_minus_x(const Poly &p) { return p - p.mul_monomial(1, 0); }
+// the small products of lib.rs:70-124 as shifted terms of one fused pass (X * p = p shifted by one row, Y * p = by one column)
+inline Poly mul_by_x_minus_one(const Poly &p) { return Poly::lincomb({Term(fr_one(), &p, 1, 0), Term(fr_neg(fr_one()), &p)}); }
+inline Poly mul_by_one_minus_x(const Poly &p) { return Poly::lincomb({Term(fr_one(), &p), Term(fr_neg(fr_one()), &p, 1, 0)}); }
 inline Poly mul_by_linear(const Poly &p, const std::array<ScalarField, 2> &c, bool x_axis) {   // lib.rs:80-94
-    return p * c[0] + (x_axis ? p.mul_monomial(1, 0) : p.mul_monomial(0, 1)) * c[1];
+    return Poly::lincomb({Term(c[0], &p), x_axis ? Term(c[1], &p, 1, 0) : Term(c[1], &p, 0, 1)});
 }
-inline Poly mul_by_term9(const Poly &p, const std::array<ScalarField, 2> &rB_X, const std::array<ScalarField, 2> &rB_Y,
-                         const ScalarField &t_mi_eval, const ScalarField &t_smax_eval) {   // lib.rs:96-124
+// terms of mul_by_term9 (lib.rs:96-124): (constant + cx X + cy Y) * p
+inline std::vector<Term> term9(const Poly &p, const std::array<ScalarField, 2> &rB_X, const std::array<ScalarField, 2> &rB_Y,
+                               const ScalarField &t_mi_eval, const ScalarField &t_smax_eval) {
     ScalarField constant = fr_add(fr_mul(t_mi_eval, rB_X[0]), fr_mul(t_smax_eval, rB_Y[0]));
-    Poly partial = p * constant + p.mul_monomial(1, 0) * fr_mul(t_mi_eval, rB_X[1]);
-    return partial + p.mul_monomial(0, 1) * fr_mul(t_smax_eval, rB_Y[1]);
+    return {Term(constant, &p), Term(fr_mul(t_mi_eval, rB_X[1]), &p, 1, 0), Term(fr_mul(t_smax_eval, rB_Y[1]), &p, 0, 1)};
 }
 // several equally long linear combinations of G1 points in one batched MSM call (G1serde `+`, `-`, `* scalar`)
 inline std::vector<G1Affine> g1_lincombs(const std::vector<std::vector<std::pair<ScalarField, G1Affine>>> &rows) {
@@ -325,11 +320,16 @@ class Prover {
         ScalarField zero{};
         Poly X_mono = Poly::from_coeffs(std::vector<ScalarField>{zero, fr_one()}, 2, 1);
         Poly Y_mono = Poly::from_coeffs(std::vector<ScalarField>{zero, fr_one()}, 1, 2);
-        Poly f = add_const((bXY + s0XY * th[0]) + s1XY * th[1], th[2]);
-        Poly g = add_const((bXY + X_mono * th[0]) + Y_mono * th[1], th[2]);
+        Poly f = Poly::lincomb({Term(fr_one(), &bXY), Term(th[0], &s0XY), Term(th[1], &s1XY)});
+        Poly g = Poly::lincomb({Term(fr_one(), &bXY), Term(th[0], &X_mono), Term(th[1], &Y_mono)});
+        add_const_in_place(f, th[2]);
+        add_const_in_place(g, th[2]);
         return {std::move(f), std::move(g)};
     }
-    Poly blinded_R() const { return rXY + (t_mi * mixer.rR_X + t_smax * mixer.rR_Y); }
+    Poly blinded_R() const {
+        using namespace prover_detail;
+        return poly_comb({{fr_one(), &rXY}, {mixer.rR_X, &t_mi}, {mixer.rR_Y, &t_smax}});
+    }
     Poly blinded_V() const {
         using namespace prover_detail;
         return poly_comb({{fr_one(), &vXY}, {mixer.rV_X, &t_n}, {mixer.rV_Y, &t_smax}});
@@ -349,13 +349,13 @@ class Prover {
         Poly UXY = poly_comb({{one, &uXY}, {mx.rU_X, &t_n}, {mx.rU_Y, &t_smax}});
         Poly VXY = blinded_V();
         w_zk.reset(new Poly(low_degree_times_vanishing(mx.rW_X, n, true) + low_degree_times_vanishing(mx.rW_Y, s_max, false)));
-        Poly WXY = wXY + *w_zk;
+        Poly WXY = poly_comb({{one, &wXY}, {one, w_zk.get()}});
         Poly Q_AX_XY = poly_comb({{one, &q0XY}, {mx.rU_X, &vXY}, {mx.rV_X, &uXY}, {minus_one, &rW_X}, {fr_mul(mx.rU_X, mx.rV_X), &t_n},
                                   {fr_mul(mx.rU_Y, mx.rV_X), &t_smax}});
         Poly Q_AY_XY = poly_comb({{one, &q1XY}, {mx.rU_Y, &vXY}, {mx.rV_Y, &uXY}, {minus_one, &rW_Y}, {fr_mul(mx.rU_X, mx.rV_Y), &t_n},
                                   {fr_mul(mx.rU_Y, mx.rV_Y), &t_smax}});
         term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
-        Poly BXY = bXY + *term_b_zk;
+        Poly BXY = poly_comb({{one, &bXY}, {one, term_b_zk.get()}});
         auto c = sigma->sigma1.encode_polys({&UXY, &VXY, &WXY, &Q_AX_XY, &Q_AY_XY, &BXY});
         return Proof0{c[0], c[1], c[2], c[3], c[4], c[5]};
     }
@@ -407,14 +407,19 @@ class Prover {
         Poly p_comb = E::weighted_sum(std::move(terms)).evaluate_fused_with_domain(4 * m_i, 2 * s_max);
         auto q23 = p_comb.div_by_vanishing_opt((int64_t)m_i, (int64_t)s_max);
         q2XY = std::move(q23.first), q3XY = std::move(q23.second);
-        Poly r_D1 = rXY - r_omegaX, r_D2 = rXY - r_omegaX_omegaY, g_D = gXY - fXY;
+        ScalarField minus_one = fr_neg(one);
+        Poly r_D1 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX}}), r_D2 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX_omegaY}});
+        Poly g_D = poly_comb({{one, &gXY}, {minus_one, &fXY}});
 
         auto q_c = [&](const Poly &quot, const std::array<ScalarField, 2> &rB, const ScalarField &rR, bool x_axis) {
-            Poly d1_comb = mul_by_linear(r_D1, rB, x_axis) + g_D * rR;
-            Poly d2_comb = mul_by_linear(r_D2, rB, x_axis) + g_D * rR;
-            Poly xm1_d1 = mul_by_x_minus_one(d1_comb);
+            // d_comb = (rB[0] + rB[1] T) * r_D + rR * g_D with T = X or Y (mul_by_linear, lib.rs:80-94), in one pass each
+            auto d_comb = [&](const Poly &r_D) {
+                return Poly::lincomb({Term(rB[0], &r_D), x_axis ? Term(rB[1], &r_D, 1, 0) : Term(rB[1], &r_D, 0, 1), Term(rR, &g_D)});
+            };
+            Poly d1_comb = d_comb(r_D1), d2_comb = d_comb(r_D2);
             Poly k0_d2 = K0 * d2_comb;
-            return poly_comb({{one, &quot}, {rR, &KL}, {kappa0, &xm1_d1}, {kappa0_sq, &k0_d2}});
+            // kappa0 * (X - 1) * d1_comb enters as two shifted terms
+            return Poly::lincomb({Term(one, &quot), Term(rR, &KL), Term(kappa0, &d1_comb, 1, 0), Term(fr_neg(kappa0), &d1_comb), Term(kappa0_sq, &k0_d2)});
         };
         Poly Q_CX_XY = q_c(q2XY, mx.rB_X, mx.rR_X, true);
         Poly Q_CY_XY = q_c(q3XY, mx.rB_Y, mx.rR_Y, false);
@@ -449,7 +454,8 @@ class Prover {
         Poly rW_X = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_X.begin(), mx.rW_X.end()), 4, 1);
         Poly rW_Y = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_Y.begin(), mx.rW_Y.end()), 1, 4);
         if (!w_zk) w_zk.reset(new Poly(low_degree_times_vanishing(mx.rW_X, n, true) + low_degree_times_vanishing(mx.rW_Y, s_max, false)));
-        Poly V_minus = sub_const(blinded_V(), proof3.V_eval);
+        Poly V_minus = blinded_V();
+        add_const_in_place(V_minus, fr_neg(proof3.V_eval));
         Poly pA_XY = poly_comb({{kappa1, &V_minus},
                                 {small_v_eval, &uXY},
                                 {minus_one, &wXY},
@@ -486,15 +492,21 @@ class Prover {
                                 {fr_mul(kappa0_sq, K0_eval), &term6},
                                 {fr_neg(t_mi_eval), &q2XY},
                                 {fr_neg(t_s_max_eval), &q3XY}});
-        Poly r_D1 = rXY - r_omegaX, r_D2 = rXY - r_omegaX_omegaY;
+        Poly r_D1 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX}}), r_D2 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX_omegaY}});
         ScalarField r_D1_eval = ev(r_D1), r_D2_eval = ev(r_D2);
         if (!term_b_zk) term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
-        Poly g_minus_f = gXY - fXY;
-        Poly term10 = g_minus_f * fr_add(fr_mul(mx.rR_X, t_mi_eval), fr_mul(mx.rR_Y, t_s_max_eval));
-        Poly r_d1_t = mul_by_term9(r_D1, mx.rB_X, mx.rB_Y, t_mi_eval, t_s_max_eval) + term10;
-        Poly one_minus_x_times = mul_by_one_minus_x(r_d1_t);
-        Poly LHS_zk1 = poly_comb({{fr_mul(chi_m1, r_D1_eval), term_b_zk.get()}, {one, &one_minus_x_times}, {chi_m1, &term10}});
-        Poly r_d2_t = mul_by_term9(r_D2, mx.rB_X, mx.rB_Y, t_mi_eval, t_s_max_eval) + term10;
+        // term10 = (rR_X t_mi(chi) + rR_Y t_smax(zeta)) * (g - f)
+        ScalarField c10 = fr_add(fr_mul(mx.rR_X, t_mi_eval), fr_mul(mx.rR_Y, t_s_max_eval));
+        Poly term10 = poly_comb({{c10, &gXY}, {fr_neg(c10), &fXY}});
+        auto with_term10 = [&](const Poly &r_D) {   // mul_by_term9(r_D) + term10 (lib.rs:96-124), one pass
+            std::vector<Term> t = term9(r_D, mx.rB_X, mx.rB_Y, t_mi_eval, t_s_max_eval);
+            t.emplace_back(one, &term10);
+            return Poly::lincomb(t);
+        };
+        Poly r_d1_t = with_term10(r_D1);
+        // (1 - X) * r_d1_t enters LHS_zk1 as two shifted terms
+        Poly LHS_zk1 = Poly::lincomb({Term(fr_mul(chi_m1, r_D1_eval), term_b_zk.get()), Term(one, &r_d1_t), Term(minus_one, &r_d1_t, 1, 0), Term(chi_m1, &term10)});
+        Poly r_d2_t = with_term10(r_D2);
         Poly k0_r_d2_t = K0 * r_d2_t;
         Poly LHS_zk2 = poly_comb({{fr_mul(K0_eval, r_D2_eval), term_b_zk.get()}, {K0_eval, &term10}, {minus_one, &k0_r_d2_t}});
         Poly R_minus_eval = sub_const(RXY, proof3.R_eval);

@@ -95,7 +95,7 @@ SYMBOLS = [
     "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini", "tkmk_r1cs_eval_rows",
     "tkmk_msm_multi_ex", "bls12_381_msm_convert_bases", "tkmk_r1cs_library_create", "tkmk_r1cs_library_destroy", "tkmk_r1cs_library_eval",
     "tkmk_witness_route", "tkmk_fr_scatter_table", "tkmk_host_malloc", "tkmk_host_free", "tkmk_stats_reset", "tkmk_stats_get",
-    "bls12_381_ntt_domain_size", "bn254_ntt_domain_size",
+    "bls12_381_ntt_domain_size", "bn254_ntt_domain_size", "tkmk_poly_lincomb", "tkmk_bintt_padded",
 ]
 
 
@@ -236,6 +236,15 @@ def ntt_domain_size(curve="bls12_381"):
     sym = "bls12_381_ntt_domain_size" if curve == "bls12_381" else "bn254_ntt_domain_size"
     _check(getattr(lib(), sym)(ctypes.byref(v)), sym)
     return v.value
+
+
+def bintt_padded(a, in_x, in_y, x_size, y_size, coset_x=None, coset_y=None, out=None):
+    """forward _biNTT of the zero-padded extension of the compact in_x x in_y matrix `a` (DeviceBuffer) to x_size x y_size"""
+    STATS["ntt_elements"] += int(x_size) * int(y_size)
+    out = DeviceBuffer(32 * x_size * y_size) if out is None else out
+    _check(lib().tkmk_bintt_padded(_p(a), ctypes.c_size_t(in_x), ctypes.c_size_t(in_y), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size),
+                                   _p(coset_x), _p(coset_y), None, _p(out)), "tkmk_bintt_padded")
+    return out
 
 
 def release_ntt_domain(curve="bls12_381"):
