@@ -122,3 +122,33 @@ def test_full_domain_sizes(dom, oracle):
     for k in (0, 1, 12345, n - 1):
         want = (pow(w, k, oracle.R_MOD) + 2 * pow(w, 5 * k, oracle.R_MOD)) % oracle.R_MOD
         assert oracle.to_ints(X[32 * k:32 * k + 32].copy(), 32)[0] == want
+
+
+@pytest.mark.parametrize("in_x,in_y,xs,ys", [(4, 8, 16, 16), (1, 16, 64, 16), (16, 1, 16, 128), (32, 32, 32, 32), (8, 512, 4096, 1024), (256, 64, 1024, 64),
+                                             (64, 256, 64, 1024), (1, 1, 1, 1), (1, 4, 1, 4096), (8, 1, 2048, 1), (2, 2, 8192, 2048), (512, 128, 2048, 512)])
+def test_bintt_padded_equals_bintt_of_the_resized_matrix(gpu, oracle, in_x, in_y, xs, ys):
+    """tkmk_bintt_padded (row pass over the existing rows only, absent rows / columns read as zeros) == the oracle's _biNTT of the
+    explicitly zero-padded matrix — what resize + _biNTT of the reference computes (bivariate_polynomial/mod.rs:1646-1674)"""
+    gpu.init_ntt_domain_for_size(max(xs * ys, 4))
+    a = np.asarray(oracle.fr_random(4000 + in_x * 7 + in_y, in_x * in_y)).reshape(in_x, in_y, 32)
+    padded = np.zeros((xs, ys, 32), np.uint8)
+    padded[:in_x, :in_y] = a
+    d = gpu.DeviceBuffer.from_host(np.ascontiguousarray(a.reshape(-1)))
+    for cx, cy in ((None, None), (oracle.fr_random(9, 1), oracle.fr_random(10, 1))):
+        want = np.asarray(oracle.bintt(np.ascontiguousarray(padded.reshape(-1)), xs, ys, coset_x=cx, coset_y=cy))
+        got = np.asarray(gpu.bintt_padded(d, in_x, in_y, xs, ys, coset_x=cx, coset_y=cy).to_host())
+        assert (got == want).all(), (cx is not None)
+    # the output buffer may hold anything beforehand (rows past in_x of the intermediate are never written and never read)
+    out = gpu.DeviceBuffer.from_host(np.full(32 * xs * ys, 0xAB, np.uint8))
+    got = np.asarray(gpu.bintt_padded(d, in_x, in_y, xs, ys, out=out).to_host())
+    assert (got == np.asarray(oracle.bintt(np.ascontiguousarray(padded.reshape(-1)), xs, ys))).all()
+
+
+def test_bintt_padded_refuses_bad_shapes(gpu):
+    gpu.init_ntt_domain_for_size(1 << 10)
+    d = gpu.DeviceBuffer(32 * 64)
+    for args in ((8, 8, 4, 8), (8, 8, 8, 4), (3, 8, 8, 8), (8, 8, 8, 24)):
+        with pytest.raises(gpu.TkmkError):
+            gpu.bintt_padded(d, *args)
+    with pytest.raises(gpu.TkmkError):
+        gpu.bintt_padded(d, 8, 8, 8, 8, out=d)      # in place is not possible: the operand is compact

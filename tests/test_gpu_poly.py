@@ -327,3 +327,33 @@ def test_expr_one_pass_kernel(P, gpu, oracle):
     for _ in range(8):
         want = B + want
     assert (deep.evaluate_fused_with_domain(xs, ys).copy_coeffs() == want.copy_coeffs()).all()
+
+
+def test_poly_lincomb_fused_pass(gpu, oracle):
+    """tkmk_poly_lincomb == sum of c_t X^ox Y^oy p_t computed with Python integers: operands of different shapes, shifts, the
+    unit / minus-one fast paths, zero coefficients, more terms than one launch holds, and the refusals"""
+    import random
+    rnd = random.Random(12)
+    R = oracle.R_MOD
+    out_xs, out_ys = 32, 16
+    shapes = [(32, 16, 0, 0), (8, 16, 3, 0), (16, 4, 0, 12), (1, 1, 31, 15), (4, 8, 28, 8), (32, 1, 0, 7), (1, 16, 9, 0)]
+    for n_terms in (1, 3, 7, 16, 17, 40):
+        terms, dense = [], [[0] * out_ys for _ in range(out_xs)]
+        for t in range(n_terms):
+            xs, ys, ox, oy = shapes[t % len(shapes)]
+            vals = [rnd.randrange(R) for _ in range(xs * ys)]
+            c = rnd.choice([1, R - 1, 0, rnd.randrange(R), rnd.randrange(R)])
+            buf = gpu.DeviceBuffer.from_host(np.asarray(oracle.to_bytes(vals, 32)))
+            terms.append((np.asarray(oracle.to_bytes([c], 32)), buf, xs, ys, ox, oy))
+            for i in range(xs):
+                for j in range(ys):
+                    dense[i + ox][j + oy] = (dense[i + ox][j + oy] + c * vals[i * ys + j]) % R
+        got = oracle.to_ints(np.asarray(gpu.poly_lincomb(terms, out_xs, out_ys).to_host()), 32)
+        assert got == [v for row in dense for v in row], n_terms
+    zero = gpu.poly_lincomb([], 4, 4).to_host()
+    assert not np.asarray(zero).any()
+    buf = gpu.DeviceBuffer.from_host(np.zeros(32 * 64, np.uint8))
+    one = np.asarray(oracle.to_bytes([1], 32))
+    for bad in ([(one, buf, 8, 8, 1, 0)], [(one, buf, 8, 8, 0, 1)], [(one, buf, 16, 4)]):     # a shifted operand must fit into out
+        with pytest.raises(gpu.TkmkError):
+            gpu.poly_lincomb(bad, 8, 8)

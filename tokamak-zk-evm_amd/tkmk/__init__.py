@@ -549,6 +549,19 @@ def profile_get(name):
     return ms.value, cnt.value
 
 
+def poly_lincomb(terms, out_xs, out_ys):
+    """terms = [(coefficient (32-byte array), DeviceBuffer, x_size, y_size[, off_x, off_y])] -> DeviceBuffer holding
+    sum_t c_t X^ox Y^oy p_t as an out_xs x out_ys coefficient matrix (tkmk_poly_lincomb: one fused pass)"""
+    n = len(terms)
+    coeffs = np.ascontiguousarray(np.concatenate([np.asarray(t[0], np.uint8).reshape(32) for t in terms])) if n else np.zeros(32, np.uint8)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[_p(t[1]).value for t in terms])
+    arr = lambda k, d: (ctypes.c_uint32 * max(n, 1))(*[(t[k] if len(t) > k else d) for t in terms])   # noqa: E731
+    out = DeviceBuffer(32 * out_xs * out_ys)
+    _check(lib().tkmk_poly_lincomb(n, _p(coeffs), ptrs, arr(2, 1), arr(3, 1), arr(4, 0), arr(5, 0), _p(out), int(out_xs), int(out_ys), None),
+           "tkmk_poly_lincomb")
+    return out
+
+
 def native_stats_reset():
     _check(lib().tkmk_stats_reset(), "tkmk_stats_reset")
 
