@@ -384,6 +384,7 @@ def _ntt_secondary(tkmk):
 def _msm_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch):
     """BASELINE.json configs[4]'s shape: every rank holds 2^logn points of one MSM (generated in HBM from the seed), runs the full
     single-GPU pipeline on its shard, the 144-byte partial results meet in ONE all_gather (RCCL over xGMI) and every rank adds them"""
+    from tkmk import dist as tkdist
     from tkmk import sharding
     n = 1 << logn
     scalars = tkmk.fr_random_device(SEED + 2 + 16 * rank, n)
@@ -391,12 +392,16 @@ def _msm_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch)
     g = np.frombuffer(bytes(_generator()), np.uint8).copy()
     bases = tkmk.g1_batch_scalar_mul_device(h, g, n)
     h.free()
-    sharding.msm_sharded(tkmk, dist, scalars, bases, device=comm_device)
+    # the C-ABI entry (libtkmk_dist.so: RCCL all_gather on device buffers) when the ranks talk over RCCL; the torch helper for the
+    # gloo rehearsal of the same partitioning
+    comm = tkdist.comm_from_torch(dist) if comm_device == "cuda" else None
+    run = (lambda: comm.msm_sharded(scalars, bases)) if comm is not None else (lambda: sharding.msm_sharded(tkmk, dist, scalars, bases, device=comm_device))
+    run()
     barrier()
     steps = 3
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = sharding.msm_sharded(tkmk, dist, scalars, bases, device=comm_device)
+        res = run()
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=comm_device)
@@ -404,7 +409,10 @@ def _msm_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch)
     dt = float(tt.item()) / steps
     scalars.free()
     bases.free()
+    if comm is not None:
+        comm.close()
     return {"workload": "2^%d-point BLS12-381 G1 MSM, 2^%d points per rank, one all_gather of 144-byte partial results" % (logn + (world - 1).bit_length(), logn),
+            "entry": "tkmk_msm_sharded (C ABI, RCCL on device buffers)" if comm_device == "cuda" else "tkmk/sharding.py over torch.distributed (%s)" % comm_device,
             "ms_per_msm": dt * 1e3, "points_per_s": n * world / dt, "result_x_lo": int.from_bytes(bytes(res[:8]), "little")}
 
 

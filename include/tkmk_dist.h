@@ -1,0 +1,50 @@
+/* tkmk_dist.h — C ABI of libtkmk_dist.so: the two sub-paths that shard across the GPUs of one node, for a host
+ * in any language (one process per GPU).  The reference is single-device (device index 0 everywhere:
+ * packages/backend/libs/src/utils/mod.rs:88-110), so there is no reference interface to replace; the entry points take the same
+ * operands as their single-GPU twins in tkmk.h (bls12_381_msm, tkmk_bintt) plus a communicator.
+ *
+ * Collectives run through RCCL (xGMI between the GPUs of a node) on DEVICE buffers — nothing is staged through the host around
+ * them.  The communicator is bootstrapped like NCCL's: rank 0 calls tkmk_comm_unique_id, hands the 128 bytes to the other ranks
+ * over any channel the host already has (a file, MPI, torch.distributed, a socket), and every rank calls tkmk_comm_init.
+ *
+ * WHY all_gather + add and not a "bucket-sum reduce": RCCL has no reduction operator over 1152-bit group elements, and reducing
+ * the 16 x 2^15 bucket sets of every rank (100 MB per GPU) would move 10^5 times more data than the 144-byte partial RESULTS
+ * for the same answer (the MSM sum is associative: sum over ranks of (sum over the rank's points)).  Each rank therefore runs the
+ * whole single-GPU pipeline on its shard and only the partial results meet: one ncclAllGather of 144 bytes per rank. */
+#ifndef TKMK_DIST_H
+#define TKMK_DIST_H
+#include "tkmk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tkmk_comm tkmk_comm;
+#define TKMK_COMM_ID_BYTES 128
+
+tkmk_error tkmk_comm_unique_id(uint8_t id[TKMK_COMM_ID_BYTES]);                 /* rank 0 only */
+/* collective over all ranks; uses the calling thread's current device (tkmk_set_device) */
+tkmk_error tkmk_comm_init(const uint8_t id[TKMK_COMM_ID_BYTES], int world_size, int rank, tkmk_comm **out);
+tkmk_error tkmk_comm_destroy(tkmk_comm *comm);
+int tkmk_comm_rank(const tkmk_comm *comm);
+int tkmk_comm_size(const tkmk_comm *comm);
+const char *tkmk_dist_last_error(void);
+
+/* One MSM whose points are sharded over the ranks: this rank holds msm_size points (scalars / bases as in bls12_381_msm, host or
+ * device per cfg).  Every rank gets the full result (canonical projective, host).  Exchange: ONE ncclAllGather of the 144-byte
+ * partial results (device to device), then every rank adds the world_size partials. */
+tkmk_error tkmk_msm_sharded(tkmk_comm *comm, const tkmk_fr *scalars, const tkmk_g1_affine *bases, int msm_size, const tkmk_msm_config *cfg,
+                            tkmk_g1_projective *result);
+
+/* One x_size x y_size bivariate NTT sharded over the ranks (both sizes multiples of world_size).
+ *   in : this rank's x-slab, rows [rank * x_size / G, (rank + 1) * x_size / G) of the matrix (element (ix, iy) at ix * y_size + iy): device
+ *   out: this rank's y-slab, ALL rows, columns [rank * y_size / G, (rank + 1) * y_size / G), row-major x_size x (y_size / G): device
+ * Rows (length y_size, coset_y) are transformed locally, ONE ncclAllToAll moves block (rows of r) x (columns of q) to rank q,
+ * columns (length x_size, coset_x) are transformed locally.  dir / cosets as tkmk_bintt.  in_slab_dev is overwritten. */
+tkmk_error tkmk_bintt_sharded(tkmk_comm *comm, tkmk_fr *in_slab_dev, size_t x_size, size_t y_size, tkmk_ntt_dir dir, const tkmk_fr *coset_x,
+                              const tkmk_fr *coset_y, tkmk_fr *out_slab_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -28,6 +28,24 @@ def test_library_exports_every_declared_symbol(tkmk):
     assert lib.tkmk_is_hip_build() == 1
 
 
+def test_prover_and_dist_libraries_export_their_headers(tkmk):
+    """libtkmk_prover.so / libtkmk_dist.so load on a box without a GPU and export every symbol include/tkmk_prover.h /
+    include/tkmk_dist.h declare; without a device the entry points fail loudly (TKMK_ERR_NO_DEVICE), they do not fall back"""
+    import ctypes
+    from tkmk import dist, service
+    for mod, header in ((service, "tkmk_prover.h"), (dist, "tkmk_dist.h")):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        declared = sorted(set(re.findall(r"\b(tkmk_[a-z0-9_]+)\s*\(", hdr)))
+        assert declared == sorted(mod.SYMBOLS), header
+        for name in declared:
+            assert hasattr(mod.lib(), name), name
+    if tkmk.device_count() == 0:
+        h = ctypes.c_void_p()
+        assert service.lib().tkmk_prover_open(b"/nonexistent", b"/nonexistent", ctypes.byref(h)) == 12
+        assert dist.lib().tkmk_comm_init((ctypes.c_uint8 * 128)(), 1, 0, ctypes.byref(h)) == 12
+
+
 def test_config_defaults_match_icicle(tkmk):
     m = tkmk.lib().tkmk_msm_default_config()
     assert (m.precompute_factor, m.c, m.bitsize, m.batch_size, m.are_points_shared_in_batch) == (1, 0, 0, 1, True)

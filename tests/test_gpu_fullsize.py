@@ -1,0 +1,120 @@
+"""gpu tier: the FULL-SIZE prove configurations, end to end, checked with what scales.
+
+  production shape   n = 4096, m_I = 4096, s_max = 256, 166 placements   (packages/frontend/qap-compiler/subcircuits/library/setupParams.json;
+                     the run behind the reference's published walls)
+  BASELINE configs[3] n = 4096, m_I = 4096, s_max = 1024, every placement  (the "2^22-constraint circuit", SURVEY.md section 8d cfg 4)
+
+on synthetic satisfying circuits in the reference's file formats (tools/synth_circuit.py), CRS = the fixed-tau trusted setup of the
+circuit.  The exponent restatement (tests/prove_ref.py) cannot run at these sizes, so the checks are the size-independent ones:
+  * the proof the resident native prover writes VERIFIES from its files alone with real pairings (tests/verify_files.py: the combined
+    equation of verify-rust/src/lib.rs:198-352 on proof.json + preprocess.json + instance.json + the CRS file), and is rejected when
+    a public input is changed;
+  * the Python prover run with testing_mode=True passes every assertion of the reference's `testing-mode` feature at full size
+    (R1CS satisfaction of u*v = w, Lemma 3 / copy constraints, quotient identities at a random point, zero Ruffini remainders:
+    prove/src/lib.rs:916-1019, 1472-1545, 2591-2600, 3087-3096) and three of its commitments equal [P(tau_x, tau_y)]G (the commit
+    identity of setup/trusted-setup/src/main.rs:236-246);
+  * the native prover and that Python prover produce the SAME proof.json for the same blinding scalars (production shape)."""
+import json
+import os
+import random
+import shutil
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def production_files(gpu):
+    import prove_bench
+    files = prove_bench.stage_files(s_max=256, placements=166)
+    yield files
+    shutil.rmtree(files["tmp"], ignore_errors=True)
+
+
+def _hex_mixer(mixer, path):
+    hx = lambda v: [hx(e) for e in v] if isinstance(v, list) else "0x%x" % v          # noqa: E731
+    json.dump({k: hx(v) for k, v in mixer.items()}, open(path, "w"))
+    return path
+
+
+def test_production_shape_native_proof_verifies_with_pairings(gpu, production_files):
+    import verify_files
+    from tkmk import service
+    f = production_files
+    assert f["constraint_slots"] == 1 << 20 and f["placements"] == 166
+    out = os.path.join(f["tmp"], "out")
+    with service.Prover(f["qap"], f["crs"]) as p:
+        _, tm = p.prove(f["synth"], out, want_json=False)
+    assert tm["init_s"] < tm["total_s"]
+    assert verify_files.verify(f["qap"], f["synth"], f["crs"], out)
+    assert not verify_files.verify(f["qap"], f["synth"], f["crs"], out, tamper_public_input=True)
+
+
+def test_production_shape_python_testing_mode_commit_identity_and_equality_with_native(gpu, production_files):
+    import prove_bench
+    from tkmk import crs as crsmod
+    from tkmk import proofio, service
+    from tkmk.prove import Prover, fr, random_mixer, run_rounds
+    f = production_files
+    sp = f["setup_params"]
+    sections = crsmod.read_payload(os.path.join(f["crs"], "combined_sigma.tkcrs"))
+    sigma1, tables = crsmod.load_sigma1(sections, sp)
+    singles = {k: np.array(crsmod.single_g1(sections, k)) for k in ("delta", "eta")}
+    mixer = random_mixer(random.Random(2024))
+    prover, binding = Prover.init(f["qap"], f["synth"], None, mixer=mixer, testing_mode=True, sigma=(sigma1, tables, singles))   # Lemma 3 etc. inside
+    points, scalars, _, _, _ = run_rounds(prover, binding)                                                                      # the other assertions inside
+    g = np.array(crsmod.single_g1(sections, "G"))
+    mx = prover.mixer
+    for name, poly in (("B", prover.bXY + prover.cache["term_b_zk"]),
+                       ("R", prover.rXY + (prover.t_mi.mul_scalar(fr(mx["rR_X"])) + prover.t_smax.mul_scalar(fr(mx["rR_Y"])))),
+                       ("A_free", prover.a_free_X)):
+        want = gpu.projective_to_affine_bytes(gpu.msm(poly.eval(fr(prove_bench.TAU_X), fr(prove_bench.TAU_Y)), g))
+        assert (np.asarray(points[name]) == np.asarray(want)).all(), "commit identity fails for " + name
+    del prover
+    want_doc = proofio.format_proof(points, scalars)
+    mixer_path = _hex_mixer(mixer, os.path.join(f["tmp"], "mixer.json"))
+    with service.Prover(f["qap"], f["crs"]) as p:
+        doc, _ = p.prove(f["synth"], None, testing_mixer_json=mixer_path)
+    assert doc == want_doc
+
+
+def test_configs3_native_proof_verifies_with_pairings_and_commit_identity(gpu):
+    """BASELINE.json configs[3]: 2^22 constraint slots, 1024 placements (the bench.py headline workload)"""
+    import prove_bench
+    import verify_files
+    from tkmk import crs as crsmod
+    from tkmk import proofio, service
+    from tkmk.prove import Prover, fr, random_mixer, run_rounds
+    files = prove_bench.stage_files(s_max=1024)
+    try:
+        assert files["constraint_slots"] == 1 << 22 and files["placements"] == 1024
+        out = os.path.join(files["tmp"], "out")
+        mixer = random_mixer(random.Random(4096))
+        mixer_path = _hex_mixer(mixer, os.path.join(files["tmp"], "mixer.json"))
+        with service.Prover(files["qap"], files["crs"]) as p:
+            doc, tm = p.prove(files["synth"], out, testing_mixer_json=mixer_path)
+        assert verify_files.verify(files["qap"], files["synth"], files["crs"], out)
+        assert not verify_files.verify(files["qap"], files["synth"], files["crs"], out, tamper_public_input=True)
+        # the Python prover with the reference's testing-mode assertions on the same inputs and blinding scalars: same proof,
+        # and three commitments equal [P(tau)]G
+        sections = crsmod.read_payload(os.path.join(files["crs"], "combined_sigma.tkcrs"))
+        sigma1, tables = crsmod.load_sigma1(sections, files["setup_params"])
+        singles = {k: np.array(crsmod.single_g1(sections, k)) for k in ("delta", "eta")}
+        prover, binding = Prover.init(files["qap"], files["synth"], None, mixer=mixer, testing_mode=True, sigma=(sigma1, tables, singles))
+        points, scalars, _, _, _ = run_rounds(prover, binding)
+        assert proofio.format_proof(points, scalars) == doc
+        g = np.array(crsmod.single_g1(sections, "G"))
+        mx = prover.mixer
+        for name, poly in (("B", prover.bXY + prover.cache["term_b_zk"]),
+                           ("R", prover.rXY + (prover.t_mi.mul_scalar(fr(mx["rR_X"])) + prover.t_smax.mul_scalar(fr(mx["rR_Y"])))),
+                           ("A_free", prover.a_free_X)):
+            want = gpu.projective_to_affine_bytes(gpu.msm(poly.eval(fr(prove_bench.TAU_X), fr(prove_bench.TAU_Y)), g))
+            assert (np.asarray(points[name]) == np.asarray(want)).all(), "commit identity fails for " + name
+        del prover
+    finally:
+        shutil.rmtree(files["tmp"], ignore_errors=True)
+        gpu.release_scratch()

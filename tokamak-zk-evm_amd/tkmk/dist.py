@@ -1,0 +1,92 @@
+"""ctypes binding of libtkmk_dist.so (include/tkmk_dist.h): the sharded MSM / bivariate NTT over RCCL on device buffers, one
+process per GPU.  The communicator id (128 bytes from rank 0) travels over whatever channel the host has; with torch.distributed
+that is one broadcast_object_list (comm_from_torch).  The torch-based helpers of tkmk/sharding.py remain for the CPU (gloo)
+rehearsal of the same partitioning."""
+import ctypes
+import os
+
+import numpy as np
+
+import tkmk
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libtkmk_dist.so")
+_lib = None
+
+# every symbol include/tkmk_dist.h declares (tests/test_abi.py checks the library exports all of them)
+SYMBOLS = ["tkmk_comm_unique_id", "tkmk_comm_init", "tkmk_comm_destroy", "tkmk_comm_rank", "tkmk_comm_size", "tkmk_dist_last_error",
+           "tkmk_msm_sharded", "tkmk_bintt_sharded"]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libtkmk_dist.so is not built (run __graft_entry__.build())")
+        tkmk.lib()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.tkmk_dist_last_error.restype = ctypes.c_char_p
+        _lib.tkmk_comm_destroy.argtypes = [ctypes.c_void_p]
+        _lib.tkmk_comm_rank.argtypes = [ctypes.c_void_p]
+        _lib.tkmk_comm_size.argtypes = [ctypes.c_void_p]
+    return _lib
+
+
+class DistError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__("%s failed: %s (tkmk_error %d)" % (where, lib().tkmk_dist_last_error().decode(), code))
+
+
+def _check(code, where):
+    if code != 0:
+        raise DistError(code, where)
+
+
+def unique_id():
+    buf = (ctypes.c_uint8 * 128)()
+    _check(lib().tkmk_comm_unique_id(buf), "tkmk_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    def __init__(self, comm_id, world, rank):
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_uint8 * 128)(*comm_id)
+        _check(lib().tkmk_comm_init(buf, int(world), int(rank), ctypes.byref(h)), "tkmk_comm_init")
+        self._h = h
+        self.world, self.rank = world, rank
+
+    def msm_sharded(self, scalars, bases, n=None):
+        """this rank's shard (host arrays or DeviceBuffers) -> the full result, 144-byte canonical projective, on every rank"""
+        cfg = tkmk.lib().tkmk_msm_default_config()
+        cfg.are_scalars_on_device, cfg.are_points_on_device = tkmk._on_dev(scalars), tkmk._on_dev(bases)
+        n = tkmk._len(scalars) if n is None else n
+        out = np.empty(144, np.uint8)
+        _check(lib().tkmk_msm_sharded(self._h, tkmk._p(scalars), tkmk._p(bases), int(n), ctypes.byref(cfg), tkmk._p(out)), "tkmk_msm_sharded")
+        return out
+
+    def bintt_sharded(self, slab, x_size, y_size, inverse=False, coset_x=None, coset_y=None):
+        """slab: DeviceBuffer with this rank's x-slab (overwritten) -> DeviceBuffer with this rank's y-slab"""
+        out = tkmk.DeviceBuffer(32 * x_size * (y_size // self.world))
+        _check(lib().tkmk_bintt_sharded(self._h, tkmk._p(slab), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size), 1 if inverse else 0,
+                                        tkmk._p(coset_x), tkmk._p(coset_y), tkmk._p(out)), "tkmk_bintt_sharded")
+        return out
+
+    def close(self):
+        if self._h:
+            lib().tkmk_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_from_torch(dist):
+    """communicator over the ranks of an initialised torch.distributed group: rank 0's id goes out in one broadcast"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    box = [unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return Comm(box[0], world, rank)
