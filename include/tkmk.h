@@ -74,11 +74,19 @@ typedef void *tkmk_stream;                                /* IcicleStream handle
  * libs/src/utils/mod.rs:78-110 (check_device); libs/src/vector_operations/mod.rs:484-549.
  * --------------------------------------------------------------------------------------------- */
 tkmk_error tkmk_device_count(int *count);                 /* is_device_available */
-tkmk_error tkmk_set_device(int device_id);                /* icicle_runtime::set_device (id is 0 in the reference) */
+/* icicle_runtime::set_device (id is 0 in the reference: libs/src/utils/mod.rs:88-110).  The library's state (scratch arenas,
+ * allocation cache, NTT domain, internal streams) lives on ONE device, the one current when the first entry point runs: call this
+ * first to choose it.  A later call naming another device returns TKMK_ERR_INVALID_DEVICE — one process per GPU (tkmk_dist.h). */
+tkmk_error tkmk_set_device(int device_id);
+/* the verdict tkmk_set_device would give for (device the library is bound to or -1, requested device, devices present): no device
+ * is touched — lets a host (and the not-gpu tests) check the rule */
+tkmk_error tkmk_diag_device_switch(int bound_device, int requested_device, int device_count);
 tkmk_error tkmk_get_available_memory(size_t *total, size_t *free_bytes); /* get_available_memory */
 tkmk_error tkmk_malloc(void **ptr, size_t bytes);         /* DeviceVec::device_malloc */
 tkmk_error tkmk_malloc_async(void **ptr, size_t bytes, tkmk_stream s);
-tkmk_error tkmk_free(void *ptr);                          /* Drop for DeviceVec */
+/* Drop for DeviceVec.  The block goes to a reuse cache and is handed out again only after everything queued before this call has
+ * finished — on the default stream AND on every stream made by tkmk_stream_create (no stream is named here, as in Drop). */
+tkmk_error tkmk_free(void *ptr);
 tkmk_error tkmk_free_async(void *ptr, tkmk_stream s);
 tkmk_error tkmk_memcpy_h2d(void *dst, const void *src, size_t bytes);   /* copy_from_host */
 tkmk_error tkmk_memcpy_d2h(void *dst, const void *src, size_t bytes);   /* copy_to_host   */

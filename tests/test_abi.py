@@ -46,6 +46,18 @@ def test_prover_and_dist_libraries_export_their_headers(tkmk):
         assert dist.lib().tkmk_comm_init((ctypes.c_uint8 * 128)(), 1, 0, ctypes.byref(h)) == 12
 
 
+def test_library_state_is_bound_to_one_device(tkmk):
+    """tkmk_set_device's rule (csrc/runtime.hip): free choice before the first entry point has bound the library, the bound device
+    again afterwards, TKMK_ERR_INVALID_DEVICE for any other — the arenas / allocation cache / NTT domain are per process, not per
+    device (a host that hops devices like ICICLE's set_device allows would get device-0 scratch on device 1)"""
+    v = tkmk.lib().tkmk_diag_device_switch
+    assert v(-1, 0, 8) == 0 and v(-1, 5, 8) == 0          # nothing bound yet: any present device
+    assert v(3, 3, 8) == 0                                 # re-selecting the bound device
+    assert v(0, 1, 8) == 1 and v(3, 0, 8) == 1             # TKMK_ERR_INVALID_DEVICE: state lives on another device
+    assert v(-1, 8, 8) == 1 and v(-1, -1, 8) == 1          # not a device
+    assert v(-1, 0, 0) == 12 and v(0, 0, 0) == 12          # TKMK_ERR_NO_DEVICE
+
+
 def test_config_defaults_match_icicle(tkmk):
     m = tkmk.lib().tkmk_msm_default_config()
     assert (m.precompute_factor, m.c, m.bitsize, m.batch_size, m.are_points_shared_in_batch) == (1, 0, 0, 1, True)

@@ -82,3 +82,52 @@ def test_strided_copy_and_allocation_cache(gpu, oracle):
     assert c.to_host(16).size == 16
     with pytest.raises(gpu.TkmkError):
         gpu.DeviceBuffer(1 << 50)                             # absurd size: OUT_OF_MEMORY / ALLOCATION_FAILED, not a crash
+
+
+def test_free_then_reuse_waits_for_work_on_caller_streams(gpu, oracle):
+    """tkmk_free names no stream (Drop for DeviceVec): a block released while a kernel queued on a tkmk_stream_create stream is still
+    using it must not be handed to the next tkmk_malloc before that kernel is done — the reuse cache orders the hand-out behind
+    every caller stream (csrc/runtime.hip).  Also the regression test of the allocator's own free-list reuse for the
+    stale-data failure characterised in tools/coherence_test.hip: what the new owner reads is what the last writer wrote.
+    One pass, no repetition."""
+    lib = gpu.lib()
+    st = ctypes.c_void_p()
+    gpu._check(lib.tkmk_stream_create(ctypes.byref(st)), "tkmk_stream_create")
+    try:
+        n = 1 << 22                                              # 128 MiB operands: the queued work takes a while
+        gpu.init_ntt_domain_for_size(n)
+        x = oracle.fr_random(31, 1 << 12)
+        tile = np.tile(np.asarray(x), n >> 12)
+        src = gpu.DeviceBuffer.from_host(tile)
+        ncfg = lib.tkmk_ntt_default_config()
+        ncfg.stream_handle = st
+        ncfg.are_inputs_on_device = ncfg.are_outputs_on_device = True
+        ncfg.is_async = True
+        ncfg.batch_size = n >> 12
+        vcfg = lib.tkmk_vecops_default_config()
+        vcfg.stream_handle = st
+        vcfg.is_a_on_device = vcfg.is_b_on_device = vcfg.is_result_on_device = True
+        vcfg.is_async = True
+        victim = gpu.DeviceBuffer(32 * n)
+        result = gpu.DeviceBuffer(32 * n)
+        # stream st: victim = NTT rows(src); a few dependent passes over victim; result = victim * victim   (all asynchronous)
+        gpu._check(lib.bls12_381_ntt(gpu._p(src), 1 << 12, 0, ctypes.byref(ncfg), gpu._p(victim)), "bls12_381_ntt")
+        for _ in range(6):
+            gpu._check(lib.bls12_381_vector_add(gpu._p(victim), gpu._p(src), ctypes.c_uint64(n), ctypes.byref(vcfg), gpu._p(victim)), "vector_add")
+        for _ in range(6):
+            gpu._check(lib.bls12_381_vector_sub(gpu._p(victim), gpu._p(src), ctypes.c_uint64(n), ctypes.byref(vcfg), gpu._p(victim)), "vector_sub")
+        gpu._check(lib.bls12_381_vector_mul(gpu._p(victim), gpu._p(victim), ctypes.c_uint64(n), ctypes.byref(vcfg), gpu._p(result)), "vector_mul")
+        # drop the victim while all of that is still queued, and immediately ask for a block of the same class
+        ptr = victim.ptr
+        victim.free()
+        thief = gpu.DeviceBuffer(32 * n)
+        assert thief.ptr == ptr                                  # the cache did hand the same block out ...
+        gpu._check(lib.tkmk_memset(gpu._p(thief), 0xEE, ctypes.c_size_t(32 * n)), "tkmk_memset")   # ... and the new owner scribbles over it at once
+        gpu._check(lib.tkmk_stream_synchronize(st), "tkmk_stream_synchronize")
+        ev = np.asarray(oracle.ntt(np.asarray(x), 1 << 12))
+        want = np.asarray(oracle.fr_mul(ev, ev))
+        got = np.asarray(result.to_host()).reshape(n >> 12, -1)
+        assert (got == want).all()                               # the queued kernels saw their own data, not the scribble
+        assert (np.asarray(thief.to_host(1 << 16)) == 0xEE).all()
+    finally:
+        gpu._check(lib.tkmk_stream_destroy(st), "tkmk_stream_destroy")

@@ -57,6 +57,8 @@ def verify(qap_dir, synth_dir, crs_dir, out_dir, tamper_public_input=False, seed
     sections = crs_sections(crs_dir, sp)
     crs_g1 = {k: np.asarray(crsmod.single_g1(sections, k)) for k in ("G", "x", "y", "lagrange_KL")}
     recs = np.asarray(sections["g2"]).reshape(10, 192)
+    if not recs.any():
+        raise ValueError("the CRS holds no Sigma2 (all-zero G2 section): every pairing would be 1 and the check vacuous")
     sigma2 = {name: g2.decode(recs[i]) for i, name in enumerate(crsmod.G2_POINTS)}
     kappa2 = random.Random(seed).randrange(1, prove_ref.R)
     return bool(prove_ref.verify_snark_pairing(points, scalars, ch, sp, crs_g1, pre_points, sigma2, a_eval, kappa2))

@@ -25,6 +25,22 @@ tkmk_error tk_map_hip_error(hipError_t e) {
 
 static std::once_flag g_dev_once;
 static tkmk_error g_dev_status = TKMK_ERR_NO_DEVICE;
+// The library's state — scratch arenas, the allocation cache, the NTT domain and its tables, the MSM pipeline's streams — lives on
+// ONE device: the one that is current when the first entry point runs (one process per GPU: DESIGN.md section 6).  ICICLE lets a
+// process hop between devices with set_device; here a later tkmk_set_device to ANOTHER device is refused instead of handing
+// device-0 scratch to kernels running on device 1 (without peer access that is a memory fault).
+static std::atomic<int> g_bound_device{-1};
+
+// the decision tkmk_set_device takes, as a pure function (tests/test_abi.py exercises it without a GPU through tkmk_diag_device_switch)
+tkmk_error tk_device_switch_verdict(int bound_device, int requested_device, int device_count) {
+    if (device_count <= 0) return TKMK_ERR_NO_DEVICE;
+    if (requested_device < 0 || requested_device >= device_count) return TKMK_ERR_INVALID_DEVICE;
+    if (bound_device >= 0 && bound_device != requested_device) return TKMK_ERR_INVALID_DEVICE;   // state exists on another device
+    return TKMK_SUCCESS;
+}
+TK_API tkmk_error tkmk_diag_device_switch(int bound_device, int requested_device, int device_count) {
+    return tk_device_switch_verdict(bound_device, requested_device, device_count);
+}
 
 tkmk_error tk_require_device() {
     std::call_once(g_dev_once, [] {
@@ -44,6 +60,7 @@ tkmk_error tk_require_device() {
         const char *arch = prop.gcnArchName;
         bool ok = arch[0] == 'g' && arch[1] == 'f' && arch[2] == 'x' && arch[3] == '9' && arch[4] == '5' && arch[5] == '0';
         g_dev_status = ok ? TKMK_SUCCESS : TKMK_ERR_INVALID_DEVICE;
+        if (ok) g_bound_device.store(dev);
     });
     return g_dev_status;
 }
@@ -193,9 +210,9 @@ TK_API tkmk_error tkmk_device_count(int *count) {
 TK_API tkmk_error tkmk_set_device(int device_id) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TKMK_ERR_NO_DEVICE;
-    if (device_id < 0 || device_id >= n) return TKMK_ERR_INVALID_DEVICE;
+    TK_TRY(tk_device_switch_verdict(g_bound_device.load(), device_id, n));
     TK_HIP(hipSetDevice(device_id));
-    return tk_require_device();
+    return tk_require_device();   // binds the library to device_id if this is the first entry point of the process
 }
 TK_API tkmk_error tkmk_get_available_memory(size_t *total, size_t *free_bytes) {
     TK_TRY(tk_require_device());
@@ -212,10 +229,16 @@ TK_API tkmk_error tkmk_get_available_memory(size_t *total, size_t *free_bytes) {
 // completed.  (hipMallocAsync's pool is not used: recycled pool memory read stale data across XCD L2s on this ROCm — see
 // tools/coherence_test.hip.)  tkmk_release_scratch() returns everything to the driver.
 namespace {
+// a parked block may be handed out again once everything queued before its release has finished: the event on the releasing
+// stream, and — for tkmk_free, which like Drop for DeviceVec names no stream — one event on every stream the caller created with
+// tkmk_stream_create (they are non-blocking: the NULL stream's event does not order their work).  The library's own pipeline
+// streams have drained when an entry point returns.
 struct cached_block {
     void *p;
-    hipEvent_t ev;
+    std::vector<hipEvent_t> evs;
 };
+std::mutex g_streams_mu;
+std::vector<hipStream_t> g_user_streams;
 std::mutex g_alloc_mu;
 std::map<void *, size_t> g_live;                       // block -> class size
 std::map<size_t, std::vector<cached_block>> g_cache;   // class size -> free blocks
@@ -236,8 +259,10 @@ size_t alloc_cache_cap() {
 void alloc_cache_flush_locked() {
     for (auto &kv : g_cache)
         for (auto &b : kv.second) {
-            (void)hipEventSynchronize(b.ev);
-            (void)hipEventDestroy(b.ev);
+            for (hipEvent_t e : b.evs) {
+                (void)hipEventSynchronize(e);
+                (void)hipEventDestroy(e);
+            }
             (void)hipFree(b.p);
         }
     g_cache.clear();
@@ -245,7 +270,7 @@ void alloc_cache_flush_locked() {
 }
 tkmk_error cached_malloc(void **ptr, size_t bytes) {
     const size_t cls = alloc_class(bytes);
-    cached_block blk{nullptr, nullptr};
+    cached_block blk{nullptr, {}};
     {
         std::lock_guard<std::mutex> lk(g_alloc_mu);
         auto it = g_cache.find(cls);
@@ -257,8 +282,10 @@ tkmk_error cached_malloc(void **ptr, size_t bytes) {
         }
     }
     if (blk.p) {
-        (void)hipEventSynchronize(blk.ev);   // work queued before the release has finished
-        (void)hipEventDestroy(blk.ev);
+        for (hipEvent_t e : blk.evs) {
+            (void)hipEventSynchronize(e);   // work queued before the release has finished
+            (void)hipEventDestroy(e);
+        }
         *ptr = blk.p;
         return TKMK_SUCCESS;
     }
@@ -280,7 +307,7 @@ tkmk_error cached_malloc(void **ptr, size_t bytes) {
     g_live[*ptr] = cls;
     return TKMK_SUCCESS;
 }
-tkmk_error cached_free(void *ptr, hipStream_t s) {
+tkmk_error cached_free(void *ptr, hipStream_t s, bool every_caller_stream) {
     size_t cls = 0;
     {
         std::lock_guard<std::mutex> lk(g_alloc_mu);
@@ -297,10 +324,25 @@ tkmk_error cached_free(void *ptr, hipStream_t s) {
         }
         return TKMK_SUCCESS;
     }
-    cached_block blk{ptr, nullptr};
-    if (hipEventCreateWithFlags(&blk.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(blk.ev, s) != hipSuccess) {
-        (void)hipGetLastError();
-        if (blk.ev) (void)hipEventDestroy(blk.ev);
+    cached_block blk{ptr, {}};
+    std::vector<hipStream_t> streams = {s};
+    if (every_caller_stream) {
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        streams.insert(streams.end(), g_user_streams.begin(), g_user_streams.end());
+    }
+    bool ok = true;
+    for (hipStream_t st : streams) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, st) != hipSuccess) {
+            (void)hipGetLastError();
+            if (e) (void)hipEventDestroy(e);
+            ok = false;
+            break;
+        }
+        blk.evs.push_back(e);
+    }
+    if (!ok) {   // cannot order the release: fall back to the synchronising free
+        for (hipEvent_t e : blk.evs) (void)hipEventDestroy(e);
         return hipFree(ptr) == hipSuccess ? TKMK_SUCCESS : TKMK_ERR_DEALLOCATION_FAILED;
     }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
@@ -333,11 +375,11 @@ TK_API tkmk_error tkmk_malloc_async(void **ptr, size_t bytes, tkmk_stream s) {
 }
 TK_API tkmk_error tkmk_free(void *ptr) {
     if (!ptr) return TKMK_SUCCESS;
-    return cached_free(ptr, nullptr);
+    return cached_free(ptr, nullptr, true);
 }
 TK_API tkmk_error tkmk_free_async(void *ptr, tkmk_stream s) {
     if (!ptr) return TKMK_SUCCESS;
-    return cached_free(ptr, tk_stream(s));
+    return cached_free(ptr, tk_stream(s), false);   // the caller names the stream that last used the block
 }
 static tkmk_error copy(void *dst, const void *src, size_t bytes, hipMemcpyKind k) {
     if (bytes == 0) return TKMK_SUCCESS;
@@ -394,6 +436,10 @@ TK_API tkmk_error tkmk_stream_create(tkmk_stream *s) {
         (void)hipGetLastError();
         return TKMK_ERR_STREAM_CREATION_FAILED;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        g_user_streams.push_back(h);
+    }
     *s = (tkmk_stream)h;
     return TKMK_SUCCESS;
 }
@@ -407,6 +453,15 @@ TK_API tkmk_error tkmk_stream_synchronize(tkmk_stream s) {
 }
 TK_API tkmk_error tkmk_stream_destroy(tkmk_stream s) {
     if (!s) return TKMK_SUCCESS;
+    {
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        for (size_t i = 0; i < g_user_streams.size(); i++)
+            if (g_user_streams[i] == tk_stream(s)) {
+                g_user_streams.erase(g_user_streams.begin() + i);
+                break;
+            }
+    }
+    (void)hipStreamSynchronize(tk_stream(s));   // parked blocks may hold events recorded on this stream
     if (hipStreamDestroy(tk_stream(s)) != hipSuccess) {
         (void)hipGetLastError();
         return TKMK_ERR_STREAM_DESTRUCTION_FAILED;

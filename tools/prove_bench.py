@@ -32,7 +32,9 @@ def stage_crs(tkmk, inst):
     from tkmk.setup import Sigma
     g = np.frombuffer(int(PINS["fixed_tau_g1_x"], 16).to_bytes(48, "little") + int(PINS["fixed_tau_g1_y"], 16).to_bytes(48, "little"), np.uint8).copy()
     tau = {k: int(PINS["tau_" + k], 16) for k in ("x", "y", "alpha", "gamma", "delta", "eta")}
-    return Sigma.gen(inst["setup_params"], tau, inst["qap"], inst["infos"], g), g
+    from tkmk import g2
+    h2 = g2.from_hex_pair(PINS["fixed_tau_g2_x"], PINS["fixed_tau_g2_y"])      # Sigma2 (ten host-side G2 points): the verifier's side of the CRS
+    return Sigma.gen(inst["setup_params"], tau, inst["qap"], inst["infos"], g, h2), g
 
 
 def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, seed=0x746F6B616D616B04, profile_host=False,
