@@ -468,6 +468,9 @@ tkmk_error tkmk_stats_reset(void);
 tkmk_error tkmk_stats_get(const char *name, uint64_t *value);
 /* arithmetic micro-benchmarks (kind 0 Fr mul, 1 Fq mul, 2 v_mad_u64_u32, 3 G1 mixed add, 4 Fr add+sub, 5 Fq sqr) */
 tkmk_error tkmk_diag_bench(int kind, uint32_t iters, uint32_t blocks, int reps, float *ms_out);
+/* known-bytes gather probe (calibration of the FETCH_SIZE counter for the bucket-accumulation access pattern): n rows of row_bytes
+ * (64 / 96 / 128) gathered from table_dev at idx_dev[i], one lane per row with consecutive 16-byte loads; *ms_out = mean launch time */
+tkmk_error tkmk_diag_gather_probe(const void *table_dev, uint32_t row_bytes, const uint32_t *idx_dev, uint64_t n, int reps, float *ms_out);
 /* out[i] = a[i]*b[i] through the device Montgomery product; field 0 = Fr (32 B), 1 = Fq (48 B); device pointers */
 tkmk_error tkmk_diag_field_mul(int field, const void *a_dev, const void *b_dev, void *out_dev, uint64_t n);
 

@@ -276,3 +276,52 @@ TK_API tkmk_error tkmk_diag_field_mul(int field, const void *a_dev, const void *
     TK_HIP(hipDeviceSynchronize());
     return TKMK_SUCCESS;
 }
+
+// ---- known-bytes gather probe: calibrates rocprofv3's FETCH_SIZE for the access pattern of k_accumulate_chunks ----
+// One lane loads one whole row (row_vecs x 16 bytes with consecutive dwordx4 loads, exactly as tk_load<g1_affine_t> does) at a
+// caller-given row index and folds it into a checksum; n rows are gathered in total.  The number of useful bytes (n * row bytes)
+// and of 64-byte sectors / 128-byte lines touched is known from the index list, so the counter's unit for THIS pattern can be
+// read off (MI355X_MICROARCH.md: "other access widths are uncalibrated: calibrate on a known byte count in your own access
+// pattern").  Also reports the launch time (gather bandwidth).
+template <int VECS>
+__global__ __launch_bounds__(256) void k_gather_probe(const uint4 *__restrict__ table, const uint32_t *__restrict__ idx, uint64_t n,
+                                                     uint32_t *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *row = table + (uint64_t)idx[i] * VECS;
+    uint4 v[VECS];
+#pragma unroll
+    for (int k = 0; k < VECS; k++) v[k] = row[k];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < VECS; k++) s ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    if (s == 0x9e3779b9u) out[0] = s;   // keeps the loads alive; practically never true
+}
+TK_API tkmk_error tkmk_diag_gather_probe(const void *table_dev, uint32_t row_bytes, const uint32_t *idx_dev, uint64_t n, int reps, float *ms_out) {
+    if (!table_dev || !idx_dev || !ms_out || reps < 1) return TKMK_ERR_INVALID_POINTER;
+    if (row_bytes != 96 && row_bytes != 64 && row_bytes != 128) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    uint32_t *out = nullptr;
+    TK_HIP(hipMalloc((void **)&out, 4));
+    hipEvent_t e0, e1;
+    TK_HIP(hipEventCreate(&e0));
+    TK_HIP(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (row_bytes == 96) hipLaunchKernelGGL(k_gather_probe<6>, tk_div_up(n, 256), 256, 0, 0, (const uint4 *)table_dev, idx_dev, n, out);
+        else if (row_bytes == 64) hipLaunchKernelGGL(k_gather_probe<4>, tk_div_up(n, 256), 256, 0, 0, (const uint4 *)table_dev, idx_dev, n, out);
+        else hipLaunchKernelGGL(k_gather_probe<8>, tk_div_up(n, 256), 256, 0, 0, (const uint4 *)table_dev, idx_dev, n, out);
+    };
+    launch();
+    TK_HIP(hipDeviceSynchronize());
+    TK_HIP(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; r++) launch();
+    TK_HIP(hipEventRecord(e1, 0));
+    TK_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    TK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    return TKMK_SUCCESS;
+}

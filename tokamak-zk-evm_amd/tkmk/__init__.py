@@ -95,7 +95,7 @@ SYMBOLS = [
     "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini", "tkmk_r1cs_eval_rows",
     "tkmk_msm_multi_ex", "bls12_381_msm_convert_bases", "tkmk_r1cs_library_create", "tkmk_r1cs_library_destroy", "tkmk_r1cs_library_eval",
     "tkmk_witness_route", "tkmk_fr_scatter_table", "tkmk_host_malloc", "tkmk_host_free", "tkmk_stats_reset", "tkmk_stats_get",
-    "bls12_381_ntt_domain_size", "bn254_ntt_domain_size", "tkmk_poly_lincomb", "tkmk_bintt_padded", "tkmk_diag_device_switch",
+    "bls12_381_ntt_domain_size", "bn254_ntt_domain_size", "tkmk_poly_lincomb", "tkmk_bintt_padded", "tkmk_diag_device_switch", "tkmk_diag_gather_probe",
 ]
 
 
