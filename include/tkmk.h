@@ -196,6 +196,14 @@ typedef struct {
     uint32_t base_cols, base_stride;       /* 0, 0 = contiguous */
     const uint32_t *base_index;            /* NULL = none; takes precedence over base_cols */
     uint64_t base_table_len;
+    /* precomputed TABLE (0, 0 = none): `bases` was made by bls12_381_msm_precompute_bases over the WHOLE base table
+     * (base_table_len rows) with cfg->c = table_c and cfg->precompute_factor = table_factor: level j of the table (rows
+     * [j * base_table_len, (j + 1) * base_table_len)) holds the 2^(table_c * W' * j) multiples of level 0, W' = ceil(windows /
+     * table_factor).  The MSM then runs W' windows of table_c bits over msm_size * table_factor entries — with table_factor =
+     * windows a SINGLE bucket set, so that wide windows (table_c up to 20: 13 instead of 16 bucket additions per point) do not
+     * multiply the bucket-reduction work.  Views address level 0; bases_form must be TKMK_BASES_CONVERTED.  Results are
+     * bit-identical to the plain MSM.  A job with table_c > 16 needs msm_size * table_factor >= 2^18. */
+    uint32_t table_c, table_factor;
 } tkmk_msm_job_ex;
 tkmk_error tkmk_msm_multi_ex(const tkmk_msm_job_ex *jobs, int n_jobs, const tkmk_msm_config *cfg, int bases_form,
                              tkmk_g1_projective *results);
