@@ -216,3 +216,47 @@ def test_native_setup_writes_archives_the_prover_reads(gpu, tmp_path):
         assert bytes(arch[name]) == bytes(flat[name]), name
     pre = rkyv.decode_sigma_preprocess(open(os.path.join(out, "sigma_preprocess.rkyv"), "rb").read())
     assert bytes(pre["xy_powers"]) == bytes(flat["xy_powers"]) and bytes(pre["gamma_inv_o_inst"]) == bytes(flat["gamma_inv_o_inst"])
+
+
+@pytest.mark.parametrize("c", [12, 16, 18, 20])
+def test_msm_table_jobs_wide_windows_single_bucket_set(gpu, oracle, c):
+    """precomputed TABLE jobs of tkmk_msm_multi_ex: the whole base table expanded once (bls12_381_msm_precompute_bases, factor =
+    window count: one bucket set), then MSMs over strided boxes and index lists of level 0 — bit-identical to the oracle's MSM on
+    the gathered operands, for window widths up to 20 bits (1024 x 512 bins in the two-pass sort)"""
+    tk = gpu
+    rows, cols = 600, 512                                           # table of 307200 points; boxes of >= 2^18 / windows entries
+    table = np.asarray(oracle.g1_random_bases(50 + c, 4096))        # 4096 distinct points, tiled (the arithmetic does not care)
+    table = np.ascontiguousarray(np.tile(table.reshape(-1, 96), (rows * cols // 4096, 1)).reshape(-1))
+    table[96 * 11:96 * 12] = 0
+    windows = 255 // c + 1
+    d_table = tk.msm_precompute_bases(table, rows * cols, windows, c=c)
+    assert d_table.nbytes == 96 * rows * cols * windows
+    xs, ys = 1024, 512
+    coeffs = np.asarray(oracle.fr_random(60 + c, 1 << 16))
+    coeffs = np.ascontiguousarray(np.tile(coeffs.reshape(-1, 32), (xs * ys // (1 << 16), 1)).reshape(-1))
+    coeffs[32 * 5:32 * 6] = 0
+    d_coeffs = tk.DeviceBuffer.from_host(coeffs)
+    rnd = np.random.default_rng(c)
+    n_idx = 70000
+    idx = rnd.integers(0, rows * cols, n_idx, dtype=np.uint32)
+    d_idx = tk.DeviceBuffer.from_host(idx.view(np.uint8))
+    jobs, want = [], []
+    for tx, ty in ((600, 512), (513, 300), (37, 512)):
+        if c > 16 and tx * ty * windows < (1 << 18):
+            continue
+        jobs.append(dict(scalars=d_coeffs, bases=d_table, n=tx * ty, scalar_view=(ty, ys), base_view=(ty, cols), table_len=rows * cols, table=(c, windows)))
+        cc = coeffs.reshape(xs, ys, 32)[:tx, :ty].reshape(-1)
+        bb = table.reshape(rows, cols, 96)[:tx, :ty].reshape(-1)
+        want.append(np.asarray(oracle.g1_msm(np.ascontiguousarray(cc), np.ascontiguousarray(bb))))
+    jobs.append(dict(scalars=d_coeffs, bases=d_table, n=n_idx, base_index=d_idx, table_len=rows * cols, table=(c, windows)))
+    want.append(np.asarray(oracle.g1_msm(np.ascontiguousarray(coeffs[:32 * n_idx]), np.ascontiguousarray(table.reshape(-1, 96)[idx].reshape(-1)))))
+    # a plain job over level 0 of the same buffer next to them (small commits keep the multi-window path)
+    jobs.append(dict(scalars=d_coeffs, bases=d_table, n=300, base_view=(10, cols), scalar_view=(10, ys), table_len=rows * cols))
+    want.append(np.asarray(oracle.g1_msm(np.ascontiguousarray(coeffs.reshape(xs, ys, 32)[:30, :10].reshape(-1)),
+                                         np.ascontiguousarray(table.reshape(rows, cols, 96)[:30, :10].reshape(-1)))))
+    got = _aff(tk, tk.msm_multi_ex(jobs, bases_form=tk.BASES_CONVERTED))
+    for k, w in enumerate(want):
+        assert (got[96 * k:96 * (k + 1)] == w).all(), (c, k)
+    if c > 16:      # too small for a wide window: refused, not silently narrowed
+        with pytest.raises(tk.TkmkError):
+            tk.msm_multi_ex([dict(scalars=d_coeffs, bases=d_table, n=1000, table_len=rows * cols, table=(c, windows))], bases_form=tk.BASES_CONVERTED)

@@ -374,7 +374,7 @@ _CURVES = {
 }
 
 
-def msm_windows(n, c=0, bitsize=0, curve="bls12_381"):
+def msm_windows(n, c=0, bitsize=0, curve="bls12_381", explicit_c=False):
     """number of scalar windows the library uses for an n-point MSM (c = 0: its own choice), i.e. the largest useful
     precompute factor; mirrors choose_c / msm_resolve_c in csrc/msm_impl.inc"""
     bits = bitsize or (255 if curve == "bls12_381" else 254)
@@ -385,7 +385,9 @@ def msm_windows(n, c=0, bitsize=0, curve="bls12_381"):
             if cost is None or v < cost:
                 best, cost = cc, v
         c = best
-    c = min(max(c, 2), 18)
+    if explicit_c:                                   # msm_precompute_bases takes an explicit width as given (tables for table jobs)
+        return bits // min(max(c, 2), 20) + 1
+    c = min(max(c, 2), 20)
     if c > 16 and n < (1 << 18):
         c = 16
     return bits // c + 1
@@ -400,7 +402,7 @@ def msm_precompute_bases(bases, n, factor, c=0, bitsize=0, curve="bls12_381", po
     cfg.are_points_on_device = _on_dev(bases)
     cfg.are_points_montgomery_form = points_montgomery
     cfg.are_results_on_device = True
-    f = min(factor, msm_windows(n, c, bitsize, curve))
+    f = min(factor, msm_windows(n, c, bitsize, curve, explicit_c=bool(c)))
     out = DeviceBuffer(aff * n * f)
     _check(getattr(lib(), sym)(_p(bases), int(n), ctypes.byref(cfg), _p(out)), sym)
     return out
@@ -462,7 +464,8 @@ def msm_multi(jobs, c=0, bitsize=0, stream=None, curve="bls12_381", precompute_f
 class MsmJobEx(ctypes.Structure):
     _fields_ = [("scalars", ctypes.c_void_p), ("bases", ctypes.c_void_p), ("msm_size", ctypes.c_int),
                 ("scalar_cols", ctypes.c_uint32), ("scalar_stride", ctypes.c_uint32), ("base_cols", ctypes.c_uint32),
-                ("base_stride", ctypes.c_uint32), ("base_index", ctypes.c_void_p), ("base_table_len", ctypes.c_uint64)]
+                ("base_stride", ctypes.c_uint32), ("base_index", ctypes.c_void_p), ("base_table_len", ctypes.c_uint64),
+                ("table_c", ctypes.c_uint32), ("table_factor", ctypes.c_uint32)]
 
 
 BASES_PLAIN, BASES_MONTGOMERY, BASES_CONVERTED = 0, 1, 2
@@ -494,8 +497,9 @@ def msm_multi_ex(jobs, bases_form=BASES_PLAIN, c=0, bitsize=0, stream=None):
     for k, j in enumerate(jobs):
         sv, bv, ix = j.get("scalar_view") or (0, 0), j.get("base_view") or (0, 0), j.get("base_index")
         STATS["msm_points"] += int(j["n"])
+        tc, tf = j.get("table", (0, 0))                  # (c, factor) of a precomputed table (msm_precompute_bases over the whole table)
         arr[k] = MsmJobEx(_p(j["scalars"]).value, _p(j["bases"]).value, int(j["n"]), sv[0], sv[1], bv[0], bv[1],
-                          None if ix is None else _p(ix).value, int(j.get("table_len", 0)))
+                          None if ix is None else _p(ix).value, int(j.get("table_len", 0)), int(tc), int(tf))
     out = np.empty(144 * len(jobs), np.uint8)
     _check(lib().tkmk_msm_multi_ex(arr, len(jobs), ctypes.byref(cfg), int(bases_form), _p(out)), "tkmk_msm_multi_ex")
     return out
