@@ -104,6 +104,11 @@ tkmk_error tkmk_device_synchronize(void);
 /* scratch used by MSM / NTT calls lives in per-stream grow-only arenas; this returns all of it to the driver */
 tkmk_error tkmk_release_scratch(void);
 const char *tkmk_error_string(tkmk_error e);
+/* GenerateRandom (icicle_core::traits): n uniform scalars (the prover's blinding scalars, prove/src/lib.rs:1040-1080) / n random G1
+ * points [k]G into HOST buffers; the scalars come from getrandom() with rejection sampling (host-only), the points are computed on
+ * the device */
+tkmk_error bls12_381_generate_scalars(tkmk_fr *out_host, size_t n);
+tkmk_error bls12_381_generate_random_affine_points(tkmk_g1_affine *out_host, size_t n);
 /* 1 if libtkmk_hip.so was built with gfx950 code objects (always, for this library) */
 int tkmk_is_hip_build(void);
 /* host-only: Keccak-256 (original 0x01 padding), the hash of the Fiat-Shamir transcript — replaces the tiny_keccak calls of
@@ -285,6 +290,8 @@ typedef struct {
 
 tkmk_vecops_config tkmk_vecops_default_config(void);      /* VecOpsConfig::default() */
 tkmk_error bls12_381_vector_add(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
+/* accumulate (icicle_core::vec_ops::accumulate_scalars): a[i] += b[i], in place in a */
+tkmk_error bls12_381_vector_accumulate(tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg);
 tkmk_error bls12_381_vector_sub(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
 tkmk_error bls12_381_vector_mul(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
 tkmk_error bls12_381_vector_div(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *cfg, tkmk_fr *out);
@@ -416,6 +423,33 @@ tkmk_error tkmk_poly_lincomb(uint32_t n_terms, const tkmk_fr *coeffs_host, const
 /* div_by_ruffini (mod.rs:2412-2477): P = Q_X (X - x) + Q_Y (Y - y) + r; q_x is x_size x y_size, q_y has y_size elements */
 tkmk_error tkmk_poly_div_by_ruffini(const tkmk_fr *p_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, const tkmk_fr *y,
                                     tkmk_fr *q_x_dev, tkmk_fr *q_y_dev, tkmk_fr *r_host, tkmk_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Opaque univariate polynomial — replaces icicle_bls12_381::polynomials::DensePolynomial, the storage object inside
+ * DensePolynomialExt (libs/src/bivariate_polynomial/mod.rs:112-127): from_coeffs :1520,1542,1803, clone :523, copy_coeffs
+ * :1485,1681,1706, get_coeff :1757, coeffs_mut_slice :127, eval :1725-1737, divide :2070 (+ the arithmetic ICICLE's object offers).
+ * A handle owns one device buffer of plain Fr coefficients, low degree first; clone = device copy; delete releases it.
+ * Results of add / subtract / multiply / multiply_by_scalar / slice / divide are NEW handles the caller deletes.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct tkmk_polynomial tkmk_polynomial;
+tkmk_error bls12_381_polynomial_create_from_coefficients(const tkmk_fr *coeffs, size_t n, bool on_device, tkmk_polynomial **out);
+tkmk_error bls12_381_polynomial_create_from_rou_evaluations(const tkmk_fr *evals, size_t n, bool on_device, tkmk_polynomial **out);
+tkmk_error bls12_381_polynomial_clone(const tkmk_polynomial *p, tkmk_polynomial **out);
+tkmk_error bls12_381_polynomial_delete(tkmk_polynomial *p);
+tkmk_error bls12_381_polynomial_nof_coeffs(const tkmk_polynomial *p, size_t *n);
+tkmk_error bls12_381_polynomial_degree(const tkmk_polynomial *p, int64_t *degree);             /* -1 for the zero polynomial */
+tkmk_error bls12_381_polynomial_copy_coeffs(const tkmk_polynomial *p, size_t start, size_t count, tkmk_fr *out, bool out_on_device);
+tkmk_error bls12_381_polynomial_get_coeff(const tkmk_polynomial *p, size_t idx, tkmk_fr *out_host);
+tkmk_error bls12_381_polynomial_coeffs_device_ptr(tkmk_polynomial *p, tkmk_fr **ptr, size_t *n);   /* coeffs_mut_slice */
+tkmk_error bls12_381_polynomial_evaluate(const tkmk_polynomial *p, const tkmk_fr *x_host, tkmk_fr *out_host);
+tkmk_error bls12_381_polynomial_add(const tkmk_polynomial *a, const tkmk_polynomial *b, tkmk_polynomial **out);
+tkmk_error bls12_381_polynomial_subtract(const tkmk_polynomial *a, const tkmk_polynomial *b, tkmk_polynomial **out);
+tkmk_error bls12_381_polynomial_multiply(const tkmk_polynomial *a, const tkmk_polynomial *b, tkmk_polynomial **out);   /* NTT domain must cover deg a + deg b */
+tkmk_error bls12_381_polynomial_multiply_by_scalar(const tkmk_polynomial *a, const tkmk_fr *s_host, tkmk_polynomial **out);
+/* out[i] = p[offset + i * stride], i < size */
+tkmk_error bls12_381_polynomial_slice(const tkmk_polynomial *p, size_t offset, size_t stride, size_t size, tkmk_polynomial **out);
+/* num = quot * den + rem with deg rem < deg den (long division); den must not be the zero polynomial */
+tkmk_error bls12_381_polynomial_divide(const tkmk_polynomial *num, const tkmk_polynomial *den, tkmk_polynomial **quot, tkmk_polynomial **rem);
 
 /* ---------------------------------------------------------------------------------------------
  * Witness side of the path: sparse R1CS rows x placement variables -> rows of the u / v / w evaluation

@@ -217,6 +217,33 @@ TK_API tkmk_error tkmk_bn254_g1_batch_scalar_mul_device(const tkmk_bn254_fr *sca
                                                                                out_dev, s);
 }
 
+// G1Affine::generate_random (icicle_core::traits::GenerateRandom, used by the reference's tests): n points [k_i]G with fresh uniform
+// k_i, G the standard generator; HOST output.  The multiples are computed on the device (fixed-base path above).
+extern "C" tkmk_error bls12_381_generate_scalars(tkmk_fr *out_host, size_t n);
+TK_API tkmk_error bls12_381_generate_random_affine_points(tkmk_g1_affine *out_host, size_t n) {
+    if (!out_host && n) return TKMK_ERR_INVALID_POINTER;
+    if (n == 0) return TKMK_SUCCESS;
+    TK_TRY(tk_require_device());
+    static const uint32_t GX[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+                                    0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};   // setup/mpc-setup/src/conversions.rs:68-79
+    static const uint32_t GY[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
+                                    0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+    std::vector<tkmk_fr> k(n);
+    TK_TRY(bls12_381_generate_scalars(k.data(), n));
+    void *d_k = nullptr, *d_out = nullptr;
+    TK_HIP(hipMalloc(&d_k, n * sizeof(tkmk_fr)));
+    hipError_t e = hipMalloc(&d_out, n * sizeof(tkmk_g1_affine));
+    if (e != hipSuccess) {
+        (void)hipFree(d_k);
+        return tk_map_hip_error(e);
+    }
+    tkmk_error r = tk_map_hip_error(hipMemcpy(d_k, k.data(), n * sizeof(tkmk_fr), hipMemcpyHostToDevice));
+    if (r == TKMK_SUCCESS) r = g1_batch_scalar_mul_device<Fr, Fq>((const tkmk_fr *)d_k, GX, GY, n, (tkmk_g1_affine *)d_out, nullptr);
+    if (r == TKMK_SUCCESS) r = tk_map_hip_error(hipMemcpy(out_host, d_out, n * sizeof(tkmk_g1_affine), hipMemcpyDeviceToHost));
+    (void)hipFree(d_k), (void)hipFree(d_out);
+    return r;
+}
+
 // dst[i] = src[idx[i]] for rows of row_bytes (multiple of 16): the device-side gather behind the binding
 // commitments, which the reference builds on the host by walking nested CRS tables
 // (packages/backend/libs/src/group_structures/mod.rs:145-300 encode_*_common -> msm_g1_bases :127-143)

@@ -94,3 +94,39 @@ TK_API tkmk_error tkmk_keccak256(const uint8_t *data, size_t len, uint8_t out[32
     std::memcpy(out, a, 32);
     return TKMK_SUCCESS;
 }
+
+// ScalarCfg::generate_random (icicle_core::traits::GenerateRandom; the prover's blinding scalars: prove/src/lib.rs:1040-1080): n uniform
+// elements of Fr into a HOST buffer — 255 bits from the kernel's CSPRNG (getrandom), redrawn until below r (rejection sampling: no
+// modular bias).  Host-only: no device is touched.
+#include <errno.h>
+#include <sys/random.h>
+TK_API tkmk_error bls12_381_generate_scalars(tkmk_fr *out_host, size_t n) {
+    if (!out_host && n) return TKMK_ERR_INVALID_POINTER;
+    static const uint32_t R[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+    for (size_t i = 0; i < n;) {
+        uint8_t b[32];
+        size_t got = 0;
+        while (got < sizeof b) {
+            ssize_t k = getrandom(b + got, sizeof b - got, 0);
+            if (k < 0) {
+                if (errno == EINTR) continue;
+                return TKMK_ERR_UNKNOWN;
+            }
+            got += (size_t)k;
+        }
+        b[31] &= 0x7f;
+        uint32_t l[8];
+        std::memcpy(l, b, 32);
+        bool below = false;
+        for (int k = 7; k >= 0; k--) {
+            if (l[k] != R[k]) {
+                below = l[k] < R[k];
+                break;
+            }
+        }
+        if (!below) continue;
+        std::memcpy(out_host[i].limbs, l, 32);
+        i++;
+    }
+    return TKMK_SUCCESS;
+}

@@ -180,6 +180,13 @@ TK_API tkmk_vecops_config tkmk_vecops_default_config(void) {
 TK_API tkmk_error bls12_381_vector_add(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *c, tkmk_fr *o) {
     return vec_entry(OP_ADD, a, b, n, c, o);
 }
+// accumulate (icicle_core::vec_ops::accumulate_scalars): a[i] += b[i], in place in `a` (is_result_on_device is taken from is_a_on_device)
+TK_API tkmk_error bls12_381_vector_accumulate(tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *c) {
+    if (!c) return TKMK_ERR_INVALID_ARGUMENT;
+    tkmk_vecops_config cc = *c;
+    cc.is_result_on_device = c->is_a_on_device;
+    return vec_entry(OP_ADD, a, b, n, &cc, a);
+}
 TK_API tkmk_error bls12_381_vector_sub(const tkmk_fr *a, const tkmk_fr *b, uint64_t n, const tkmk_vecops_config *c, tkmk_fr *o) {
     return vec_entry(OP_SUB, a, b, n, c, o);
 }

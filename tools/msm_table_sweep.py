@@ -56,9 +56,17 @@ def main():
                     tkmk.msm_multi_ex(jobs, bases_form=tkmk.BASES_CONVERTED)
                 tkmk.synchronize()
                 ms = (time.perf_counter() - t0) / reps / jobs_per_call * 1e3
+                sections = None
+                if jobs_per_call == 1:
+                    tkmk.profile_enable(True)
+                    tkmk.profile_reset()
+                    tkmk.msm_multi_ex(jobs, bases_form=tkmk.BASES_CONVERTED)
+                    tkmk.profile_enable(False)
+                    sections = {k: round(tkmk.profile_get("msm." + k)[0], 3) for k in ("digits", "hist", "scan", "scatter", "accumulate", "combine",
+                                                                                       "reduce_segments", "reduce_windows")}
                 print(json.dumps({"logn": logn, "mode": "table c=%d F=%d" % (c, windows) if c else "plain (auto c)", "jobs_per_call": jobs_per_call,
                                   "ms_per_msm": round(ms, 3), "Mpoints_per_s": round(n / ms / 1e3, 1), "equals_plain": ok,
-                                  "table_build_s": round(build_s, 2) if c else None}), flush=True)
+                                  "table_build_s": round(build_s, 2) if c else None, "sections_ms": sections}), flush=True)
         if c:
             table.free()
         tkmk.release_scratch()
