@@ -56,3 +56,76 @@ def test_scanner_rejects_malformed_documents(tkmk, tmp_path, text):
     p.write_text(text)
     rc, lines = _run(p)
     assert rc == 1 and lines and lines[0].startswith("error: "), (text, lines)
+
+
+# ---- the multi-threaded readers of host/tkmk_fastparse.hpp (what the resident prover uses per proof) ----
+def _run_args(*args):
+    r = subprocess.run([DRIVER] + [str(a) for a in args], capture_output=True, text=True, timeout=60)
+    return r.returncode, r.stdout.strip().splitlines()
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_fast_reader_equals_serial_scanner_and_json(tkmk, tmp_path, threads):
+    rnd = random.Random(5)
+    n_wires = [rnd.randrange(0, 30) for _ in range(6)]
+    n_wires[2] = 0
+    docs = [{"subcircuitId": k, "variables": ["0x%x" % rnd.choice([0, 1, rnd.randrange(R), R - 1, R + 3, rnd.randrange(1 << 64), rnd.randrange(1 << 255)])
+                                              for _ in range(n_wires[k])]} for k in [rnd.randrange(6) for _ in range(300)]]
+    nw = ",".join(str(v) for v in n_wires)
+    variants = [json.dumps(docs), json.dumps(docs, indent=2), json.dumps(docs, separators=(",", ":")),
+                json.dumps([{"variables": d["variables"], "note": "x y", "k": 12, "subcircuitId": d["subcircuitId"]} for d in docs], indent=1),
+                "\n \t" + json.dumps(docs) + "\n\n", json.dumps(docs[:1]), json.dumps(docs[:2])]
+    for k, text in enumerate(variants):
+        p = tmp_path / ("pv%d.json" % k)
+        p.write_text(text)
+        want = _expected(json.loads(text))
+        assert _run_args("fast", p, threads, nw) == (0, want), k
+        assert _run(p) == (0, want), k                                   # the serial scanner agrees
+    p = tmp_path / "empty.json"
+    p.write_text(" [ ] ")
+    assert _run_args("fast", p, threads, nw) == (0, ["ok 0 0"])
+    # a placement with the wrong number of variables for its kind, or an unknown kind: the reference's messages
+    for bad, msg in (([{"subcircuitId": 0, "variables": ["0x1"] * (n_wires[0] + 1)}], "Corrupted placement variables."),
+                     ([{"subcircuitId": 1, "variables": ["0x1"] * max(0, n_wires[1] - 1)}] if n_wires[1] else [{"subcircuitId": 0, "variables": []}] if n_wires[0] else None,
+                      "Corrupted placement variables."),
+                     ([{"subcircuitId": 6, "variables": []}], "Invalid subcircuit id in placement_variables.")):
+        if bad is None:
+            continue
+        p = tmp_path / "bad.json"
+        p.write_text(json.dumps(docs[:5] + bad + docs[5:9]))
+        rc, lines = _run_args("fast", p, threads, nw)
+        assert rc == 1 and msg in lines[0], (bad, lines)
+
+
+@pytest.mark.parametrize("text", [
+    "", "[", "[{", '[{"subcircuitId": 1}]', '[{"variables": ["0x1"]}]', '[{"subcircuitId": 1, "variables": ["0x1"', '[{"subcircuitId": 1, "variables": ["0xzz"]}]',
+    '[{"subcircuitId": 1, "variables": ["0x1" "0x2"]}]', '[{"subcircuitId": -1, "variables": []}]', '[{"subcircuitId": 1, "variables": ["0x' + "f" * 65 + '"]}]',
+    '[{"subcircuitId": 1, "variables": ["a\\\\u0041"]}]', '{"subcircuitId": 1, "variables": []}', '[{"subcircuitId": 1, "variables": []} {"subcircuitId": 2, "variables": []}]',
+    '[{"subcircuitId": 1, "variables": [], }]', '[{"subcircuitId": 1, "variables": ["0x1",]}]', '[{"subcircuitId": 1, "variables": []}] x', 'x [{"subcircuitId": 1, "variables": []}]',
+    '[{"subcircuitId": 1, "variables": []},]', '[{"subcircuitId": 1, "subcircuitId": 1, "variables": []}]', '[{"subcircuitId": 1, "variables": [], "z": {"a": 1}}]'])
+def test_fast_reader_rejects_malformed_documents(tkmk, tmp_path, text):
+    p = tmp_path / "bad.json"
+    p.write_text(text)
+    for threads in (1, 4):
+        rc, lines = _run_args("fast", p, threads, "1,1,2")
+        assert rc == 1 and lines and lines[0].startswith("error: "), (text, lines)
+
+
+def test_fast_permutation_reader(tkmk, tmp_path):
+    rnd = random.Random(6)
+    perm = [{"row": rnd.randrange(4096), "col": rnd.randrange(1024), "X": rnd.randrange(4096), "Y": rnd.randrange(1024)} for _ in range(5000)]
+    want = ["ok %d" % len(perm)] + ["%d %d %d %d" % (e["row"], e["col"], e["X"], e["Y"]) for e in perm]
+    shuffled = [{"Y": e["Y"], "note": "n", "row": e["row"], "X": e["X"], "col": e["col"]} for e in perm]
+    for k, text in enumerate((json.dumps(perm), json.dumps(perm, indent=1), json.dumps(shuffled), json.dumps(perm, separators=(",", ":")))):
+        p = tmp_path / ("perm%d.json" % k)
+        p.write_text(text)
+        for threads in (1, 5):
+            assert _run_args("perm", p, threads) == (0, want), (k, threads)
+    p = tmp_path / "e.json"
+    p.write_text("[]")
+    assert _run_args("perm", p, 2) == (0, ["ok 0"])
+    for bad in ('[{"row": 1, "col": 2, "X": 3}]', '[{"row": 1, "col": 2, "X": 3, "Y": 4}', '[{"row": 1, "col": 2, "X": 3, "Y": -4}]', '[{"row": 1, "row": 1, "col": 2, "X": 3, "Y": 4}]',
+                '[{"row": 1, "col": 2, "X": 3, "Y": 4} {"row": 1, "col": 2, "X": 3, "Y": 4}]', '[{"row": 1, "col": 2, "X": 3, "Y": 99999999999}]'):
+        p.write_text(bad)
+        rc, lines = _run_args("perm", p, 2)
+        assert rc == 1 and lines[0].startswith("error: "), (bad, lines)
