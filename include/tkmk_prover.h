@@ -35,6 +35,10 @@ typedef struct {          /* seconds */
     double total_s;
 } tkmk_prove_timing;
 
+/* Loads the circuit-static state.  Because the context is meant to stay, xy_powers is expanded once into a precomputed commit
+ * table (ICICLE's msm_precompute_bases; 20-bit windows, 13 x the table in HBM: 21 GB for the 2^24-point CRS of BASELINE.json
+ * configs[3]) so that every large commit costs 13 instead of 16 bucket additions per point; commitments are bit-identical either
+ * way.  Environment: TKMK_PROVER_TABLE_C=0 disables the table, 13..20 picks another window width. */
 tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const char *crs_dir, tkmk_prover **out);
 /* output_dir may be NULL (no file is written); proof_json_out (optional) receives a malloc'ed copy of the document, to be
  * released with tkmk_prover_free_string.  testing_mixer_json: NULL in production (blinding scalars from getrandom());

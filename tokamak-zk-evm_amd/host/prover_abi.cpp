@@ -38,7 +38,7 @@ TKP_API tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const ch
         if (tkmk_device_count(&ndev) != TKMK_SUCCESS || ndev < 1) throw Error(TKMK_ERR_NO_DEVICE, "tkmk_prover_open: no HIP device (the MI355X backend has no CPU fallback)");
         std::string crs = crs_dir;
         std::unique_ptr<tkmk_prover> p(new tkmk_prover());
-        p->ctx = ProverContext::open(subcircuit_library_dir, crs, [&](const SetupParams &sp, std::string &source) { return load_prover_sigma(crs, sp, source); });
+        p->ctx = ProverContext::open(subcircuit_library_dir, crs, [&](const SetupParams &sp, std::string &source) { return load_prover_sigma(crs, sp, source, resident_table_c(sp)); });
         *out = p.release();
     });
 }

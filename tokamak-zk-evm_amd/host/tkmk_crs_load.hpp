@@ -45,10 +45,22 @@ inline CrsPayload load_combined_sigma(const std::string &crs_dir, const SetupPar
     }
     throw Error("No reference string is found. Run the Setup first (expected " + archive + ").");
 }
-inline std::unique_ptr<ProverSigma> load_prover_sigma(const std::string &crs_dir, const SetupParams &sp, std::string &source) {
+// table_c: window width of the precomputed commit table (0 = none): worth its one-time cost (seconds) and memory (13 x xy_powers at
+// 20 bits) only for a prover that stays resident
+inline std::unique_ptr<ProverSigma> load_prover_sigma(const std::string &crs_dir, const SetupParams &sp, std::string &source, uint32_t table_c = 0) {
     CrsPayload crs = load_combined_sigma(crs_dir, sp);
     source = crs.container;
-    return std::unique_ptr<ProverSigma>(new ProverSigma(ProverSigma::from_payload(crs, sp)));
+    return std::unique_ptr<ProverSigma>(new ProverSigma(ProverSigma::from_payload(crs, sp, table_c)));
+}
+// the resident prover's default: 20-bit windows once xy_powers is large enough for the wide sort to pay (>= 2^20 points);
+// TKMK_PROVER_TABLE_C = 0 turns the table off, 13..20 picks another width
+inline uint32_t resident_table_c(const SetupParams &sp) {
+    if (const char *e = std::getenv("TKMK_PROVER_TABLE_C")) {
+        int v = std::atoi(e);
+        return v >= 2 && v <= 20 ? (uint32_t)v : 0;
+    }
+    size_t m_i = sp.l_D - sp.l, points = std::max(2 * sp.n, 2 * m_i) * 2 * sp.s_max;
+    return points >= (1u << 20) ? 20u : 0u;
 }
 
 }  // namespace tkmk

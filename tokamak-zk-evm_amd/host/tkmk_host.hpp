@@ -567,20 +567,37 @@ class PolyExpr {
 // sub-grid through strided VIEWS (tkmk_msm_multi_ex), where the reference copies both, point by point, before every MSM
 // (iotools/mod.rs:2061-2088).
 class Sigma1 {
-    DeviceVec<G1Affine> xy_powers_;
+    DeviceVec<G1Affine> xy_powers_;   // level 0: the table in resident form; with table_c_: levels 1 .. table_factor_ - 1 behind it
     size_t rs_x_, rs_y_;
+    uint32_t table_c_ = 0, table_factor_ = 0;
 
   public:
-    // xy_powers[i*rs_y + j] = [tau_x^i tau_y^j]G (plain affine records);  rs_x = max(2n, 2(l_D - l)), rs_y = 2 s_max
-    Sigma1(DeviceVec<G1Affine> &&xy_powers, size_t rs_x_size, size_t rs_y_size) : xy_powers_(std::move(xy_powers)), rs_x_(rs_x_size), rs_y_(rs_y_size) {
+    // xy_powers[i*rs_y + j] = [tau_x^i tau_y^j]G (plain affine records);  rs_x = max(2n, 2(l_D - l)), rs_y = 2 s_max.
+    // table_c > 0 (a resident prover that amortises it over many proofs): the table is expanded ONCE into its 2^(table_c j)
+    // multiples (ICICLE's msm_precompute_bases, MSMConfig::precompute_factor — left at 1 by the reference), so that every large
+    // commit runs as ONE bucket set with table_c-bit windows: 13 instead of 16 bucket additions per point at table_c = 20.
+    // HBM: windows x the table (2^24 points at table_c = 20: 21 GB of the 288).
+    Sigma1(DeviceVec<G1Affine> &&xy_powers, size_t rs_x_size, size_t rs_y_size, uint32_t table_c = 0) : xy_powers_(std::move(xy_powers)), rs_x_(rs_x_size), rs_y_(rs_y_size) {
         if (xy_powers_.len() != rs_x_ * rs_y_) throw Error("xy_powers has the wrong length");
         tkmk_msm_config cfg = tkmk_msm_default_config();
         cfg.are_points_on_device = cfg.are_results_on_device = true;
-        check(bls12_381_msm_convert_bases(xy_powers_.ptr(), xy_powers_.len(), &cfg, xy_powers_.ptr()), "msm::convert_bases");
+        if (table_c >= 2 && xy_powers_.len() >= 2) {
+            const uint32_t windows = 255 / table_c + 1;
+            if ((uint64_t)xy_powers_.len() * windows >= (1ull << 31)) throw Error("xy_powers is too large for a precomputed table");
+            DeviceVec<G1Affine> table(xy_powers_.len() * windows);
+            cfg.c = (int)table_c;
+            cfg.precompute_factor = (int)windows;
+            check(bls12_381_msm_precompute_bases(xy_powers_.ptr(), (int)xy_powers_.len(), &cfg, table.ptr()), "msm::precompute_bases");
+            xy_powers_ = std::move(table);
+            table_c_ = table_c, table_factor_ = windows;
+        } else {
+            check(bls12_381_msm_convert_bases(xy_powers_.ptr(), xy_powers_.len(), &cfg, xy_powers_.ptr()), "msm::convert_bases");
+        }
     }
-    const DeviceVec<G1Affine> &converted_table() const { return xy_powers_; }
     size_t rs_x() const { return rs_x_; }
     size_t rs_y() const { return rs_y_; }
+    size_t table_len() const { return rs_x_ * rs_y_; }
+    uint32_t table_c() const { return table_c_; }
     // the MSM job of one commit: coefficient box x CRS sub-grid, both as views (msm_size 0 for the zero polynomial)
     tkmk_msm_job_ex job(DensePolynomialExt &poly) const {
         poly.optimize_size();
@@ -593,7 +610,10 @@ class Sigma1 {
         j.scalar_cols = (uint32_t)ty, j.scalar_stride = (uint32_t)poly.y_size;
         j.base_cols = (uint32_t)ty, j.base_stride = (uint32_t)rs_y_;
         j.base_index = nullptr;
-        j.base_table_len = xy_powers_.len();
+        j.base_table_len = table_len();
+        // large commits through the expanded table; small ones (the wide windows' two-pass sort needs 2^18 entries, and a 2^19-bucket
+        // reduction is not worth paying for a few thousand points) through level 0 with the ordinary multi-window path
+        if (table_c_ && (uint64_t)tx * ty * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
         return j;
     }
     static G1Affine to_affine(const tkmk_g1_projective &res) {

@@ -124,7 +124,7 @@ struct ProverSigma {
     std::vector<G1Affine> delta_inv_alphak_xh_tx, delta_inv_alpha4_xj_tx, delta_inv_alphak_yi_ty;   // 3x3, 2, 4x3
     G1Affine delta, eta;
     bool binding_tables_converted = false;   // ProverContext keeps the three binding tables in the MSM's resident form
-    static ProverSigma from_payload(const CrsPayload &crs, const SetupParams &sp) {
+    static ProverSigma from_payload(const CrsPayload &crs, const SetupParams &sp, uint32_t table_c = 0) {
         size_t m_i = sp.l_D - sp.l, rs_x = std::max(2 * sp.n, 2 * m_i), rs_y = 2 * sp.s_max;
         auto want = [&](CrsPayload::Section s, size_t pts, const char *name) {
             if (crs.points(s) != pts) throw Error(std::string("CRS section ") + name + " does not match setupParams.json");
@@ -138,7 +138,7 @@ struct ProverSigma {
         want(CrsPayload::DeltaInvAlphakYiTy, 12, "delta_inv_alphak_yi_ty");
         auto host = [&](CrsPayload::Section s) { return std::vector<G1Affine>(crs.g1(s), crs.g1(s) + crs.points(s)); };
         const G1Affine *singles = crs.g1(CrsPayload::G1Singles);   // G, x, y, delta, eta, lagrange_KL
-        return ProverSigma{Sigma1(crs.upload(CrsPayload::XyPowers), rs_x, rs_y),
+        return ProverSigma{Sigma1(crs.upload(CrsPayload::XyPowers), rs_x, rs_y, table_c),
                            crs.upload(CrsPayload::GammaInvOInst),
                            crs.upload(CrsPayload::EtaInvLiOInterAlpha4Kj),
                            crs.upload(CrsPayload::DeltaInvLiOPrv),
