@@ -310,6 +310,20 @@ tkmk_error tkmk_vec_suffix_product(const tkmk_fr *a_dev, uint64_t n, tkmk_fr *ou
 tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, uint32_t cols, const tkmk_vecops_config *cfg, tkmk_fr *out);
 
 /* ---------------------------------------------------------------------------------------------
+ * G2 MSM on BLS12-381 (the twist y^2 = x^3 + 4(1 + u) over Fp2 = Fq[u]/(u^2 + 1)) — ICICLE v3's `bls12_381_g2_msm`
+ * (icicle_bls12_381::curve::G2CurveCfg).  The reference has no G2 MSM call site: G2 appears as nine scalar multiplications
+ * of the generator in Sigma2::gen (packages/backend/libs/src/group_structures/mod.rs:752-777), which fit this entry as a
+ * batch of one-point MSMs with shared points, and in the verifier's pairings.  Config fields as in bls12_381_msm except:
+ * precompute_factor must be 0 or 1, c must be 0 (auto) or 2..12.  An affine record of all zeros is the point at infinity;
+ * results are canonical projective, (x_affine, y_affine, 1) or (0, 1, 0), c0 before c1 in every Fp2 element.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct { tkmk_fq c0, c1; } tkmk_fq2;               /* c0 + c1 u  (96 B) */
+typedef struct { tkmk_fq2 x, y; } tkmk_g2_affine;          /* G2Affine (192 B) */
+typedef struct { tkmk_fq2 x, y, z; } tkmk_g2_projective;   /* G2Projective (288 B) */
+tkmk_error bls12_381_g2_msm(const tkmk_fr *scalars, const tkmk_g2_affine *bases, int msm_size, const tkmk_msm_config *cfg,
+                            tkmk_g2_projective *results);
+
+/* ---------------------------------------------------------------------------------------------
  * BN254 (alt_bn128) G1 MSM — the same Pippenger kernels instantiated over the 254-bit fields
  * (ICICLE v3 exports the per-curve twin `bn254_msm`).  The reference links only icicle-bls12-381
  * (packages/backend/Cargo.toml:23), so no reference call site exists for it; it is here

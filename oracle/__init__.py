@@ -215,6 +215,53 @@ def g1_proj_to_affine(p144):
     return out
 
 
+class _G2:
+    """G2 of BLS12-381 (twist over Fp2): the curve-generic oracle code instantiated over Fp2.  Affine 192 B (x then y, each real then
+    imaginary part, 48-byte little-endian; all zero = infinity), projective 288 B.  Same method names as the module-level G1 functions."""
+    AFF_BYTES = 192
+
+    def generator(self):
+        out = np.empty(192, np.uint8)
+        lib().tko_g2_generator(_p(out))
+        return out
+
+    def on_curve(self, p):
+        return bool(lib().tko_g2_on_curve(_p(p)))
+
+    def add(self, p, q):
+        out = np.empty(192, np.uint8)
+        lib().tko_g2_add(_p(p), _p(q), _p(out))
+        return out
+
+    def neg(self, p):
+        out = np.empty(192, np.uint8)
+        lib().tko_g2_neg(_p(p), _p(out))
+        return out
+
+    def scalar_mul(self, s, p):
+        out = np.empty(192, np.uint8)
+        lib().tko_g2_scalar_mul(_p(s), _p(p), _p(out))
+        return out
+
+    def random_bases(self, seed, n, first=0):
+        out = np.empty(192 * n, np.uint8)
+        lib().tko_g2_random_bases(_u64(seed), _sz(first), _sz(n), _p(out))
+        return out
+
+    def msm_naive(self, s, p):
+        out = np.empty(192, np.uint8)
+        lib().tko_g2_msm_naive(_p(s), _p(p), _sz(s.size // 32), _p(out))
+        return out
+
+    def msm(self, s, p, threads=0):
+        out = np.empty(192, np.uint8)
+        lib().tko_g2_msm(_p(s), _p(p), _sz(s.size // 32), int(threads), _p(out))
+        return out
+
+
+g2 = _G2()
+
+
 class _Bn254:
     """BN254 (alt_bn128) instantiation of the oracle's field / G1 code: Fr and Fq 32 B, affine 64 B, projective 96 B.
     Same method names as the module-level BLS12-381 functions."""

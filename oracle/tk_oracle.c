@@ -190,6 +190,7 @@ static bnq_t bn_CURVE_B; /* curve constant 3 (Montgomery) */
 static fr_t FR_ROOT32;   /* w_{2^32} = g^((r-1)/2^32) (Montgomery), g = TKMK_BLS12_381_FR_ROOT_GENERATOR (include/tkmk.h) */
 static bnr_t BNR_ROOT28; /* BN254: w_{2^28} = 5^((r-1)/2^28) (Montgomery) */
 
+static void g2_init(void);
 static void tko_init(void) {
     if (fr_ready && fq_ready) return;
 #pragma omp critical(tko_init_lock)
@@ -200,6 +201,7 @@ static void tko_init(void) {
             memset(&four, 0, sizeof four);
             four.l[0] = 4;
             fq_to_mont(&g1_CURVE_B, &four);
+            g2_init();
             bnq_init(BNQ_MOD);
             bnr_init(BNR_MOD);
             bnq_t three;
@@ -433,6 +435,69 @@ static const uint32_t g1_GEN_Y[12] = {1187375073u, 212476713u,  2726857444u, 349
 #define G(x) g1_##x
 #define TKO(x) tko_g1_##x
 #define FQB 48
+#include "tk_g1.inc"
+#undef FQ
+#undef FS
+#undef G
+#undef TKO
+#undef FQB
+
+/* ------------------------------------------------------------------------------------------
+ * G2 of BLS12-381: the same curve-generic code over Fp2 = Fq[u] / (u^2 + 1), twist y^2 = x^3 + 4(1 + u).  The reference has no G2
+ * MSM call site (G2 appears as nine scalar multiplications in Sigma2::gen, libs/src/group_structures/mod.rs:752-777, and in the
+ * verifier's pairings); BASELINE.json's north_star names "G1/G2", so the product has bls12_381_g2_msm and this is its oracle twin.
+ * Encoding (libs/src/iotools/mod.rs:1709-1713 G2SerdeRkyv; tests/test_g2.py pins it on the reference's fixed G2 generator): a
+ * 96-byte Fp2 element = real part then imaginary part, 48-byte little-endian each; a point = x then y; all zero = infinity.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { fq_t c0, c1; } fq2_t;
+static fq2_t fq2_R1;    /* 1 */
+static fq2_t g2_CURVE_B; /* 4 + 4u (Montgomery) */
+static inline void fq2_add(fq2_t *o, const fq2_t *a, const fq2_t *b) { fq_add(&o->c0, &a->c0, &b->c0); fq_add(&o->c1, &a->c1, &b->c1); }
+static inline void fq2_sub(fq2_t *o, const fq2_t *a, const fq2_t *b) { fq_sub(&o->c0, &a->c0, &b->c0); fq_sub(&o->c1, &a->c1, &b->c1); }
+static inline void fq2_neg(fq2_t *o, const fq2_t *a) { fq_neg(&o->c0, &a->c0); fq_neg(&o->c1, &a->c1); }
+static inline int fq2_is_zero(const fq2_t *a) { return fq_is_zero(&a->c0) && fq_is_zero(&a->c1); }
+static inline int fq2_eq(const fq2_t *a, const fq2_t *b) { return fq_eq(&a->c0, &b->c0) && fq_eq(&a->c1, &b->c1); }
+static inline void fq2_mul(fq2_t *o, const fq2_t *a, const fq2_t *b) { /* schoolbook: (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u */
+    fq_t t0, t1, t2, t3;
+    fq_mul(&t0, &a->c0, &b->c0);
+    fq_mul(&t1, &a->c1, &b->c1);
+    fq_mul(&t2, &a->c0, &b->c1);
+    fq_mul(&t3, &a->c1, &b->c0);
+    fq_sub(&o->c0, &t0, &t1);
+    fq_add(&o->c1, &t2, &t3);
+}
+static inline void fq2_sqr(fq2_t *o, const fq2_t *a) { fq2_mul(o, a, a); }
+static void fq2_inv(fq2_t *o, const fq2_t *a) { /* conj(a) / (a0^2 + a1^2) */
+    fq_t n, t, ni;
+    fq_sqr(&n, &a->c0);
+    fq_sqr(&t, &a->c1);
+    fq_add(&n, &n, &t);
+    fq_inv(&ni, &n);
+    fq_mul(&o->c0, &a->c0, &ni);
+    fq_neg(&t, &a->c1);
+    fq_mul(&o->c1, &t, &ni);
+}
+static inline void fq2_load(fq2_t *o, const uint8_t *b) { fq_load(&o->c0, b); fq_load(&o->c1, b + 48); }
+static inline void fq2_store(uint8_t *b, const fq2_t *a) { fq_store(b, &a->c0); fq_store(b + 48, &a->c1); }
+/* the standard G2 generator of BLS12-381 (the constant both arkworks and zkcrypto publish), u32 LE limbs: x.c0, x.c1, y.c0, y.c1 */
+static const uint32_t g2_GEN_X[24] = {0xc121bdb8, 0xd48056c8, 0xa805bbef, 0x0bac0326, 0x7ae3d177, 0xb4510b64, 0xfa403b02, 0xc6e47ad4, 0x2dc51051, 0x26080527, 0xf08f0a91, 0x024aa2b2,
+                                      0x5d042b7e, 0xe5ac7d05, 0x13945d57, 0x334cf112, 0xdc7f5049, 0xb5da61bb, 0x9920b61a, 0x596bd0d0, 0x88274f65, 0x7dacd3a0, 0x52719f60, 0x13e02b60};
+static const uint32_t g2_GEN_Y[24] = {0x08b82801, 0xe1935486, 0x3baca289, 0x923ac9cc, 0x5160d12c, 0x6d429a69, 0x8cbdd3a7, 0xadfd9baa, 0xda2e351a, 0x8cc9cdc6, 0x727d6e11, 0x0ce5d527,
+                                      0xf05f79be, 0xaaa9075f, 0x5cec1da1, 0x3f370d27, 0x572e99ab, 0x267492ab, 0x85a763af, 0xcb3e287e, 0x2bc28b99, 0x32acd2b0, 0x2ea734cc, 0x0606c4a0};
+static void g2_init(void) {
+    memset(&fq2_R1, 0, sizeof fq2_R1);
+    fq2_R1.c0 = fq_R1;
+    fq_t four;
+    memset(&four, 0, sizeof four);
+    four.l[0] = 4;
+    fq_to_mont(&g2_CURVE_B.c0, &four);
+    g2_CURVE_B.c1 = g2_CURVE_B.c0;
+}
+#define FQ(x) fq2_##x
+#define FS(x) fr_##x
+#define G(x) g2_##x
+#define TKO(x) tko_g2_##x
+#define FQB 96
 #include "tk_g1.inc"
 #undef FQ
 #undef FS

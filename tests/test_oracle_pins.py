@@ -299,3 +299,39 @@ def test_bn254_constants(oracle):
         acc = add(acc, mul(k, P))
     assert oracle.to_ints(bn.g1_msm(s, pts), 32) == list(acc)
     assert (bn.g1_msm(s, pts) == bn.g1_msm_naive(s, pts)).all()
+
+
+def test_g2_instantiation_against_independent_bigint_g2(oracle, tkmk):
+    """oracle.g2 (the curve-generic C code over Fp2) against tkmk/g2.py's Python big-int Jacobian arithmetic, which tests/test_g2.py
+    pins on the reference's fixed G2 generator (setup/trusted-setup/src/main.rs:75-78) and on the standard generator's order."""
+    from tkmk import g2 as big
+    import random
+    G = oracle.g2
+    gen = G.generator()
+    assert G.on_curve(gen) and (gen == big.encode(big.STD_G2)).all()
+    fixed = big.encode(big.from_hex_pair(PINS["fixed_tau_g2_x"], PINS["fixed_tau_g2_y"]))
+    assert G.on_curve(fixed)
+    bad = fixed.copy()
+    bad[0] ^= 1
+    assert not G.on_curve(bad)
+    rnd = random.Random(17)
+    le = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), np.uint8).copy()
+    for base in (big.STD_G2, big.decode(fixed)):
+        enc = big.encode(base)
+        for k in (1, 2, 3, big.R - 1, rnd.randrange(big.R), rnd.randrange(1 << 64)):
+            assert (G.scalar_mul(le(k), enc) == big.encode(big.scalar_mul(k, base))).all(), k
+        assert not G.scalar_mul(le(0), enc).any()
+        a, b = big.scalar_mul(rnd.randrange(big.R), base), big.scalar_mul(rnd.randrange(big.R), base)
+        assert (G.add(big.encode(a), big.encode(b)) == big.encode(big.add(a, b))).all()
+        assert (G.add(big.encode(a), big.encode(a)) == big.encode(big.scalar_mul(2, a))).all()        # doubling through add
+        assert not G.add(big.encode(a), G.neg(big.encode(a))).any()
+    # [r - 1] G = -G (the generator has order r), MSM == naive == big-int sum
+    assert (G.scalar_mul(le(big.R - 1), gen) == G.neg(gen)).all()
+    n = 40
+    s, pts = oracle.fr_random(23, n), G.random_bases(24, n)
+    acc = None
+    for i in range(n):
+        p = big.decode(pts[192 * i:192 * i + 192])
+        assert big.on_curve(p)
+        acc = big.add(acc, big.scalar_mul(int.from_bytes(bytes(s[32 * i:32 * i + 32]), "little"), p))
+    assert (G.msm(s, pts) == big.encode(acc)).all() and (G.msm_naive(s, pts) == big.encode(acc)).all()

@@ -82,7 +82,7 @@ SYMBOLS = [
     "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
     "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
     "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
-    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_keccak256", "tkmk_r1cs_index", "tkmk_msm_default_config", "bls12_381_msm", "bls12_381_msm_precompute_bases", "bn254_msm_precompute_bases", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "bn254_get_root_of_unity", "bn254_ntt_init_domain", "bn254_ntt_release_domain",
+    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_keccak256", "tkmk_r1cs_index", "tkmk_msm_default_config", "bls12_381_msm", "bls12_381_g2_msm", "bls12_381_msm_precompute_bases", "bn254_msm_precompute_bases", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "bn254_get_root_of_unity", "bn254_ntt_init_domain", "bn254_ntt_release_domain",
     "bn254_ntt", "tkmk_bn254_bintt", "tkmk_bn254_fr_random_device",
     "tkmk_bn254_g1_batch_scalar_mul_device",
     "tkmk_ntt_default_config", "bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain",
@@ -428,6 +428,26 @@ def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize
     cfg.are_points_montgomery_form = points_montgomery
     out = np.empty(aff // 2 * 3 * batch, np.uint8)
     _check(getattr(lib(), sym)(_p(scalars), _p(bases), int(n), ctypes.byref(cfg), _p(out)), sym)
+    return out
+
+
+def msm_g2(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize=0, stream=None, scalars_montgomery=False,
+           points_montgomery=False):
+    """G2 MSM (bls12_381_g2_msm): bases are 192-byte affine records (x.c0, x.c1, y.c0, y.c1; all zeros = infinity); returns `batch`
+    canonical projective results (288 B each) on the host"""
+    cfg = lib().tkmk_msm_default_config()
+    n = _len(scalars) // (32 * batch) if msm_size is None else msm_size
+    cfg.batch_size = batch
+    cfg.are_points_shared_in_batch = shared_points
+    cfg.are_scalars_on_device = _on_dev(scalars)
+    cfg.are_points_on_device = _on_dev(bases)
+    cfg.c = c
+    cfg.bitsize = bitsize
+    cfg.stream_handle = stream
+    cfg.are_scalars_montgomery_form = scalars_montgomery
+    cfg.are_points_montgomery_form = points_montgomery
+    out = np.empty(288 * batch, np.uint8)
+    _check(lib().bls12_381_g2_msm(_p(scalars), _p(bases), int(n), ctypes.byref(cfg), _p(out)), "bls12_381_g2_msm")
     return out
 
 
