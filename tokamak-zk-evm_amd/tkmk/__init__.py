@@ -436,7 +436,7 @@ def msm_g2(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bits
     """G2 MSM (bls12_381_g2_msm): bases are 192-byte affine records (x.c0, x.c1, y.c0, y.c1; all zeros = infinity); returns `batch`
     canonical projective results (288 B each) on the host"""
     cfg = lib().tkmk_msm_default_config()
-    n = _len(scalars) // (32 * batch) if msm_size is None else msm_size
+    n = _len(scalars) // batch if msm_size is None else msm_size
     cfg.batch_size = batch
     cfg.are_points_shared_in_batch = shared_points
     cfg.are_scalars_on_device = _on_dev(scalars)
