@@ -3,7 +3,8 @@
 // packages/backend/libs/src/field_structures/mod.rs:67-165).  The C++ twin of tkmk/setup.py, whose payload it must reproduce byte for byte
 // (tests/test_gpu_prove.py::test_native_setup_binary): Lagrange values by one inverse NTT of the power vector, the QAP mixture through
 // tkmk_r1cs_eval_rows on the transposed sparse matrices, outer products with gathers + a vector multiplication, every G1 point through the
-// fixed-base batched scalar multiplication; Sigma2's ten G2 points on the host (tkmk_g2.hpp).
+// fixed-base batched scalar multiplication; Sigma2's ten G2 points through bls12_381_g2_msm (the generator is validated on the
+// host, tkmk_g2.hpp).
 #pragma once
 #include <algorithm>
 #include <fstream>
@@ -172,7 +173,20 @@ struct Sigma {
         if (g2_gen) {   // Sigma2::gen (:752-777) and H
             if (g2_gen->inf || !g2h::on_curve(*g2_gen)) throw Error("the G2 generator is not a point of the twist");
             ScalarField ks[10] = {one, tau.alpha, a2, apow[3], a4, tau.gamma, tau.delta, tau.eta, tau.x, tau.y};
-            for (int i = 0; i < 10; i++) out.g2[i] = g2h::encode(g2h::scalar_mul(ks[i], *g2_gen));
+            // ten multiples of one point = a batch of one-point G2 MSMs over shared points (bls12_381_g2_msm); results come back
+            // as (x_affine, y_affine, 1) or (0, 1, 0)
+            std::array<uint8_t, 192> h = g2h::encode(*g2_gen);
+            tkmk_msm_config cfg = tkmk_msm_default_config();
+            cfg.batch_size = 10;
+            cfg.are_points_shared_in_batch = true;
+            std::vector<tkmk_g2_projective> res(10);
+            check(bls12_381_g2_msm(reinterpret_cast<const tkmk_fr *>(ks), reinterpret_cast<const tkmk_g2_affine *>(h.data()), 1, &cfg, res.data()), "g2 msm");
+            for (int i = 0; i < 10; i++) {
+                const uint8_t *r = reinterpret_cast<const uint8_t *>(&res[i]);
+                bool inf = true;
+                for (int b = 192; b < 288; b++) inf = inf && r[b] == 0;
+                if (!inf) std::memcpy(out.g2[i].data(), r, 192);
+            }
         }
         return out;
     }

@@ -13,7 +13,7 @@ Where the work runs:
   * every point as one fixed-base batched scalar multiplication (tkmk_g1_batch_scalar_mul_device): 2^22 .. 2^24 of them
     for xy_powers, (m_D - l_D) * s_max for delta_inv_li_o_prv.
 Sigma2 (H and its nine multiples by the trapdoor scalars, consumed only by the pairing verifiers) is ten single-point operations;
-they run on the host (tkmk/g2.py), as in the reference; without a G2 generator the payload's G2 section is left zero.
+they run as one batch of one-point G2 MSMs (bls12_381_g2_msm; tkmk/g2.py's big-int version is the check in the tests); without a G2 generator the payload's G2 section is left zero.
 """
 import json
 import os
@@ -172,7 +172,11 @@ class Sigma:
         g2_points = None
         if g2_gen is not None:               # Sigma2::gen (:752-777) and H
             from tkmk import g2
-            g2_points = g2.sigma2_gen(tau, g2_gen)
+            if g2_gen is None or not g2.on_curve(g2_gen):
+                raise ValueError("the G2 generator is not a point of the twist")
+            ks = [1, a % R, a * a % R, pow(a, 3, R), pow(a, 4, R), tau["gamma"] % R, tau["delta"] % R, tau["eta"] % R, x % R, y % R]
+            res = tkmk.msm_g2(_frs(ks), g2.encode(g2_gen), msm_size=1, batch=10, shared_points=True).reshape(10, 288)
+            g2_points = [g2.decode(r[:192]) if r[192:].any() else None for r in res]      # (x, y, 1) or (0, 1, 0)
         return cls(sigma1, tables, singles, sp, g2_points)
 
     def prover_view(self):
