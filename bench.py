@@ -31,6 +31,7 @@ MSM points / NTT elements: a LOWER bound on CPU prove time (polynomial bookkeepi
 Secondary objects (N = 1; each records {"error": ...} instead of costing the line if it fails):
   production_2p20  the reference's production shape (s_max = 256, 166 placements; published walls 45.70 s CPU / 21.08 s CUDA)
   msm_2p24         BASELINE.json configs[1]: 2^24-point G1 MSM, BLS12-381 and (as worded) BN254
+  msm_2p28_one_gpu BASELINE.json configs[4]'s operands on one GPU: a rank's 2^25-point shard and the whole 2^28-point MSM
   ntt              BASELINE.json configs[2]: 256 x 2^20 scalar-field NTTs, and the production _biNTT
 """
 import argparse
@@ -65,7 +66,7 @@ def main():
     ap.add_argument("--s-max", type=int, default=1024, help="1024 = BASELINE.json configs[3] (2^22 constraint slots); 256 = the reference's production shape")
     ap.add_argument("--placements", type=int, default=None, help="used placements (default: all s_max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip production_2p20 / msm_2p24 / ntt")
+    ap.add_argument("--no-secondary", action="store_true", help="skip production_2p20 / msm_2p24 / ntt / msm_2p28_one_gpu")
     ap.add_argument("--msm-sharded", action="store_true", help="N > 1: also time the point-sharded MSM of BASELINE.json configs[4] (2^25 points per rank)")
     ap.add_argument("--msm-sharded-logn", type=int, default=25)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
@@ -217,6 +218,8 @@ def main():
                 leg("msm_2p24", lambda: _msm_leg(tkmk))
                 tkmk.release_scratch()
                 leg("ntt", lambda: _ntt_secondary(tkmk))
+                tkmk.release_scratch()
+                leg("msm_2p28_one_gpu", lambda: _msm_2p28_leg(tkmk))
             print(json.dumps(out), flush=True)
     finally:
         if dist is not None:
@@ -341,6 +344,41 @@ def _msm_leg(tkmk):
                       "group_adds_per_s": n / dt * ADDS_PER_POINT, "accumulate_kernel_ms": acc_ms / acc_cnt if acc_cnt else None,
                       "hbm_frac_of_peak": (n * bytes_pt / (acc_ms / acc_cnt * 1e-3) / 1e9 / HBM_PEAK_GBS) if acc_cnt else None}
         tkmk.release_scratch()
+    return res
+
+
+def _msm_2p28_leg(tkmk):
+    """BASELINE.json configs[4]'s operands (2^28 points) on ONE GPU: a rank's 2^25-point shard, and the whole MSM in one call (34 GB of
+    operands resident in HBM).  The 8-GPU job itself is `bench.py --gpus 8 --msm-sharded` (one all-gather of 144-byte partials)."""
+    import ctypes
+    n_shard, shards = 1 << 25, 8
+    n = n_shard * shards
+    gen = np.frombuffer(bytes(_generator()), np.uint8).copy()
+    s = tkmk.fr_random_device(SEED + 7, n)
+    b = tkmk.DeviceBuffer(96 * n)
+    for j in range(shards):
+        h = tkmk.fr_random_device(SEED + 8, n_shard, first=j * n_shard)
+        pj = tkmk.g1_batch_scalar_mul_device(h, gen, n_shard)
+        tkmk._check(tkmk.lib().tkmk_memcpy_d2d(ctypes.c_void_p(b.ptr + 96 * n_shard * j), ctypes.c_void_p(pj.ptr), ctypes.c_size_t(96 * n_shard)), "tkmk_memcpy_d2d")
+        h.free()
+        pj.free()
+    res = {}
+    s0, b0 = tkmk.DeviceBuffer(32 * n_shard), tkmk.DeviceBuffer(96 * n_shard)
+    tkmk._check(tkmk.lib().tkmk_memcpy_d2d(ctypes.c_void_p(s0.ptr), ctypes.c_void_p(s.ptr), ctypes.c_size_t(32 * n_shard)), "tkmk_memcpy_d2d")
+    tkmk._check(tkmk.lib().tkmk_memcpy_d2d(ctypes.c_void_p(b0.ptr), ctypes.c_void_p(b.ptr), ctypes.c_size_t(96 * n_shard)), "tkmk_memcpy_d2d")
+    for key, sc, ba, pts, reps in (("shard_2p25", s0, b0, n_shard, 3), ("whole_2p28", s, b, n, 2)):
+        tkmk.msm(sc, ba)
+        tkmk.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            tkmk.msm(sc, ba)
+        tkmk.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[key] = {"ms_per_msm": dt * 1e3, "points_per_s": pts / dt}
+    for x in (s, b, s0, b0):
+        x.free()
+    tkmk.release_scratch()
+    res["workload"] = "BLS12-381 G1 MSM, operands resident in HBM; correctness of both shapes: tests/test_gpu_baseline_sizes.py"
     return res
 
 

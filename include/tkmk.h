@@ -415,6 +415,18 @@ typedef struct { uint8_t op; uint8_t arg; } tkmk_expr_instr;
 tkmk_error tkmk_poly_expr_eval(const tkmk_expr_instr *prog, uint32_t n_instr, const tkmk_fr *const *leaves_dev, uint32_t n_leaves,
                                const tkmk_fr *consts, uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev,
                                tkmk_stream stream);
+/* The same evaluator over leaf VIEWS.  x_len is x_size or 1, y_len is y_size or 1 (a vector broadcast along the other axis: the
+ * evaluations of an X-only or Y-only polynomial, which then cost a 1-D transform); element (i, j) of the domain reads
+ * data[((i - rot_x) mod x_len) * y_len + ((j - rot_y) mod y_len)]: a rotation is the evaluation-domain form of
+ * p(w_x^-rot_x X, w_y^-rot_y Y) (prove2's r(w^-1 X, Y), lib.rs:1969-1975, shares r's evaluations instead of a transform of its
+ * own).  x_size and y_size must be powers of two. */
+typedef struct {
+    const tkmk_fr *data;          /* device */
+    uint32_t x_len, y_len, rot_x, rot_y;
+} tkmk_expr_leaf;
+tkmk_error tkmk_poly_expr_eval_views(const tkmk_expr_instr *prog, uint32_t n_instr, const tkmk_expr_leaf *leaves, uint32_t n_leaves,
+                                     const tkmk_fr *consts, uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev,
+                                     tkmk_stream stream);
 /* eval_x / eval_y / eval (mod.rs:1719-1750): out_dev has y_size / x_size elements; out_host one */
 tkmk_error tkmk_poly_eval_x(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, tkmk_fr *out_dev,
                             tkmk_stream stream);

@@ -357,3 +357,60 @@ def test_poly_lincomb_fused_pass(gpu, oracle):
     for bad in ([(one, buf, 8, 8, 1, 0)], [(one, buf, 8, 8, 0, 1)], [(one, buf, 16, 4)]):     # a shifted operand must fit into out
         with pytest.raises(gpu.TkmkError):
             gpu.poly_lincomb(bad, 8, 8)
+
+
+def test_expr_leaf_views(P, gpu, oracle):
+    """tkmk_poly_expr_eval_views: broadcast vectors and rotated matrices as leaves.  (a) index algebra against numpy rolls /
+    repeats; (b) the reason the views exist: on a domain that contains the sub-domain's root, the evaluations of
+    p(w^-1 X, Y) are p's evaluations rotated by domain/order rows, and an X-only polynomial's evaluations are a column vector
+    — both against the transform-everything route on the coefficients"""
+    xs, ys = 32, 8
+    n = xs * ys
+    la, lb = oracle.fr_random(150, n), oracle.fr_random(151, n)
+    vx, vy = oracle.fr_random(152, xs), oracle.fr_random(153, ys)
+    k1 = oracle.fr_random(160, 1)
+    da, db, dx, dy = (gpu.DeviceBuffer.from_host(v) for v in (la, lb, vx, vy))
+    mul, add, sub = oracle.fr_mul, oracle.fr_add, oracle.fr_sub
+    LEAF, CONST, ADD, SUB, MUL, SCALE, XM1 = range(7)
+    A = np.asarray(la).reshape(xs, ys, 32)
+    rolled = np.ascontiguousarray(np.roll(A, (5, 3), axis=(0, 1))).reshape(-1)          # [i][j] <- A[i - 5][j - 3]
+    bx = np.ascontiguousarray(np.repeat(np.asarray(vx).reshape(xs, 1, 32), ys, axis=1)).reshape(-1)
+    by = np.ascontiguousarray(np.tile(np.asarray(vy).reshape(1, ys, 32), (xs, 1, 1))).reshape(-1)
+    leaves = [(da, xs, ys, 5, 3), (db, xs, ys, 0, 0), (dx, xs, 1, 0, 0), (dy, 1, ys, 0, 0), (dx, xs, 1, 31, 0), (dy, 1, ys, 0, 7)]
+    bx31 = np.ascontiguousarray(np.repeat(np.roll(np.asarray(vx).reshape(xs, 32), 31, axis=0).reshape(xs, 1, 32), ys, axis=1)).reshape(-1)
+    by7 = np.ascontiguousarray(np.tile(np.roll(np.asarray(vy).reshape(ys, 32), 7, axis=0).reshape(1, ys, 32), (xs, 1, 1))).reshape(-1)
+    cases = [([(LEAF, 0)], rolled),
+             ([(LEAF, 0), (LEAF, 1), (MUL, 0)], mul(rolled, lb)),
+             ([(LEAF, 2), (LEAF, 3), (MUL, 0), (LEAF, 1), (ADD, 0)], add(mul(bx, by), lb)),               # outer product + matrix
+             ([(LEAF, 4), (LEAF, 5), (SUB, 0), (SCALE, 0), (LEAF, 0), (MUL, 0)], mul(oracle.fr_scalar_mul(k1, sub(bx31, by7)), rolled))]
+    for prog, want in cases:
+        assert (gpu.poly_expr_eval_views(prog, leaves, k1, 1, xs, ys).to_host() == want).all(), prog
+    for bad in ([(da, xs, ys, xs, 0)], [(da, xs, ys, 0, ys)], [(dx, xs // 2, 1, 0, 0)], [(dy, 1, 3, 0, 0)]):
+        with pytest.raises(gpu.TkmkError):
+            gpu.poly_expr_eval_views([(LEAF, 0)], bad, k1, 1, xs, ys)
+    with pytest.raises(gpu.TkmkError):
+        gpu.poly_expr_eval_views([(LEAF, 0)], [(da, 24, ys, 0, 0)], k1, 1, 24, ys)                   # sizes must be powers of two
+    # (b) p(w_8^-1 X, w_4^-1 Y) on the 32 x 8 domain = p's evaluations rotated by (32/8, 8/4); X-only polynomial = column vector
+    gpu.init_ntt_domain_for_size(1 << 12)
+    R = oracle.R_MOD
+    px, py = 8, 4
+    coeffs = oracle.fr_random(170, px * py)
+    p = P.from_coeffs(gpu.DeviceBuffer.from_host(coeffs), px, py)
+    wix = pow(oracle.to_ints(oracle.root_of_unity(px), 32)[0], R - 2, R)
+    wiy = pow(oracle.to_ints(oracle.root_of_unity(py), 32)[0], R - 2, R)
+    shifted = p.scale_coeffs_x(oracle.to_bytes([wix], 32)).scale_coeffs_y(oracle.to_bytes([wiy], 32))
+    q = p.clone()
+    q.resize(xs, ys)
+    ev_p = q.to_rou_evals()
+    q = shifted.clone()
+    q.resize(xs, ys)
+    want = q.to_rou_evals().to_host()
+    got = gpu.poly_expr_eval_views([(LEAF, 0)], [(ev_p, xs, ys, xs // px, ys // py)], k1, 1, xs, ys).to_host()
+    assert (got == want).all()
+    ux = P.from_coeffs(gpu.DeviceBuffer.from_host(oracle.fr_random(171, px)), px, 1)
+    col = ux.clone()
+    col.resize(xs, 1)
+    col_ev = col.to_rou_evals()
+    full = ux.clone()
+    full.resize(xs, ys)
+    assert (gpu.poly_expr_eval_views([(LEAF, 0)], [(col_ev, xs, 1, 0, 0)], k1, 1, xs, ys).to_host() == full.to_rou_evals().to_host()).all()

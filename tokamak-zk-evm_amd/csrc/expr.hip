@@ -32,11 +32,19 @@ enum {
     X_FROMMONT_TOP = 9,
 };
 
+// a leaf operand: element (ix, iy) of the domain reads data[((ix - rot_x) & xmask) * y_len + ((iy - rot_y) & ymask)].  A full matrix
+// has xmask = x_size - 1, ymask = y_size - 1; a vector broadcast along Y has ymask = 0, y_len = 1 (X-only polynomials), along X
+// xmask = 0 (Y-only); a rotation by (rot_x, rot_y) is the evaluation-domain form of p(w_x^-rot_x X, w_y^-rot_y Y)
+struct expr_leaf_t {
+    const fr_t *data;
+    uint32_t xmask, ymask, y_len, rot_x, rot_y;
+    uint32_t plain;   // 1: no view, address = linear element index
+};
 struct expr_args_t {
     uint32_t n_instr;
     uint8_t op[EXPR_MAX_INSTR];
     uint8_t arg[EXPR_MAX_INSTR];
-    const fr_t *leaf[EXPR_MAX_LEAVES];
+    expr_leaf_t leaf[EXPR_MAX_LEAVES];
     fr_t cst[EXPR_MAX_CONSTS];   // Montgomery
 };
 
@@ -58,16 +66,22 @@ __global__ __launch_bounds__(256) void k_expr_eval(expr_args_t a, const fr_t *__
     };
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + t; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t sp = 0;  // number of live stack levels (uniform over the wave: the program is)
+        const uint32_t ix = (uint32_t)(e / y_size), iy = (uint32_t)(e - (uint64_t)ix * y_size);
         for (uint32_t pc = 0; pc < a.n_instr; pc++) {
             const uint32_t op = a.op[pc], arg = a.arg[pc];
             switch (op) {
-                case X_PUSH_LEAF: put(sp++, Fr::canon(tk_load(a.leaf[arg] + e))); break;
+                case X_PUSH_LEAF: {
+                    const expr_leaf_t &L = a.leaf[arg];
+                    uint64_t at = L.plain ? e : (uint64_t)((ix - L.rot_x) & L.xmask) * L.y_len + ((iy - L.rot_y) & L.ymask);
+                    put(sp++, Fr::canon(tk_load(L.data + at)));
+                    break;
+                }
                 case X_PUSH_CONST: put(sp++, a.cst[arg]); break;
                 case X_ADD: put(sp - 2, Fr::add(get(sp - 2), get(sp - 1))); sp--; break;
                 case X_SUB: put(sp - 2, Fr::sub(get(sp - 2), get(sp - 1))); sp--; break;
                 case X_MULM: put(sp - 2, Fr::mul(get(sp - 2), get(sp - 1))); sp--; break;
                 case X_SCALE: put(sp - 1, Fr::mul(get(sp - 1), a.cst[arg])); break;
-                case X_XM1: put(sp - 1, Fr::mul(get(sp - 1), tk_load(xm1 + (uint32_t)(e / y_size)))); break;
+                case X_XM1: put(sp - 1, Fr::mul(get(sp - 1), tk_load(xm1 + ix))); break;
                 case X_TOMONT_TOP: put(sp - 1, Fr::to_mont(get(sp - 1))); break;
                 case X_TOMONT_SECOND: put(sp - 2, Fr::to_mont(get(sp - 2))); break;
                 default: put(sp - 1, Fr::from_mont(get(sp - 1))); break;  // X_FROMMONT_TOP
@@ -102,18 +116,50 @@ struct emitter {
 };
 }  // namespace
 
+static tkmk_error expr_eval_impl(const tkmk_expr_instr *prog, uint32_t n_instr, expr_args_t &a, uint32_t n_leaves, const tkmk_fr *consts,
+                                 uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev, tkmk_stream stream);
+
 TK_API tkmk_error tkmk_poly_expr_eval(const tkmk_expr_instr *prog, uint32_t n_instr, const tkmk_fr *const *leaves_dev, uint32_t n_leaves,
                                       const tkmk_fr *consts, uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev,
                                       tkmk_stream stream) {
     if (!prog || !out_dev || (n_leaves && !leaves_dev) || (n_consts && !consts)) return TKMK_ERR_INVALID_POINTER;
     if (!n_instr || !x_size || !y_size || n_leaves > EXPR_MAX_LEAVES || n_consts > EXPR_MAX_CONSTS) return TKMK_ERR_INVALID_ARGUMENT;
-    TK_TRY(tk_require_device());
     expr_args_t a;
     memset(&a, 0, sizeof a);
     for (uint32_t k = 0; k < n_leaves; k++) {
         if (!leaves_dev[k]) return TKMK_ERR_INVALID_POINTER;
-        a.leaf[k] = (const fr_t *)leaves_dev[k];
+        a.leaf[k].data = (const fr_t *)leaves_dev[k];
+        a.leaf[k].plain = 1;
     }
+    return expr_eval_impl(prog, n_instr, a, n_leaves, consts, n_consts, x_size, y_size, out_dev, stream);
+}
+
+// the same evaluator over leaf VIEWS (include/tkmk.h tkmk_expr_leaf): vectors broadcast along one axis and cyclic rotations of a
+// matrix, so that X-only / Y-only polynomials cost a 1-D transform and p(w^-1 X, Y) shares p's evaluations
+TK_API tkmk_error tkmk_poly_expr_eval_views(const tkmk_expr_instr *prog, uint32_t n_instr, const tkmk_expr_leaf *leaves, uint32_t n_leaves,
+                                            const tkmk_fr *consts, uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev,
+                                            tkmk_stream stream) {
+    if (!prog || !out_dev || (n_leaves && !leaves) || (n_consts && !consts)) return TKMK_ERR_INVALID_POINTER;
+    if (!n_instr || !x_size || !y_size || n_leaves > EXPR_MAX_LEAVES || n_consts > EXPR_MAX_CONSTS) return TKMK_ERR_INVALID_ARGUMENT;
+    if ((x_size & (x_size - 1)) || (y_size & (y_size - 1))) return TKMK_ERR_INVALID_ARGUMENT;   // rotations are taken modulo the sizes
+    expr_args_t a;
+    memset(&a, 0, sizeof a);
+    for (uint32_t k = 0; k < n_leaves; k++) {
+        const tkmk_expr_leaf &l = leaves[k];
+        if (!l.data) return TKMK_ERR_INVALID_POINTER;
+        if ((l.x_len != x_size && l.x_len != 1) || (l.y_len != y_size && l.y_len != 1)) return TKMK_ERR_INVALID_ARGUMENT;
+        if (l.rot_x >= l.x_len || l.rot_y >= l.y_len) return TKMK_ERR_INVALID_ARGUMENT;
+        a.leaf[k].data = (const fr_t *)l.data;
+        a.leaf[k].xmask = l.x_len - 1, a.leaf[k].ymask = l.y_len - 1, a.leaf[k].y_len = l.y_len;
+        a.leaf[k].rot_x = l.rot_x, a.leaf[k].rot_y = l.rot_y;
+        a.leaf[k].plain = (l.x_len == x_size && l.y_len == y_size && !l.rot_x && !l.rot_y) ? 1u : 0u;
+    }
+    return expr_eval_impl(prog, n_instr, a, n_leaves, consts, n_consts, x_size, y_size, out_dev, stream);
+}
+
+static tkmk_error expr_eval_impl(const tkmk_expr_instr *prog, uint32_t n_instr, expr_args_t &a, uint32_t n_leaves, const tkmk_fr *consts,
+                                 uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev, tkmk_stream stream) {
+    TK_TRY(tk_require_device());
     for (uint32_t k = 0; k < n_consts; k++) {
         fr_t c;
         for (int i = 0; i < 8; i++) c.l[i] = consts[k].limbs[i];

@@ -12,7 +12,11 @@
 // host for find_degree / resize / mul_monomial / scaling / divisions).  Header-only; link with -ltkmk_hip.
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdarg>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -34,6 +38,23 @@ struct Error : std::runtime_error {
 };
 inline void check(tkmk_error e, const char *where) {
     if (e != TKMK_SUCCESS) throw Error(e, where);
+}
+// TKMK_HOST_TRACE=1: one stderr line per transform / commit batch / division issued by the host side (sizes and a host clock),
+// to read a proof's operation sequence next to a kernel trace
+inline bool host_trace_on() {
+    static const bool on = getenv("TKMK_HOST_TRACE") != nullptr;
+    return on;
+}
+inline void host_trace(const char *fmt, ...) {
+    if (!host_trace_on()) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[tkmk host %9.3f ms] ", ms);
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
 }
 
 using ScalarField = tkmk_fr;
@@ -156,12 +177,14 @@ class DensePolynomialExt {
         if (!is_pow2(x_size) || !is_pow2(y_size)) throw Error("The input sizes for from_rou_evals must be powers of two.");
         if (evals.len() < x_size * y_size) throw Error("Insufficient buffer length for from_rou_evals");
         DeviceVec<ScalarField> coeffs(x_size * y_size);
+        host_trace("from_rou_evals %zu x %zu%s", x_size, y_size, coset_x || coset_y ? " coset" : "");
         check(tkmk_bintt(evals.ptr(), x_size, y_size, TKMK_NTT_INVERSE, coset_x, coset_y, true, nullptr, coeffs.ptr()), "_biNTT");
         return from_coeffs(std::move(coeffs), x_size, y_size);
     }
     // to_rou_evals (mod.rs:1646-1674) without the reference's D->H->D round trip
     void to_rou_evals(const ScalarField *coset_x, const ScalarField *coset_y, DeviceVec<ScalarField> &evals) const {
         if (evals.len() < x_size * y_size) throw Error("Insufficient buffer length for to_rou_evals");
+        host_trace("to_rou_evals %zu x %zu%s", x_size, y_size, coset_x || coset_y ? " coset" : "");
         check(tkmk_bintt(poly.ptr(), x_size, y_size, TKMK_NTT_FORWARD, coset_x, coset_y, true, nullptr, evals.ptr()), "_biNTT");
     }
     // evaluations of this polynomial on the xs x ys domain: `resize` + forward _biNTT of the reference (mod.rs:1646-1674, 1920-1960),
@@ -169,11 +192,13 @@ class DensePolynomialExt {
     DeviceVec<ScalarField> evals_on(size_t xs, size_t ys) const {
         if (x_size <= xs && y_size <= ys) {
             DeviceVec<ScalarField> out(xs * ys);
+            host_trace("evals_on %zu x %zu -> %zu x %zu (padded)", x_size, y_size, xs, ys);
             check(tkmk_bintt_padded(poly.ptr(), x_size, y_size, xs, ys, nullptr, nullptr, nullptr, out.ptr()), "_biNTT");
             return out;
         }
         DensePolynomialExt r = clone();   // larger than the domain in one direction: resize drops the (zero) excess first
         r.resize(xs, ys);
+        host_trace("evals_on %zu x %zu -> %zu x %zu (resize)", x_size, y_size, xs, ys);
         check(tkmk_bintt(r.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, r.poly.ptr()), "_biNTT");
         return std::move(r.poly);
     }
@@ -325,6 +350,7 @@ class DensePolynomialExt {
         size_t c = (size_t)denom_x_degree, d = (size_t)denom_y_degree;
         size_t xs = (x_size / c) * c, ys = (y_size / d) * d;
         DeviceVec<ScalarField> qx(xs * ys), qy(c * ys);
+        host_trace("div_by_vanishing_opt %zu x %zu by (%zu, %zu)", xs, ys, c, d);
         check(tkmk_poly_div_by_vanishing_opt(poly.ptr(), (uint32_t)xs, (uint32_t)ys, (uint32_t)c, (uint32_t)d, qx.ptr(), qy.ptr(), nullptr),
               "div_by_vanishing_opt");
         DensePolynomialExt quo_x = from_coeffs(std::move(qx), xs, ys), quo_y = from_coeffs(std::move(qy), c, ys);
@@ -349,12 +375,23 @@ class PolyExpr {
     enum Kind { Poly, Scalar, Add, Sub, Mul, Scale, MulXMinusOne, Sum };
     Kind kind;
     const DensePolynomialExt *leaf = nullptr;
+    size_t shift_ord_x = 0, shift_ord_y = 0;   // a Poly node may stand for leaf(w_ordx^-1 X, w_ordy^-1 Y); 0 = that axis unshifted
     ScalarField scalar_{};
     std::vector<PolyExpr> kids;
 
     static PolyExpr poly(const DensePolynomialExt &p) {
         PolyExpr e{Poly};
         e.leaf = &p;
+        return e;
+    }
+    // p(w_{ord_x}^-1 X, w_{ord_y}^-1 Y) — what the reference builds with scale_coeffs_x / _y before evaluating (prove2's r_omegaX,
+    // r_omegaX_omegaY, lib.rs:1969-1975).  On an evaluation domain whose sizes are multiples of the orders these are p's
+    // evaluations rotated by size/order, so the node shares p's transform.
+    static PolyExpr poly_root_shifted(const DensePolynomialExt &p, size_t ord_x, size_t ord_y) {
+        if ((ord_x && !is_pow2(ord_x)) || (ord_y && !is_pow2(ord_y))) throw Error("root shifts must have power-of-two orders");
+        PolyExpr e{Poly};
+        e.leaf = &p;
+        e.shift_ord_x = ord_x > 1 ? ord_x : 0, e.shift_ord_y = ord_y > 1 ? ord_y : 0;
         return e;
     }
     static PolyExpr scalar(const ScalarField &s) {
@@ -382,30 +419,39 @@ class PolyExpr {
         return out;
     }
 
+    using DegreeMemo = std::map<const DensePolynomialExt *, std::pair<int64_t, int64_t>>;
     std::pair<int64_t, int64_t> degree_bound() const {
+        DegreeMemo memo;   // a leaf that occurs several times is measured once (find_degree is a device round trip)
+        return degree_bound(memo);
+    }
+    std::pair<int64_t, int64_t> degree_bound(DegreeMemo &memo) const {
         switch (kind) {
-            case Poly: return leaf->find_degree();
+            case Poly: {
+                auto it = memo.find(leaf);
+                if (it == memo.end()) it = memo.emplace(leaf, leaf->find_degree()).first;
+                return it->second;
+            }
             case Scalar: return fr_is_zero(scalar_) ? std::make_pair<int64_t, int64_t>(-1, -1) : std::make_pair<int64_t, int64_t>(0, 0);
             case Add:
             case Sub: {
-                auto l = kids[0].degree_bound(), r = kids[1].degree_bound();
+                auto l = kids[0].degree_bound(memo), r = kids[1].degree_bound(memo);
                 return {std::max(l.first, r.first), std::max(l.second, r.second)};
             }
             case Mul: {
-                auto l = kids[0].degree_bound(), r = kids[1].degree_bound();
+                auto l = kids[0].degree_bound(memo), r = kids[1].degree_bound(memo);
                 if (l.first < 0 || l.second < 0 || r.first < 0 || r.second < 0) return {-1, -1};
                 return {l.first + r.first, l.second + r.second};
             }
-            case Scale: return fr_is_zero(scalar_) ? std::make_pair<int64_t, int64_t>(-1, -1) : kids[0].degree_bound();
+            case Scale: return fr_is_zero(scalar_) ? std::make_pair<int64_t, int64_t>(-1, -1) : kids[0].degree_bound(memo);
             case MulXMinusOne: {
-                auto d = kids[0].degree_bound();
+                auto d = kids[0].degree_bound(memo);
                 if (d.first < 0 || d.second < 0) return {-1, -1};
                 return {d.first + 1, d.second};
             }
             default: {
                 std::pair<int64_t, int64_t> acc{-1, -1};
                 for (auto &k : kids) {
-                    auto d = k.degree_bound();
+                    auto d = k.degree_bound(memo);
                     acc = {std::max(acc.first, d.first), std::max(acc.second, d.second)};
                 }
                 return acc;
@@ -423,18 +469,31 @@ class PolyExpr {
         auto d = degree_bound();
         if (domain_size_for_degree(d.first) > target_x_size || domain_size_for_degree(d.second) > target_y_size)
             throw Error("Fused polynomial expression domain is too small for the expression degree.");
-        std::map<const DensePolynomialExt *, std::shared_ptr<DeviceVec<ScalarField>>> cache;
+        LeafCache cache;
         // one kernel pass over the leaf evaluations when the tree fits the device evaluator (tkmk_poly_expr_eval);
         // otherwise node by node
         Program pg;
         int need = compile(pg, 0);
         if (need > 0 && need <= 6 && !pg.leaves.empty() && pg.leaves.size() <= 16 && pg.consts.size() <= 16 && pg.code.size() <= 100) {
-            std::vector<const tkmk_fr *> ptrs;
-            for (const DensePolynomialExt *l : pg.leaves) ptrs.push_back(leaf_evals(l, target_x_size, target_y_size, cache)->ptr());
+            // leaves as VIEWS: an X-only (Y-only) polynomial is transformed in one dimension and broadcast; a root-shifted leaf
+            // reads the unshifted polynomial's evaluations rotated by size / order
+            std::vector<tkmk_expr_leaf> views;
+            for (const Program::Leaf &l : pg.leaves) {
+                const bool col = l.p->y_size == 1 && target_y_size > 1, row = l.p->x_size == 1 && target_x_size > 1;
+                const size_t lx = row ? 1 : target_x_size, ly = col ? 1 : target_y_size;
+                if ((l.ord_x && target_x_size % l.ord_x) || (l.ord_y && target_y_size % l.ord_y))
+                    throw Error("Fused polynomial expression: a root shift's order does not divide the domain.");
+                tkmk_expr_leaf v{};
+                v.data = leaf_evals(l.p, lx, ly, cache)->ptr();
+                v.x_len = (uint32_t)lx, v.y_len = (uint32_t)ly;
+                v.rot_x = (l.ord_x && lx > 1) ? (uint32_t)(target_x_size / l.ord_x) : 0;
+                v.rot_y = (l.ord_y && ly > 1) ? (uint32_t)(target_y_size / l.ord_y) : 0;
+                views.push_back(v);
+            }
             DeviceVec<ScalarField> out(target_x_size * target_y_size);
-            check(tkmk_poly_expr_eval(pg.code.data(), (uint32_t)pg.code.size(), ptrs.data(), (uint32_t)ptrs.size(), pg.consts.data(),
-                                      (uint32_t)pg.consts.size(), (uint32_t)target_x_size, (uint32_t)target_y_size, out.ptr(), nullptr),
-                  "tkmk_poly_expr_eval");
+            check(tkmk_poly_expr_eval_views(pg.code.data(), (uint32_t)pg.code.size(), views.data(), (uint32_t)views.size(), pg.consts.data(),
+                                            (uint32_t)pg.consts.size(), (uint32_t)target_x_size, (uint32_t)target_y_size, out.ptr(), nullptr),
+                  "tkmk_poly_expr_eval_views");
             return DensePolynomialExt::from_rou_evals(out, target_x_size, target_y_size);
         }
         DeviceVec<ScalarField> evals = on_domain(target_x_size, target_y_size, cache);
@@ -449,23 +508,28 @@ class PolyExpr {
         e.kids.push_back(std::move(r));
         return e;
     }
-    using LeafCache = std::map<const DensePolynomialExt *, std::shared_ptr<DeviceVec<ScalarField>>>;
+    using LeafCache = std::map<std::tuple<const DensePolynomialExt *, size_t, size_t>, std::shared_ptr<DeviceVec<ScalarField>>>;
     static std::shared_ptr<DeviceVec<ScalarField>> leaf_evals(const DensePolynomialExt *leaf, size_t xs, size_t ys, LeafCache &cache) {
-        auto it = cache.find(leaf);
+        auto key = std::make_tuple(leaf, xs, ys);
+        auto it = cache.find(key);
         if (it == cache.end()) {
-            it = cache.emplace(leaf, std::make_shared<DeviceVec<ScalarField>>(leaf->evals_on(xs, ys))).first;
+            it = cache.emplace(key, std::make_shared<DeviceVec<ScalarField>>(leaf->evals_on(xs, ys))).first;
         }
         return it->second;
     }
     // postfix program for tkmk_poly_expr_eval; compile() returns the stack depth the node needs, or -1
     struct Program {
         std::vector<tkmk_expr_instr> code;
-        std::vector<const DensePolynomialExt *> leaves;
+        struct Leaf {
+            const DensePolynomialExt *p;
+            size_t ord_x, ord_y;
+        };
+        std::vector<Leaf> leaves;
         std::vector<ScalarField> consts;
-        uint8_t leaf_index(const DensePolynomialExt *p) {
+        uint8_t leaf_index(const DensePolynomialExt *p, size_t ord_x, size_t ord_y) {
             for (size_t i = 0; i < leaves.size(); i++)
-                if (leaves[i] == p) return (uint8_t)i;
-            leaves.push_back(p);
+                if (leaves[i].p == p && leaves[i].ord_x == ord_x && leaves[i].ord_y == ord_y) return (uint8_t)i;
+            leaves.push_back({p, ord_x, ord_y});
             return (uint8_t)(leaves.size() - 1);
         }
         uint8_t const_index(const ScalarField &c) {
@@ -478,7 +542,7 @@ class PolyExpr {
     int compile(Program &pg, int depth) const {
         if (pg.leaves.size() > 200 || pg.consts.size() > 200 || pg.code.size() > 1000) return -1;
         switch (kind) {
-            case Poly: pg.code.push_back({TKMK_EXPR_LEAF, pg.leaf_index(leaf)}); return 1;
+            case Poly: pg.code.push_back({TKMK_EXPR_LEAF, pg.leaf_index(leaf, shift_ord_x, shift_ord_y)}); return 1;
             case Scalar: pg.code.push_back({TKMK_EXPR_CONST, pg.const_index(scalar_)}); return 1;
             case Add:
             case Sub:
@@ -519,11 +583,23 @@ class PolyExpr {
         }
     }
     // every node returns a buffer it owns (leaf evaluations are copied out of the cache like the reference does)
-    DeviceVec<ScalarField> on_domain(size_t xs, size_t ys, std::map<const DensePolynomialExt *, std::shared_ptr<DeviceVec<ScalarField>>> &cache) const {
+    DeviceVec<ScalarField> on_domain(size_t xs, size_t ys, LeafCache &cache) const {
         size_t n = xs * ys;
         tkmk_vecops_config c = dev_cfg();
         switch (kind) {
-            case Poly: return leaf_evals(leaf, xs, ys, cache)->clone();
+            case Poly: {
+                if (!shift_ord_x && !shift_ord_y) return leaf_evals(leaf, xs, ys, cache)->clone();
+                auto inv_root = [](size_t ord) {
+                    ScalarField w;
+                    check(bls12_381_get_root_of_unity(ord, &w), "get_root_of_unity");
+                    ScalarField wi;
+                    tkmk_vecops_config hc = tkmk_vecops_default_config();   // host in, host out (host Fr arithmetic lives above this header)
+                    check(bls12_381_vector_inv(&w, 1, &hc, &wi), "vector_inv");
+                    return wi;
+                };
+                ScalarField wx = shift_ord_x ? inv_root(shift_ord_x) : fr_from_u32(1), wy = shift_ord_y ? inv_root(shift_ord_y) : fr_from_u32(1);
+                return leaf->scale_coeffs(shift_ord_x ? &wx : nullptr, shift_ord_y ? &wy : nullptr).evals_on(xs, ys);   // the reference's own route
+            }
             case Scalar: {
                 std::vector<ScalarField> v(n, scalar_);
                 return DeviceVec<ScalarField>::from_host(v);
@@ -632,6 +708,11 @@ class Sigma1 {
     static std::vector<G1Affine> run_jobs(const std::vector<tkmk_msm_job_ex> &jobs) {
         tkmk_msm_config cfg = device_cfg();
         std::vector<tkmk_g1_projective> res(jobs.size());
+        if (host_trace_on()) {
+            std::string d;
+            for (auto &j : jobs) d += " " + std::to_string(j.msm_size) + (j.table_c ? "t" : "") + (j.base_index ? "i" : "");
+            host_trace("commit batch of %zu:%s", jobs.size(), d.c_str());
+        }
         check(tkmk_msm_multi_ex(jobs.data(), (int)jobs.size(), &cfg, TKMK_BASES_CONVERTED, res.data()), "tkmk_msm_multi_ex");
         std::vector<G1Affine> out;
         for (auto &r : res) out.push_back(to_affine(r));

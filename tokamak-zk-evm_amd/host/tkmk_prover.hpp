@@ -391,15 +391,19 @@ class Prover {
         Poly r_omegaX_omegaY = r_omegaX.scale_coeffs(nullptr, &w_inv_y);
         auto f_g = fg(thetas);
         const Poly &fXY = f_g.first, &gXY = f_g.second;
-        lagrange_kl_xy.reset(new Poly(unit_evals(m_i, m_i - 1, true) * unit_evals(s_max, s_max - 1, false)));
+        Poly K_last = unit_evals(m_i, m_i - 1, true), L_last = unit_evals(s_max, s_max - 1, false);
+        lagrange_kl_xy.reset(new Poly(K_last * L_last));
         const Poly &KL = *lagrange_kl_xy;
         Poly K0 = unit_evals(m_i, 0, true);
 
+        // the reference's expression tree (lib.rs:2107-2171) with three operands in cheaper but equal forms: r(w^-1 X, Y) and
+        // r(w^-1 X, w^-1 Y) as root-shifted leaves of r (rotations of r's evaluations instead of two more 2^25-point transforms),
+        // KL as the product of its X-only and Y-only factors, K0 as an X-only leaf (1-D transforms, broadcast in the evaluator)
         using E = PolyExpr;
         auto r_g = [&]() { return E::mul(E::poly(rXY), E::poly(gXY)); };
-        E p1 = E::mul(E::sub(E::poly(rXY), E::scalar(one)), E::poly(KL));
-        E p2 = E::mul_x_minus_one(E::sub(r_g(), E::mul(E::poly(r_omegaX), E::poly(fXY))));
-        E p3 = E::mul(E::poly(K0), E::sub(r_g(), E::mul(E::poly(r_omegaX_omegaY), E::poly(fXY))));
+        E p1 = E::mul(E::sub(E::poly(rXY), E::scalar(one)), E::mul(E::poly(K_last), E::poly(L_last)));
+        E p2 = E::mul_x_minus_one(E::sub(r_g(), E::mul(E::poly_root_shifted(rXY, m_i, 0), E::poly(fXY))));
+        E p3 = E::mul(E::poly(K0), E::sub(r_g(), E::mul(E::poly_root_shifted(rXY, m_i, s_max), E::poly(fXY))));
         std::vector<std::pair<ScalarField, E>> terms;
         terms.emplace_back(one, std::move(p1));
         terms.emplace_back(kappa0, std::move(p2));
@@ -539,6 +543,7 @@ inline Proof run_rounds(Prover &prover, const Binding &binding, std::map<std::st
     TranscriptManager manager;
     auto timed = [&](const char *name, const std::function<void()> &fn) {
         double t = Prover::now();
+        host_trace("== %s", name);
         fn();
         check(tkmk_device_synchronize(), "synchronize");
         if (times) (*times)[name] = Prover::now() - t;
