@@ -395,6 +395,12 @@ tkmk_error tkmk_poly_place(const tkmk_fr *src_dev, uint32_t sx, uint32_t sy, tkm
 /* dst[i][j] = src[i][j] * factor_x^i * factor_y^j (_scale_coeffs, mod.rs:1567-1613; NULL factor = 1); in place ok */
 tkmk_error tkmk_poly_scale_coeffs(const tkmk_fr *src_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *factor_x,
                                   const tkmk_fr *factor_y, tkmk_fr *dst_dev, tkmk_stream stream);
+/* out (out_x_size x y_size) = p * scale * (1 + X + ... + X^(m-1)) truncated to out_x_size rows, in coefficient space:
+ * out[k][j] = scale * sum_{i = k-m+1 .. k} p[i][j].  With scale = 1/m that factor is the Lagrange polynomial K_0 of the m-th roots
+ * of unity (unit evaluations at index 0), which prove2 / prove4 multiply large polynomials by (lib.rs:2238-2246, 3012-3040) — there
+ * through three bivariate NTTs per product, here two running sums.  out != p. */
+tkmk_error tkmk_poly_mul_ones_x(const tkmk_fr *p_dev, uint32_t x_size, uint32_t y_size, uint32_t m, const tkmk_fr *scale,
+                                uint32_t out_x_size, tkmk_fr *out_dev, tkmk_stream stream);
 /* dst[i][j] = evals[i][j] * (w_x^i - 1): PolyExpr::MulXMinusOne on the evaluation domain (mod.rs:372-378, 504-518) */
 tkmk_error tkmk_poly_mul_x_minus_one_evals(const tkmk_fr *evals_dev, uint32_t x_size, uint32_t y_size, tkmk_fr *dst_dev,
                                            tkmk_stream stream);

@@ -414,3 +414,37 @@ def test_expr_leaf_views(P, gpu, oracle):
     full = ux.clone()
     full.resize(xs, ys)
     assert (gpu.poly_expr_eval_views([(LEAF, 0)], [(col_ev, xs, 1, 0, 0)], k1, 1, xs, ys).to_host() == full.to_rou_evals().to_host()).all()
+
+
+@pytest.mark.parametrize("xs,ys,m,rows", [(64, 4, 16, 64), (128, 8, 64, 100), (256, 2, 128, 256), (96 + 32, 16, 32, 97), (1024, 4, 256, 1000), (64, 8, 4, 33), (32, 4, 1, 32)])
+def test_mul_ones_x_equals_product_with_K0(P, gpu, oracle, xs, ys, m, rows):
+    """tkmk_poly_mul_ones_x: p * (1/m)(1 + X + ... + X^(m-1)) by running sums == the NTT product with K0 = unit evaluations at index 0
+    of the m-th roots (how the reference multiplies by K0, lib.rs:2238-2246) == the definition in big integers (small cases)"""
+    gpu.init_ntt_domain_for_size(1 << 14)
+    R = oracle.R_MOD
+    p = np.asarray(oracle.fr_random(400 + xs + m, xs * ys)).copy()
+    p[32 * rows * ys:] = 0                                               # degree rows - 1 in X inside an xs-row buffer
+    inv_m = oracle.to_bytes([pow(m, R - 2, R)], 32)
+    ox = 1 << (rows - 1 + m - 1).bit_length() if rows - 1 + m > 1 else 1
+    ox = max(ox, 1)
+    while ox < rows - 1 + m:
+        ox <<= 1
+    got = gpu.poly_mul_ones_x(gpu.DeviceBuffer.from_host(p), xs, ys, m, inv_m, ox).to_host()
+    e = np.zeros(32 * m, np.uint8)
+    e[0] = 1
+    k0 = P.from_rou_evals(gpu.DeviceBuffer.from_host(e), m, 1)                 # unit_evals(m, 0, x-axis)
+    assert (k0.copy_coeffs() == np.tile(inv_m, m)).all()                     # all coefficients 1/m
+    if m > 1:
+        prod = k0 * P.from_coeffs(gpu.DeviceBuffer.from_host(p), xs, ys)
+        pc = np.asarray(prod.copy_coeffs()).reshape(prod.x_size, prod.y_size, 32)
+        g = np.asarray(got).reshape(ox, ys, 32)
+        nx, ny = min(prod.x_size, ox), min(prod.y_size, ys)
+        assert (pc[:nx, :ny] == g[:nx, :ny]).all() and not g[nx:].any() and not g[:, ny:].any() and not pc[nx:].any() and not pc[:, ny:].any()
+    if xs * ys <= 1024:
+        v = oracle.to_ints(p, 32)
+        im = pow(m, R - 2, R)
+        want = [im * sum(v[i * ys + j] for i in range(max(0, k - m + 1), min(k, xs - 1) + 1)) % R for k in range(ox) for j in range(ys)]
+        assert oracle.to_ints(got, 32) == want
+    # truncation: fewer output rows than the product has
+    short = gpu.poly_mul_ones_x(gpu.DeviceBuffer.from_host(p), xs, ys, m, inv_m, max(1, ox // 2)).to_host()
+    assert (short == got[:short.size]).all()

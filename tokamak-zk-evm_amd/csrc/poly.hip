@@ -403,6 +403,81 @@ TK_API tkmk_error tkmk_poly_scale_coeffs(const tkmk_fr *src_dev, uint32_t x_size
     return TKMK_SUCCESS;
 }
 
+// ---- product with scale * (1 + X + ... + X^(m-1)) in coefficient space: out[k][j] = scale * sum_{i = k-m+1 .. k} p[i][j] ----
+// The Lagrange polynomial of index 0 on the m-th roots of unity is exactly that (all coefficients 1/m): prove2 and prove4 multiply
+// 2^23..2^24-coefficient polynomials by it (K0 * ..., lib.rs:2238-2246, 3012-3040), which the reference does with three bivariate
+// NTTs per product.  A sliding-window sum is two running sums over X: block sums, their scan, then one pass.
+// T[b][j] = sum of rows [b * WS_BLOCK, (b + 1) * WS_BLOCK) of column j (rows >= x_size are zero)
+__global__ __launch_bounds__(256) void k_ws_block_sums(const fr_t *__restrict__ p, uint32_t xs, uint32_t ys, uint32_t nb, uint32_t WS_BLOCK, fr_t *__restrict__ T) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (uint64_t)nb * ys) return;
+    uint32_t b = (uint32_t)(id / ys), j = (uint32_t)(id - (uint64_t)b * ys);
+    fr_t acc = Fr::zero();
+    for (uint32_t r = 0; r < WS_BLOCK; r++) {
+        uint32_t i = b * WS_BLOCK + r;
+        if (i < xs) acc = Fr::add(acc, Fr::canon(tk_load(p + (uint64_t)i * ys + j)));
+    }
+    tk_store(T + id, acc);
+}
+// exclusive scan of T along b, per column (nb is a few hundred at most)
+__global__ __launch_bounds__(256) void k_ws_scan(fr_t *__restrict__ T, uint32_t nb, uint32_t ys) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ys) return;
+    fr_t run = Fr::zero();
+    for (uint32_t b = 0; b < nb; b++) {
+        fr_t v = tk_load(T + (uint64_t)b * ys + j);
+        tk_store(T + (uint64_t)b * ys + j, run);
+        run = Fr::add(run, v);
+    }
+}
+// out rows of block b: leading running sum S[k] minus the trailing one S[k - m]; m is a multiple of WS_BLOCK, so the trailing
+// sum starts at a block boundary too
+__global__ __launch_bounds__(256) void k_ws_apply(const fr_t *__restrict__ p, const fr_t *__restrict__ T, uint32_t xs, uint32_t ys, uint32_t nb,
+                                                 uint32_t WS_BLOCK, uint32_t m, fr_t scale_mont, uint32_t out_xs, fr_t *__restrict__ out) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ob = (out_xs + WS_BLOCK - 1) / WS_BLOCK;
+    if (id >= (uint64_t)ob * ys) return;
+    uint32_t b = (uint32_t)(id / ys), j = (uint32_t)(id - (uint64_t)b * ys);
+    const uint32_t mb = m / WS_BLOCK;
+    // sums of all rows below the two blocks (past the last block of p: the total = prefix of the last block + that block)
+    auto prefix = [&](uint32_t blk) {
+        if (blk < nb) return tk_load(T + (uint64_t)blk * ys + j);
+        fr_t t = tk_load(T + (uint64_t)(nb - 1) * ys + j);
+        for (uint32_t r = 0; r < WS_BLOCK; r++) {
+            uint32_t i = (nb - 1) * WS_BLOCK + r;
+            if (i < xs) t = Fr::add(t, Fr::canon(tk_load(p + (uint64_t)i * ys + j)));
+        }
+        return t;
+    };
+    fr_t lead = prefix(b), trail = b >= mb ? prefix(b - mb) : Fr::zero();
+    for (uint32_t r = 0; r < WS_BLOCK; r++) {
+        uint32_t k = b * WS_BLOCK + r;
+        if (k >= out_xs) break;
+        if (k < xs) lead = Fr::add(lead, Fr::canon(tk_load(p + (uint64_t)k * ys + j)));
+        if (k >= m && k - m < xs) trail = Fr::add(trail, Fr::canon(tk_load(p + (uint64_t)(k - m) * ys + j)));
+        tk_store(out + (uint64_t)k * ys + j, Fr::mul(Fr::sub(lead, trail), scale_mont));   // plain * Montgomery = plain
+    }
+}
+TK_API tkmk_error tkmk_poly_mul_ones_x(const tkmk_fr *p_dev, uint32_t x_size, uint32_t y_size, uint32_t m, const tkmk_fr *scale,
+                                       uint32_t out_x_size, tkmk_fr *out_dev, tkmk_stream stream) {
+    if (!p_dev || !out_dev || !scale) return TKMK_ERR_INVALID_POINTER;
+    if (!x_size || !y_size || !out_x_size || !m || p_dev == out_dev) return TKMK_ERR_INVALID_ARGUMENT;
+    uint32_t WS_BLOCK = 64;   // rows per running-sum block: the largest power of two <= 64 that divides m
+    while (m % WS_BLOCK) WS_BLOCK >>= 1;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    const uint32_t nb = (x_size + WS_BLOCK - 1) / WS_BLOCK, ob = (out_x_size + WS_BLOCK - 1) / WS_BLOCK;
+    tk_scratch T;
+    TK_TRY(T.alloc((size_t)nb * y_size * sizeof(fr_t), s));
+    hipLaunchKernelGGL(k_ws_block_sums, tk_div_up((uint64_t)nb * y_size, 256), 256, 0, s, (const fr_t *)p_dev, x_size, y_size, nb, WS_BLOCK, T.as<fr_t>());
+    hipLaunchKernelGGL(k_ws_scan, tk_div_up(y_size, 256), 256, 0, s, T.as<fr_t>(), nb, y_size);
+    hipLaunchKernelGGL(k_ws_apply, tk_div_up((uint64_t)ob * y_size, 256), 256, 0, s, (const fr_t *)p_dev, (const fr_t *)T.p, x_size, y_size, nb, WS_BLOCK, m,
+                       Fr::to_mont(Fr::canon(fr_in(scale))), out_x_size, (fr_t *)out_dev);
+    TK_HIP(hipGetLastError());
+    return TKMK_SUCCESS;
+}
+
 // dst[i][j] = evals[i][j] * (w_x^i - 1): the evaluation-domain form of "multiply by (X - 1)" used by
 // PolyExpr::MulXMinusOne (mod.rs:372-378, x_minus_one_evals :504-518); w_x = root of unity of order x_size
 TK_API tkmk_error tkmk_poly_mul_x_minus_one_evals(const tkmk_fr *evals_dev, uint32_t x_size, uint32_t y_size, tkmk_fr *dst_dev,

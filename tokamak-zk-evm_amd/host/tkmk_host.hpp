@@ -341,6 +341,18 @@ class DensePolynomialExt {
         return from_rou_evals(le, xs, ys);
     }
 
+    // this * scale * (1 + X + ... + X^(m-1)); with scale = 1/m the factor is K_0 = unit evaluations at index 0 of the m-th roots
+    // (the reference multiplies by it with `&K0 * &poly`, three NTTs: lib.rs:2238-2246, 3012-3040)
+    DensePolynomialExt mul_ones_x(size_t m, const ScalarField &scale) const {
+        auto [xd, yd] = find_degree();
+        (void)yd;
+        if (xd < 0) return zero();
+        size_t ox = next_pow2((size_t)xd + m);
+        DeviceVec<ScalarField> out(ox * y_size);
+        host_trace("mul_ones_x %zu x %zu by m = %zu", x_size, y_size, m);
+        check(tkmk_poly_mul_ones_x(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, (uint32_t)m, &scale, (uint32_t)ox, out.ptr(), nullptr), "mul_ones_x");
+        return from_coeffs(std::move(out), ox, y_size);
+    }
     // div_by_vanishing_opt (mod.rs:2284-2410)
     std::pair<DensePolynomialExt, DensePolynomialExt> div_by_vanishing_opt(int64_t denom_x_degree, int64_t denom_y_degree) {
         if (denom_x_degree <= 0 || denom_y_degree <= 0 || !is_pow2((size_t)denom_x_degree) || !is_pow2((size_t)denom_y_degree))

@@ -385,7 +385,7 @@ class Prover {
         using namespace prover_detail;
         const Mixer &mx = mixer;
         size_t s_max = sp.s_max;
-        ScalarField kappa0_sq = fr_mul(kappa0, kappa0), one = fr_one();
+        ScalarField kappa0_sq = fr_mul(kappa0, kappa0), one = fr_one(), inv_m_i = fr_inv(fr_from_u32((uint32_t)m_i));
         ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(s_max));
         Poly r_omegaX = rXY.scale_coeffs(&w_inv_x, nullptr);
         Poly r_omegaX_omegaY = r_omegaX.scale_coeffs(nullptr, &w_inv_y);
@@ -421,7 +421,7 @@ class Prover {
                 return Poly::lincomb({Term(rB[0], &r_D), x_axis ? Term(rB[1], &r_D, 1, 0) : Term(rB[1], &r_D, 0, 1), Term(rR, &g_D)});
             };
             Poly d1_comb = d_comb(r_D1), d2_comb = d_comb(r_D2);
-            Poly k0_d2 = K0 * d2_comb;
+            Poly k0_d2 = d2_comb.mul_ones_x(m_i, inv_m_i);   // K0 * d2_comb: K0 = (1/m_I)(1 + X + ... + X^(m_I - 1))
             // kappa0 * (X - 1) * d1_comb enters as two shifted terms
             return Poly::lincomb({Term(one, &quot), Term(rR, &KL), Term(kappa0, &d1_comb, 1, 0), Term(fr_neg(kappa0), &d1_comb), Term(kappa0_sq, &k0_d2)});
         };
@@ -511,7 +511,7 @@ class Prover {
         // (1 - X) * r_d1_t enters LHS_zk1 as two shifted terms
         Poly LHS_zk1 = Poly::lincomb({Term(fr_mul(chi_m1, r_D1_eval), term_b_zk.get()), Term(one, &r_d1_t), Term(minus_one, &r_d1_t, 1, 0), Term(chi_m1, &term10)});
         Poly r_d2_t = with_term10(r_D2);
-        Poly k0_r_d2_t = K0 * r_d2_t;
+        Poly k0_r_d2_t = r_d2_t.mul_ones_x(m_i, fr_inv(fr_from_u32((uint32_t)m_i)));   // K0 * r_d2_t
         Poly LHS_zk2 = poly_comb({{fr_mul(K0_eval, r_D2_eval), term_b_zk.get()}, {K0_eval, &term10}, {minus_one, &k0_r_d2_t}});
         Poly R_minus_eval = sub_const(RXY, proof3.R_eval);
         ScalarField k1_2 = fr_mul(kappa1, kappa1);

@@ -91,7 +91,7 @@ SYMBOLS = [
     "bls12_381_scalar_sub_vec", "bls12_381_scalar_mul_vec", "bls12_381_vector_sum", "bls12_381_vector_product",
     "bls12_381_matrix_transpose", "tkmk_vec_suffix_product", "tkmk_fr_random_device", "tkmk_gather_rows_device", "tkmk_g1_batch_scalar_mul_device", "tkmk_profile_enable",
     "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench", "tkmk_diag_field_mul", "tkmk_poly_find_degree",
-    "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_expr_eval", "tkmk_poly_expr_eval_views", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
+    "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_mul_ones_x", "tkmk_poly_expr_eval", "tkmk_poly_expr_eval_views", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
     "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini", "tkmk_r1cs_eval_rows",
     "tkmk_msm_multi_ex", "bls12_381_msm_convert_bases", "tkmk_r1cs_library_create", "tkmk_r1cs_library_destroy", "tkmk_r1cs_library_eval",
     "tkmk_witness_route", "tkmk_fr_scatter_table", "tkmk_host_malloc", "tkmk_host_free", "tkmk_stats_reset", "tkmk_stats_get",
@@ -634,6 +634,14 @@ def poly_expr_eval(prog, leaves, consts, n_consts, x_size, y_size, out=None):
     _check(lib().tkmk_poly_expr_eval(arr, ctypes.c_uint32(len(prog)), ptrs, ctypes.c_uint32(len(leaves)), _p(consts),
                                      ctypes.c_uint32(n_consts), ctypes.c_uint32(x_size), ctypes.c_uint32(y_size), _p(out), None),
            "tkmk_poly_expr_eval")
+    return out
+
+
+def poly_mul_ones_x(p, x_size, y_size, m, scale, out_x_size, out=None):
+    """out = p * scale * (1 + X + ... + X^(m-1)), out_x_size rows (tkmk_poly_mul_ones_x); p: DeviceBuffer of x_size * y_size coefficients"""
+    out = DeviceBuffer(32 * out_x_size * y_size) if out is None else out
+    _check(lib().tkmk_poly_mul_ones_x(_p(p), ctypes.c_uint32(x_size), ctypes.c_uint32(y_size), ctypes.c_uint32(m), _p(scale),
+                                      ctypes.c_uint32(out_x_size), _p(out), None), "tkmk_poly_mul_ones_x")
     return out
 
 
