@@ -525,9 +525,12 @@ class Prover {
         ScalarField A_eval = ev(a_free_X);
         auto piB = sub_const(a_free_X, A_eval).div_by_ruffini(chi, zeta);
 
-        auto c = sigma->sigma1.encode_polys({&std::get<0>(piA), &std::get<1>(piA), &std::get<0>(M), &std::get<1>(M), &std::get<0>(N), &std::get<1>(N),
+        // N_X is M_X: both numerators are R minus a constant and both are divided by the same X - chi / w_x first, and a constant
+        // only moves the remainder of that division, never its quotient (the reference commits the same polynomial twice,
+        // lib.rs:2572-2700).  One 2^22-point commitment instead of two; the Y-quotients differ and are both committed.
+        auto c = sigma->sigma1.encode_polys({&std::get<0>(piA), &std::get<1>(piA), &std::get<0>(M), &std::get<1>(M), &std::get<1>(N),
                                              &std::get<0>(piC), &std::get<1>(piC), &std::get<0>(piB)});
-        const G1Affine &Pi_AX = c[0], &Pi_AY = c[1], &M_X = c[2], &M_Y = c[3], &N_X = c[4], &N_Y = c[5], &Pi_CX = c[6], &Pi_CY = c[7], &Pi_B0 = c[8];
+        const G1Affine &Pi_AX = c[0], &Pi_AY = c[1], &M_X = c[2], &M_Y = c[3], &N_X = c[2], &N_Y = c[4], &Pi_CX = c[5], &Pi_CY = c[6], &Pi_B0 = c[7];
         ScalarField k1_4 = fr_mul(k1_2, k1_2), zero{};
         auto sums = g1_lincombs({{{k1_4, Pi_B0}, {zero, Pi_B0}, {zero, Pi_B0}},   // encode(pi_B) * kappa1^4 (lib.rs:3180)
                                  {{one, Pi_AX}, {one, Pi_CX}, {k1_4, Pi_B0}},      // lib.rs:3183-3184

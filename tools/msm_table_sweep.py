@@ -28,7 +28,8 @@ def main():
     h.free()
     conv = tkmk.msm_convert_bases(plain, nmax)
     ref = {}
-    for c in (0, 16, 18, 20):
+    modes = [int(v) for v in os.environ.get("TKMK_SWEEP_MODES", "0,16,18,20").split(",")]   # 0 = plain, else the table's window width
+    for c in modes:
         table = conv
         windows = 0
         if c:
