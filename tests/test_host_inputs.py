@@ -129,3 +129,36 @@ def test_fast_permutation_reader(tkmk, tmp_path):
         p.write_text(bad)
         rc, lines = _run_args("perm", p, 2)
         assert rc == 1 and lines[0].startswith("error: "), (bad, lines)
+
+
+def test_fast_reader_every_digit_count_and_case(tkmk, tmp_path):
+    """the 16-digits-at-a-time decoder of the bulk path: every length 1..64, upper / lower / mixed case, with and without the 0x
+    prefix, values at and above the modulus; a bad character in every position of a 64-digit value is an error"""
+    rnd = random.Random(11)
+    vals = []
+    for nd in range(1, 65):
+        v = rnd.getrandbits(4 * nd) | (1 << (4 * nd - 1)) if nd < 64 else rnd.getrandbits(256)
+        h = "%x" % v
+        h = h.rjust(nd, "0")[:nd] if len(h) <= nd else h[-nd:]
+        for form in (h, h.upper(), "".join(c.upper() if rnd.random() < 0.5 else c for c in h)):
+            for prefix in ("0x", "0X", ""):
+                vals.append(prefix + form)
+    vals += ["0x" + "f" * 64, "0x%x" % R, "0x%x" % (R - 1), "0x" + "0" * 64, "0x", ""]
+    docs = [{"subcircuitId": 0, "variables": vals}]
+    p = tmp_path / "pv.json"
+    p.write_text(json.dumps(docs))
+    x = 0
+    for h in vals:
+        body = h[2:] if h[:2] in ("0x", "0X") else h
+        x ^= (int(body, 16) if body else 0) % R
+    for threads in (1, 4):
+        assert _run_args("fast", p, threads, str(len(vals))) == (0, ["ok 1 %d" % len(vals), "0 %d 0x%064x" % (len(vals), x)])
+    good = "ab" * 32
+    for pos in range(64):
+        for bad_char in ("g", "/", ":", "@", "`", " ", "\\\\"):
+            broken = good[:pos] + bad_char + good[pos + 1:]
+            if len(bad_char) > 1:
+                broken = good[:pos] + bad_char + good[pos + 2:] if pos < 63 else good[:62] + bad_char
+            p.write_text('[{"subcircuitId": 0, "variables": ["0x%s"]}]' % broken)
+            rc, lines = _run_args("fast", p, 1, "1")
+            assert rc == 1 and lines[0].startswith("error: "), (pos, bad_char, lines)

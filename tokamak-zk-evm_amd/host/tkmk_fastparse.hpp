@@ -14,6 +14,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -241,6 +244,111 @@ inline ScalarField fr_from_hex_fast(const char *h, size_t len) {
     return frh::store(v);
 }
 
+// 16 hexadecimal characters -> the 64-bit word they spell (first character most significant); false if one is not a hex digit.
+// SSE2 (the x86-64 baseline): range tests give the nibble of every byte, adjacent nibbles are merged in 16-bit lanes and packed.
+#if defined(__SSE2__)
+inline bool hex16(const char *p, uint64_t &out) {
+    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p));
+    const __m128i d = _mm_sub_epi8(v, _mm_set1_epi8('0'));
+    const __m128i l = _mm_sub_epi8(_mm_or_si128(v, _mm_set1_epi8(0x20)), _mm_set1_epi8('a'));
+    const __m128i is_d = _mm_cmpeq_epi8(_mm_min_epu8(d, _mm_set1_epi8(9)), d);
+    const __m128i is_l = _mm_cmpeq_epi8(_mm_min_epu8(l, _mm_set1_epi8(5)), l);
+    if (_mm_movemask_epi8(_mm_or_si128(is_d, is_l)) != 0xffff) return false;
+    const __m128i nib = _mm_or_si128(_mm_and_si128(is_d, d), _mm_andnot_si128(is_d, _mm_add_epi8(l, _mm_set1_epi8(10))));
+    // 16-bit lane = (second character's nibble << 8) | first character's nibble  ->  byte (first << 4) | second
+    const __m128i b16 = _mm_or_si128(_mm_slli_epi16(_mm_and_si128(nib, _mm_set1_epi16(0x00ff)), 4), _mm_srli_epi16(nib, 8));
+    const __m128i b8 = _mm_packus_epi16(b16, b16);   // 8 bytes, most significant first
+    out = __builtin_bswap64((uint64_t)_mm_cvtsi128_si64(b8));
+    return true;
+}
+#else
+inline bool hex16(const char *p, uint64_t &out) {
+    const uint8_t *lut = hex_lut();
+    uint64_t w = 0;
+    unsigned bad = 0;
+    for (int k = 0; k < 16; k++) {
+        uint8_t v = lut[(uint8_t)p[k]];
+        bad |= v;
+        w = (w << 4) | (v & 0xf);
+    }
+    out = w;
+    return !(bad & 0xf0);
+}
+#endif
+// fr_from_hex_fast for the bulk path: digits are right-aligned in a 64-character field of '0' and read 16 at a time
+inline ScalarField fr_from_hex_bulk(const char *h, size_t len) {
+    size_t off = (len >= 2 && h[0] == '0' && (h[1] == 'x' || h[1] == 'X')) ? 2 : 0;
+    const size_t nd = len - off;
+    if (nd > 64) throw Error("hex scalar longer than 32 bytes");
+    uint64_t w[4] = {0, 0, 0, 0};
+    if (nd <= 2) {   // "0x0" / "0x1" / small constants: most of a witness
+        const uint8_t *lut = hex_lut();
+        unsigned bad = 0;
+        for (size_t k = 0; k < nd; k++) {
+            uint8_t v = lut[(uint8_t)h[off + k]];
+            bad |= v;
+            w[0] = (w[0] << 4) | (v & 0xf);
+        }
+        if (bad & 0xf0) throw Error("invalid hex digit in scalar");
+    } else {
+        const char *d = h + off;
+        const size_t full = nd / 16, rem = nd % 16;   // whole 16-digit words from the least significant end, then the short top one
+        for (size_t k = 0; k < full; k++)
+            if (!hex16(d + nd - 16 * (k + 1), w[k])) throw Error("invalid hex digit in scalar");
+        if (rem) {
+            char buf[16];
+            std::memset(buf, '0', 16 - rem);
+            std::memcpy(buf + 16 - rem, d, rem);
+            if (!hex16(buf, w[full])) throw Error("invalid hex digit in scalar");
+        }
+    }
+    frh::U256 v;
+    std::memcpy(v.l, w, 32);
+    while (frh::geq(v, frh::MOD)) v = frh::sub_raw(v, frh::MOD);
+    return frh::store(v);
+}
+
+// the `variables` array of one placement, from just after its '[' to just after its ']': strings of hex digits separated by commas.
+// Returns the position after ']'.  A tight loop of its own: 3.3 million values per configs[3] proof pass through here.
+inline size_t read_hex_array(const char *t, size_t i, size_t n, ScalarField *dst, uint32_t want, uint32_t &count, const char *doc) {
+    auto fail = [&](const char *what, size_t at) { throw Error(std::string(doc) + ": " + what + " at byte " + std::to_string(at)); };
+    uint32_t cnt = 0;
+    while (i < n && is_ws(t[i])) i++;
+    if (i < n && t[i] == ']') {
+        count = 0;
+        return i + 1;
+    }
+    for (;;) {
+        while (i < n && is_ws(t[i])) i++;
+        if (i >= n || t[i] != '"') fail("unexpected character", i);
+        const size_t b = ++i;
+#if defined(__SSE2__)
+        for (bool found = false; !found && i + 16 <= n;) {   // closing quote, 16 bytes at a time (never reading past the mapping)
+            int m = _mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(t + i)), _mm_set1_epi8('"')));
+            if (m) i += (size_t)__builtin_ctz((unsigned)m), found = true;
+            else i += 16;
+        }
+#endif
+        while (i < n && t[i] != '"') i++;   // escapes cannot pass the digit test below
+        if (i >= n) fail("unterminated string", b);
+        if (cnt >= want) throw Error("Corrupted placement variables.");   // more values than the subcircuit has wires
+        dst[cnt++] = fr_from_hex_bulk(t + b, i - b);
+        i++;
+        while (i < n && is_ws(t[i])) i++;
+        if (i < n && t[i] == ',') {
+            i++;
+            continue;
+        }
+        if (i < n && t[i] == ']') {
+            i++;
+            break;
+        }
+        fail("unexpected character", i);
+    }
+    count = cnt;
+    return i;
+}
+
 }  // namespace fastparse
 
 // ---- placementVariables.json ----------------------------------------------------------------------------------------------------
@@ -337,20 +445,7 @@ inline WitnessLayout parse_placement_variables_fast(const char *t, size_t n, con
                     if (has_vars) s.fail("duplicate key");
                     s.expect('[');
                     uint32_t cnt = 0;
-                    if (s.peek(']')) s.i++;
-                    else
-                        for (;;) {
-                            size_t b, e;
-                            s.str(b, e);
-                            if (cnt >= want) throw Error("Corrupted placement variables.");   // more values than the subcircuit has wires
-                            dst[cnt++] = fr_from_hex_fast(t + b, e - b);
-                            if (s.peek(',')) {
-                                s.i++;
-                                continue;
-                            }
-                            s.expect(']');
-                            break;
-                        }
+                    s.i = read_hex_array(t, s.i, end, dst, want, cnt, doc);
                     if (cnt != want) throw Error("Corrupted placement variables.");
                     has_vars = true;
                 } else {

@@ -249,7 +249,18 @@ class Prover {
     Mixer mixer;
     Poly bXY, uXY, vXY, wXY, rXY, a_free_X, t_n, t_mi, t_smax, s0XY, s1XY;
     Poly q0XY, q1XY, q2XY, q3XY;
-    std::unique_ptr<Poly> w_zk, term_b_zk, lagrange_kl_xy;   // ProverCache (lib.rs:297-301)
+    std::unique_ptr<Poly> w_zk, term_b_zk;   // ProverCache (lib.rs:297-301)
+    // the Lagrange polynomials of prove2 / prove4 (lib.rs:2018-2100) depend on the setup parameters only: a resident context
+    // builds them once and shares them; a stand-alone Prover builds them on first use
+    struct LagrangePolys {
+        Poly K_last, L_last, K0, KL;   // K_{m_I - 1}(X), L_{s_max - 1}(Y), K_0(X), K_last * L_last
+        static std::shared_ptr<const LagrangePolys> make(size_t m_i, size_t s_max);
+    };
+    std::shared_ptr<const LagrangePolys> lagrange;
+    const LagrangePolys &lagrange_polys() {
+        if (!lagrange) lagrange = LagrangePolys::make(m_i, sp.s_max);
+        return *lagrange;
+    }
     std::map<std::string, double> timing;
 
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -391,10 +402,8 @@ class Prover {
         Poly r_omegaX_omegaY = r_omegaX.scale_coeffs(nullptr, &w_inv_y);
         auto f_g = fg(thetas);
         const Poly &fXY = f_g.first, &gXY = f_g.second;
-        Poly K_last = unit_evals(m_i, m_i - 1, true), L_last = unit_evals(s_max, s_max - 1, false);
-        lagrange_kl_xy.reset(new Poly(K_last * L_last));
-        const Poly &KL = *lagrange_kl_xy;
-        Poly K0 = unit_evals(m_i, 0, true);
+        const LagrangePolys &lg = lagrange_polys();
+        const Poly &K_last = lg.K_last, &L_last = lg.L_last, &KL = lg.KL, &K0 = lg.K0;
 
         // the reference's expression tree (lib.rs:2107-2171) with three operands in cheaper but equal forms: r(w^-1 X, Y) and
         // r(w^-1 X, w^-1 Y) as root-shifted leaves of r (rotations of r's evaluations instead of two more 2^25-point transforms),
@@ -485,13 +494,13 @@ class Prover {
         auto f_g = fg(thetas);
         const Poly &fXY = f_g.first, &gXY = f_g.second;
         ScalarField t_mi_eval = fr_sub(fr_pow(chi, m_i), one), t_s_max_eval = fr_sub(fr_pow(zeta, s_max), one);
-        Poly K0 = unit_evals(m_i, 0, true);
+        const LagrangePolys &lg = lagrange_polys();
+        const Poly &K0 = lg.K0;
         ScalarField K0_eval = ev(K0), small_r = ev(rXY), small_r_wx = ev(r_omegaX), small_r_wxy = ev(r_omegaX_omegaY);
-        if (!lagrange_kl_xy) lagrange_kl_xy.reset(new Poly(unit_evals(m_i, m_i - 1, true) * unit_evals(s_max, s_max - 1, false)));
         Poly term5 = poly_comb({{small_r, &gXY}, {fr_neg(small_r_wx), &fXY}});
         Poly term6 = poly_comb({{small_r, &gXY}, {fr_neg(small_r_wxy), &fXY}});
         ScalarField chi_m1 = fr_sub(chi, one), kappa0_sq = fr_mul(kappa0, kappa0);
-        Poly pC_XY = poly_comb({{fr_sub(small_r, one), lagrange_kl_xy.get()},
+        Poly pC_XY = poly_comb({{fr_sub(small_r, one), &lg.KL},
                                 {fr_mul(kappa0, chi_m1), &term5},
                                 {fr_mul(kappa0_sq, K0_eval), &term6},
                                 {fr_neg(t_mi_eval), &q2XY},
@@ -540,6 +549,13 @@ class Prover {
         return {p4, t};
     }
 };
+
+inline std::shared_ptr<const Prover::LagrangePolys> Prover::LagrangePolys::make(size_t m_i, size_t s_max) {
+    using namespace prover_detail;
+    Poly K_last = unit_evals(m_i, m_i - 1, true), L_last = unit_evals(s_max, s_max - 1, false), K0 = unit_evals(m_i, 0, true);
+    Poly KL = K_last * L_last;
+    return std::make_shared<const LagrangePolys>(LagrangePolys{std::move(K_last), std::move(L_last), std::move(K0), std::move(KL)});
+}
 
 // the round loop of prove/src/main.rs:47-76
 inline Proof run_rounds(Prover &prover, const Binding &binding, std::map<std::string, double> *times = nullptr) {

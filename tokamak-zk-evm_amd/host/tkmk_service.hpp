@@ -49,6 +49,7 @@ class ProverContext {
     };
     WireLists iface_, prv_, pub_;
     DeviceVec<ScalarField> s0_identity_, s1_identity_, xp_, yp_;   // w_x^row / w_y^col matrices and the two power tables
+    std::shared_ptr<const Prover::LagrangePolys> lagrange_;           // K_last, L_last, K0, KL of prove2 / prove4
     ScalarField *pinned_ = nullptr;                                 // witness staging
     uint64_t pinned_cap_ = 0;
     std::vector<uint32_t> n_wires_;
@@ -177,6 +178,7 @@ class ProverContext {
         for (DeviceVec<G1Affine> *t : {&c->sigma->gamma_inv_o_inst, &c->sigma->eta_inv_li_o_inter_alpha4_kj, &c->sigma->delta_inv_li_o_prv})
             check(bls12_381_msm_convert_bases(t->ptr(), t->len(), &cfg, t->ptr()), "msm::convert_bases");
         c->sigma->binding_tables_converted = true;
+        c->lagrange_ = Prover::LagrangePolys::make(c->m_i, c->sp.s_max);
         check(tkmk_device_synchronize(), "synchronize");
         return c;
     }
@@ -187,34 +189,16 @@ class ProverContext {
         const double t0 = Prover::now();
         const size_t n = sp.n, s_max = sp.s_max, K = infos.size();
 
-        // ---- the three per-proof documents
-        MappedFile pv_file(synth_dir + "/placementVariables.json");
-        WitnessLayout W = parse_placement_variables_fast(pv_file.data(), pv_file.size(), n_wires_, [&](uint64_t total) { return staging(total); }, threads);
-        const size_t P = W.id.size();
-        if (P > s_max) throw Error("placement_variables length exceeds s_max.");
+        // ---- the three per-proof documents.  permutation.json first: its two polynomials are built on the device while the host
+        // reads the (fourteen times larger) witness document
+        std::unique_ptr<Prover> p(new Prover());
+        p->sp = sp, p->m_i = m_i, p->sigma = sigma.get(), p->mixer = mixer, p->lagrange = lagrange_;
         MappedFile perm_file(synth_dir + "/permutation.json");
         PermutationColumns perm = parse_permutation_fast(perm_file.data(), perm_file.size(), threads);
-        std::vector<ScalarField> a_pub_user, a_pub_block;
+        DeviceVec<uint32_t> d_dst, d_x, d_y;   // alive until the kernels reading them have run (synchronised before init returns)
         {
-            const json::Value jinst = json::read_file(synth_dir + "/instance.json");
-            a_pub_user = hex_list(jinst.at("a_pub_user"));
-            a_pub_block = hex_list(jinst.at("a_pub_block"));
-        }
-        // placements grouped by kind: slot list, variable offsets, position of each kind's run
-        std::vector<uint32_t> kind_first(K + 1, 0), slots(P ? P : 1);
-        std::vector<uint64_t> offs(P ? P : 1);
-        for (size_t q = 0; q < P; q++) kind_first[W.id[q] + 1]++;
-        for (size_t k = 0; k < K; k++) kind_first[k + 1] += kind_first[k];
-        {
-            std::vector<uint32_t> cur(kind_first.begin(), kind_first.end() - 1);
-            for (size_t q = 0; q < P; q++) {
-                uint32_t at = cur[W.id[q]]++;
-                slots[at] = (uint32_t)q, offs[at] = W.off[q];
-            }
-        }
-        // Permutation::to_poly's redirects: distinct destinations (the reference's serial loop lets the last entry win)
-        std::vector<uint32_t> dst, srcx, srcy;
-        {
+            // Permutation::to_poly's redirects: distinct destinations (the reference's serial loop lets the last entry win)
+            std::vector<uint32_t> dst, srcx, srcy;
             const size_t cells = m_i * s_max;
             std::vector<uint64_t> bitmap((cells + 63) / 64, 0);
             bool dup = false;
@@ -238,6 +222,36 @@ class ProverContext {
                 }
                 dst.swap(d2), srcx.swap(x2), srcy.swap(y2);
             }
+            // Permutation::to_poly (libs/src/iotools/mod.rs:419-455)
+            DeviceVec<ScalarField> e0 = s0_identity_.clone(), e1 = s1_identity_.clone();
+            if (!dst.empty()) {
+                d_dst = DeviceVec<uint32_t>::from_host(dst), d_x = DeviceVec<uint32_t>::from_host(srcx), d_y = DeviceVec<uint32_t>::from_host(srcy);
+                check(tkmk_fr_scatter_table(xp_.ptr(), d_x.ptr(), d_dst.ptr(), dst.size(), e0.ptr(), nullptr), "tkmk_fr_scatter_table");
+                check(tkmk_fr_scatter_table(yp_.ptr(), d_y.ptr(), d_dst.ptr(), dst.size(), e1.ptr(), nullptr), "tkmk_fr_scatter_table");
+            }
+            p->s0XY = Poly::from_rou_evals(e0, m_i, s_max), p->s1XY = Poly::from_rou_evals(e1, m_i, s_max);
+        }
+        MappedFile pv_file(synth_dir + "/placementVariables.json");
+        WitnessLayout W = parse_placement_variables_fast(pv_file.data(), pv_file.size(), n_wires_, [&](uint64_t total) { return staging(total); }, threads);
+        const size_t P = W.id.size();
+        if (P > s_max) throw Error("placement_variables length exceeds s_max.");
+        std::vector<ScalarField> a_pub_user, a_pub_block;
+        {
+            const json::Value jinst = json::read_file(synth_dir + "/instance.json");
+            a_pub_user = hex_list(jinst.at("a_pub_user"));
+            a_pub_block = hex_list(jinst.at("a_pub_block"));
+        }
+        // placements grouped by kind: slot list, variable offsets, position of each kind's run
+        std::vector<uint32_t> kind_first(K + 1, 0), slots(P ? P : 1);
+        std::vector<uint64_t> offs(P ? P : 1);
+        for (size_t q = 0; q < P; q++) kind_first[W.id[q] + 1]++;
+        for (size_t k = 0; k < K; k++) kind_first[k + 1] += kind_first[k];
+        {
+            std::vector<uint32_t> cur(kind_first.begin(), kind_first.end() - 1);
+            for (size_t q = 0; q < P; q++) {
+                uint32_t at = cur[W.id[q]]++;
+                slots[at] = (uint32_t)q, offs[at] = W.off[q];
+            }
         }
         tm.parse = Prover::now() - t0;
 
@@ -253,8 +267,6 @@ class ProverContext {
 
         // ---- polynomials
         const double t2 = Prover::now();
-        std::unique_ptr<Prover> p(new Prover());
-        p->sp = sp, p->m_i = m_i, p->sigma = sigma.get(), p->mixer = mixer;
         {   // read_R1CS_gen_uvwXY (libs/src/iotools/mod.rs:1287-1420)
             DeviceVec<ScalarField> u(n * s_max), v(n * s_max), w(n * s_max);
             check(tkmk_r1cs_library_eval(lib_, d_vars.ptr(), d_id.ptr(), d_off.ptr(), (uint32_t)P, (uint32_t)n, (uint32_t)s_max, u.ptr(), v.ptr(), w.ptr(), nullptr),
@@ -298,16 +310,6 @@ class ProverContext {
         p->rXY = Poly::zero();
         p->a_free_X = gen_a_free_X(a_pub_user, a_pub_block, sp);
         p->t_n = vanishing(n, true), p->t_mi = vanishing(m_i, true), p->t_smax = vanishing(s_max, false);
-        {   // Permutation::to_poly (libs/src/iotools/mod.rs:419-455)
-            DeviceVec<ScalarField> e0 = s0_identity_.clone(), e1 = s1_identity_.clone();
-            if (!dst.empty()) {
-                DeviceVec<uint32_t> d_dst = DeviceVec<uint32_t>::from_host(dst), d_x = DeviceVec<uint32_t>::from_host(srcx), d_y = DeviceVec<uint32_t>::from_host(srcy);
-                check(tkmk_fr_scatter_table(xp_.ptr(), d_x.ptr(), d_dst.ptr(), dst.size(), e0.ptr(), nullptr), "tkmk_fr_scatter_table");
-                check(tkmk_fr_scatter_table(yp_.ptr(), d_y.ptr(), d_dst.ptr(), dst.size(), e1.ptr(), nullptr), "tkmk_fr_scatter_table");
-                check(tkmk_device_synchronize(), "synchronize");   // the index buffers go out of scope here
-            }
-            p->s0XY = Poly::from_rou_evals(e0, m_i, s_max), p->s1XY = Poly::from_rou_evals(e1, m_i, s_max);
-        }
         check(tkmk_device_synchronize(), "synchronize");
         tm.build = Prover::now() - t2;
 
