@@ -18,6 +18,7 @@
 #include <emmintrin.h>
 #endif
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -94,27 +95,88 @@ namespace fastparse {
 
 inline bool is_ws(char c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t'; }
 
-// runs fn(t) on `threads` threads; the first exception is rethrown on the caller
+// runs fn(t), t in [0, threads), on a process-wide pool of parked worker threads (a proof calls this six times; starting and
+// joining sixteen threads each time cost more than the work of the smaller calls); the first exception is rethrown on the caller.
+// One parallel section at a time (callers serialise on the pool's mutex); sections do not nest.
+class WorkerPool {
+    std::mutex mu_, call_mu_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned want_ = 0, next_ = 0, running_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false, failed_ = false;
+    std::string err_;
+
+    void run(unsigned t) {
+        try {
+            (*fn_)(t);
+        } catch (const std::exception &ex) {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!failed_) failed_ = true, err_ = ex.what();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            wake_.wait(lk, [&] { return stop_ || (generation_ != seen && next_ < want_); });
+            if (stop_) return;
+            if (generation_ == seen || next_ >= want_) continue;
+            while (next_ < want_) {   // take indices of the current section until none is left
+                unsigned t = next_++;
+                running_++;
+                lk.unlock();
+                run(t);
+                lk.lock();
+                running_--;
+            }
+            seen = generation_;
+            if (running_ == 0) done_.notify_all();
+        }
+    }
+
+  public:
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    void parallel(unsigned threads, const std::function<void(unsigned)> &fn) {
+        std::lock_guard<std::mutex> call(call_mu_);
+        std::unique_lock<std::mutex> lk(mu_);
+        while (workers_.size() + 1 < threads) workers_.emplace_back([this] { loop(); });   // the caller is the last worker
+        fn_ = &fn, want_ = threads, next_ = 0, failed_ = false, err_.clear();
+        generation_++;
+        lk.unlock();
+        wake_.notify_all();
+        lk.lock();
+        while (next_ < want_) {   // the calling thread works too
+            unsigned t = next_++;
+            running_++;
+            lk.unlock();
+            run(t);
+            lk.lock();
+            running_--;
+        }
+        done_.wait(lk, [&] { return running_ == 0; });
+        fn_ = nullptr, want_ = 0;
+        if (failed_) throw Error(err_);
+    }
+    static WorkerPool &instance() {
+        static WorkerPool pool;
+        return pool;
+    }
+};
 inline void parallel(unsigned threads, const std::function<void(unsigned)> &fn) {
     if (threads <= 1) {
         fn(0);
         return;
     }
-    std::mutex mu;
-    std::string err;
-    bool failed = false;
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; t++)
-        pool.emplace_back([&, t] {
-            try {
-                fn(t);
-            } catch (const std::exception &ex) {
-                std::lock_guard<std::mutex> lk(mu);
-                if (!failed) failed = true, err = ex.what();
-            }
-        });
-    for (auto &th : pool) th.join();
-    if (failed) throw Error(err);
+    WorkerPool::instance().parallel(threads, fn);
 }
 
 // positions of every '{' in [p, p + n), found by `threads` threads over equal slices
