@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libtkmk_hip.so")
+LIB_PATH = os.environ.get("TKMK_HIP_LIBRARY") or os.path.join(_PKG, "libtkmk_hip.so")   # the override is for kernel experiments (tools/)
 _lib = None
 
 
