@@ -50,6 +50,7 @@ class ProverContext {
     WireLists iface_, prv_, pub_;
     DeviceVec<ScalarField> s0_identity_, s1_identity_, xp_, yp_;   // w_x^row / w_y^col matrices and the two power tables
     std::shared_ptr<const Prover::LagrangePolys> lagrange_;           // K_last, L_last, K0, KL of prove2 / prove4
+
     ScalarField *pinned_ = nullptr;                                 // witness staging
     uint64_t pinned_cap_ = 0;
     std::vector<uint32_t> n_wires_;
@@ -171,14 +172,20 @@ class ProverContext {
             check(tkmk_memcpy_d2d(c->yp_.ptr(), c->s1_identity_.ptr(), 32 * s_max), "y powers");                   // row 0 of s1
         }
 
+        host_trace("open: loading the CRS");
         c->sigma = load_sigma(sp, c->crs_source);
+        host_trace("open: CRS resident");
         // binding tables -> resident form, in place (Sigma1 converts xy_powers itself)
         tkmk_msm_config cfg = tkmk_msm_default_config();
         cfg.are_points_on_device = cfg.are_results_on_device = true;
+        // (expanding delta_inv_li_o_prv into a commit table like xy_powers was measured: 1.2 ms per proof for 50 GB and 6 s at open
+        // — the table has (m_D - l_D) * s_max = 4 * 10^7 rows of which a proof touches 3 * 10^6: not kept)
         for (DeviceVec<G1Affine> *t : {&c->sigma->gamma_inv_o_inst, &c->sigma->eta_inv_li_o_inter_alpha4_kj, &c->sigma->delta_inv_li_o_prv})
             check(bls12_381_msm_convert_bases(t->ptr(), t->len(), &cfg, t->ptr()), "msm::convert_bases");
         c->sigma->binding_tables_converted = true;
+        host_trace("open: Lagrange polynomials");
         c->lagrange_ = Prover::LagrangePolys::make(c->m_i, c->sp.s_max);
+        host_trace("open: done");
         check(tkmk_device_synchronize(), "synchronize");
         return c;
     }
