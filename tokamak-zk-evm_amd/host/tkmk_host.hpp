@@ -476,12 +476,15 @@ class PolyExpr {
         auto d = degree_bound();
         return evaluate_fused_with_domain(domain_size_for_degree(d.first), domain_size_for_degree(d.second));
     }
-    DensePolynomialExt evaluate_fused_with_domain(size_t target_x_size, size_t target_y_size) const {
+    // leaf evaluations by (polynomial, domain): pass the same cache to several evaluations on one domain and every leaf is transformed once
+    using LeafCache = std::map<std::tuple<const DensePolynomialExt *, size_t, size_t>, std::shared_ptr<DeviceVec<ScalarField>>>;
+    DensePolynomialExt evaluate_fused_with_domain(size_t target_x_size, size_t target_y_size, LeafCache *shared_cache = nullptr) const {
         if (!is_pow2(target_x_size) || !is_pow2(target_y_size)) throw Error("Fused polynomial expression domains must be powers of two.");
         auto d = degree_bound();
         if (domain_size_for_degree(d.first) > target_x_size || domain_size_for_degree(d.second) > target_y_size)
             throw Error("Fused polynomial expression domain is too small for the expression degree.");
-        LeafCache cache;
+        LeafCache own_cache;
+        LeafCache &cache = shared_cache ? *shared_cache : own_cache;
         // one kernel pass over the leaf evaluations when the tree fits the device evaluator (tkmk_poly_expr_eval);
         // otherwise node by node
         Program pg;
@@ -520,7 +523,6 @@ class PolyExpr {
         e.kids.push_back(std::move(r));
         return e;
     }
-    using LeafCache = std::map<std::tuple<const DensePolynomialExt *, size_t, size_t>, std::shared_ptr<DeviceVec<ScalarField>>>;
     static std::shared_ptr<DeviceVec<ScalarField>> leaf_evals(const DensePolynomialExt *leaf, size_t xs, size_t ys, LeafCache &cache) {
         auto key = std::make_tuple(leaf, xs, ys);
         auto it = cache.find(key);

@@ -412,12 +412,19 @@ class Prover {
         auto r_g = [&]() { return E::mul(E::poly(rXY), E::poly(gXY)); };
         E p1 = E::mul(E::sub(E::poly(rXY), E::scalar(one)), E::mul(E::poly(K_last), E::poly(L_last)));
         E p2 = E::mul_x_minus_one(E::sub(r_g(), E::mul(E::poly_root_shifted(rXY, m_i, 0), E::poly(fXY))));
-        E p3 = E::mul(E::poly(K0), E::sub(r_g(), E::mul(E::poly_root_shifted(rXY, m_i, s_max), E::poly(fXY))));
+        // p3 = K0 * h, h = r g - r(w^-1 X, w^-1 Y) f: only K0 pushes the X-degree past 2 m_I.  The reference evaluates everything on the
+        // 4 m_I x 2 s_max domain (lib.rs:2160-2171); here p1 + kappa0 p2 and h are evaluated on 2 m_I x 2 s_max (half the transform
+        // and pointwise work), and K0 * h is the sliding-window sum of h's coefficients.  Same polynomial, coefficient for coefficient.
+        E h_expr = E::sub(r_g(), E::mul(E::poly_root_shifted(rXY, m_i, s_max), E::poly(fXY)));
         std::vector<std::pair<ScalarField, E>> terms;
         terms.emplace_back(one, std::move(p1));
         terms.emplace_back(kappa0, std::move(p2));
-        terms.emplace_back(kappa0_sq, std::move(p3));
-        Poly p_comb = E::weighted_sum(std::move(terms)).evaluate_fused_with_domain(4 * m_i, 2 * s_max);
+        E::LeafCache leaves;
+        Poly p12 = E::weighted_sum(std::move(terms)).evaluate_fused_with_domain(2 * m_i, 2 * s_max, &leaves);
+        Poly hXY = h_expr.evaluate_fused_with_domain(2 * m_i, 2 * s_max, &leaves);
+        leaves.clear();
+        Poly k0_h = hXY.mul_ones_x(m_i, inv_m_i);
+        Poly p_comb = Poly::lincomb({Term(one, &p12), Term(kappa0_sq, &k0_h)});
         auto q23 = p_comb.div_by_vanishing_opt((int64_t)m_i, (int64_t)s_max);
         q2XY = std::move(q23.first), q3XY = std::move(q23.second);
         ScalarField minus_one = fr_neg(one);
