@@ -310,6 +310,18 @@ tkmk_error tkmk_vec_suffix_product(const tkmk_fr *a_dev, uint64_t n, tkmk_fr *ou
 tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, uint32_t cols, const tkmk_vecops_config *cfg, tkmk_fr *out);
 
 /* ---------------------------------------------------------------------------------------------
+ * Bivariate NTT over G1 POINTS: out[i][j] = sum_{a < x_size, b < y_size} w_x^(+-i a) w_y^(+-j b) in[a][b], natural order, roots of
+ * unity as bls12_381_get_root_of_unity; the inverse direction is NOT divided by x_size * y_size.  No reference counterpart (the
+ * reference commits in the coefficient basis only).  The inverse transform of the CRS sub-grid [tau_x^a tau_y^b]G is the Lagrange-basis
+ * CRS N [L_i(tau_x) L_j(tau_y)]G: an MSM of a polynomial's EVALUATIONS over it, times 1/N, is encode_poly of its coefficients —
+ * and the prover's u, v, w, b are evaluations, mostly zeros and small numbers.  A one-time cost per circuit (seconds at 2^22 points).
+ * in: device, x_size rows of in_stride records (the first y_size of each row are used), bases_form = TKMK_BASES_*; out: device,
+ * x_size * y_size plain affine records ((0, 0) = infinity).  Sizes are powers of two, x_size * y_size < 2^31.
+ * --------------------------------------------------------------------------------------------- */
+tkmk_error tkmk_g1_ntt(const tkmk_g1_affine *in_dev, int bases_form, uint32_t in_stride, uint32_t x_size, uint32_t y_size, tkmk_ntt_dir dir,
+                       tkmk_g1_affine *out_dev, tkmk_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * G2 MSM on BLS12-381 (the twist y^2 = x^3 + 4(1 + u) over Fp2 = Fq[u]/(u^2 + 1)) — ICICLE v3's `bls12_381_g2_msm`
  * (icicle_bls12_381::curve::G2CurveCfg).  The reference has no G2 MSM call site: G2 appears as nine scalar multiplications
  * of the generator in Sigma2::gen (packages/backend/libs/src/group_structures/mod.rs:752-777), which fit this entry as a

@@ -1,0 +1,146 @@
+// g1ntt.hip — the bivariate NTT over G1 POINTS ("in the exponent") behind tkmk_g1_ntt (include/tkmk.h):
+//     out[i][j] = sum_{a < x_size, b < y_size} w_x^(+-i a) w_y^(+-j b) in[a][b]
+// No reference counterpart: the reference commits every polynomial in the coefficient basis (encode_poly, libs/src/iotools/mod.rs:2041-2113).
+// Applied once per circuit to the sub-grid [tau_x^a tau_y^b] G of the CRS (inverse direction) it yields the LAGRANGE-basis points
+//     Lambda_ij = sum_ab w_x^(-i a) w_y^(-j b) [tau_x^a tau_y^b] G = [N L_i(tau_x) L_j(tau_y)] G,
+// so that the commitment of a polynomial given by its evaluations e_ij on the roots of unity is (1/N) sum_ij e_ij Lambda_ij — the same
+// point as encode_poly of its coefficients.  The prover's u, v, w and b ARE evaluations (read_R1CS_gen_uvwXY, gen_bXY:
+// libs/src/iotools/mod.rs:1287-1420, libs/src/polynomial_structures/mod.rs:132-162), mostly zeros and small numbers, which an MSM skips or
+// passes in one window; their inverse transforms are dense 255-bit scalars.
+//
+// Stockham decimation-in-frequency stages over XYZZ points, one lane per butterfly:  (a, b) -> (a + b, [w](a - b)).  The scalar
+// multiplication is double-and-add over the bits of the twiddle; lanes are ordered with the batch index fastest, so a wave shares its
+// twiddle and only executes the additions of set bits.  A one-time cost per circuit (seconds); the per-proof kernels are elsewhere.
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct g1ntt_stage_t {
+    uint32_t m, s;                     // current transform length, stride (Stockham: m halves, s doubles)
+    uint32_t seq_stride, batch_stride; // element (k, c) of sequence c at k * seq_stride + c * batch_stride
+    uint32_t batch;                    // sequences
+    uint32_t tw_step;                  // twiddle of butterfly row p: table[p * tw_step]
+};
+
+// converted / plain / Montgomery affine records -> XYZZ in saturated Montgomery form (the strided sub-grid view is resolved here)
+__global__ __launch_bounds__(256) void k_g1ntt_load(const g1_affine_t *__restrict__ in, uint32_t in_stride, uint32_t y_size, uint64_t n, int form,
+                                                   fq_t conv, g1_xyzz_t *__restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t a = (uint32_t)(e / y_size), b = (uint32_t)(e - (uint64_t)a * y_size);
+    g1_affine_t p = tk_load(in + (uint64_t)a * in_stride + b);
+    if (!G1::is_inf(p)) {
+        p.x = Fq::canon(p.x), p.y = Fq::canon(p.y);
+        if (form == TKMK_BASES_PLAIN) p.x = Fq::to_mont(p.x), p.y = Fq::to_mont(p.y);
+        else if (form == TKMK_BASES_CONVERTED) p.x = Fq::mul(p.x, conv), p.y = Fq::mul(p.y, conv);   // x R' * (R^2 / R') / R = x R
+    }
+    tk_store(out + e, G1::from_affine(p));
+}
+
+__global__ __launch_bounds__(64) void k_g1ntt_stage(const g1_xyzz_t *__restrict__ x, g1_xyzz_t *__restrict__ y, g1ntt_stage_t st, const fr_t *__restrict__ tw,
+                                                   uint64_t lanes) {
+    uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= lanes) return;
+    const uint32_t c = (uint32_t)(L % st.batch), t = (uint32_t)(L / st.batch);   // batch index fastest: the wave shares p
+    const uint32_t h = st.m >> 1, p = t / st.s, q = t - p * st.s;
+    const uint64_t base = (uint64_t)c * st.batch_stride;
+    const g1_xyzz_t a = tk_load(x + base + (uint64_t)(q + st.s * p) * st.seq_stride);
+    const g1_xyzz_t b = tk_load(x + base + (uint64_t)(q + st.s * (p + h)) * st.seq_stride);
+    tk_store(y + base + (uint64_t)(q + st.s * (2 * p)) * st.seq_stride, G1::add(a, b));
+    g1_xyzz_t d = G1::add(a, G1::neg(b));
+    if (p) {   // [w] d, w = table[p * tw_step] (plain integer below r), most significant set bit first
+        const fr_t w = tk_load(tw + (uint64_t)p * st.tw_step);
+        int top = 254;
+        while (top > 0 && !((w.l[top >> 5] >> (top & 31)) & 1u)) top--;
+        g1_xyzz_t acc = d;
+        for (int bit = top - 1; bit >= 0; bit--) {
+            acc = G1::dbl(acc);
+            if ((w.l[bit >> 5] >> (bit & 31)) & 1u) acc = G1::add(acc, d);
+        }
+        d = acc;
+    }
+    tk_store(y + base + (uint64_t)(q + st.s * (2 * p + 1)) * st.seq_stride, d);
+}
+
+// XYZZ -> plain affine records (one inversion per point)
+__global__ __launch_bounds__(128) void k_g1ntt_store(const g1_xyzz_t *__restrict__ in, uint64_t n, g1_affine_t *__restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    g1_xyzz_t p = tk_load(in + e);
+    g1_affine_t a;
+    if (G1::is_inf(p)) {
+        a.x = Fq::zero(), a.y = Fq::zero();
+    } else {
+        a = G1::to_affine(p);
+        a.x = Fq::from_mont(a.x), a.y = Fq::from_mont(a.y);
+    }
+    tk_store(out + e, a);
+}
+
+fr_t fr_from_abi(const tkmk_fr &v) {
+    fr_t r;
+    for (int i = 0; i < 8; i++) r.l[i] = v.limbs[i];
+    return r;
+}
+
+}  // namespace
+
+TK_API tkmk_error tkmk_g1_ntt(const tkmk_g1_affine *in_dev, int bases_form, uint32_t in_stride, uint32_t x_size, uint32_t y_size, tkmk_ntt_dir dir,
+                              tkmk_g1_affine *out_dev, tkmk_stream stream) {
+    if (!in_dev || !out_dev) return TKMK_ERR_INVALID_POINTER;
+    if (!x_size || !y_size || (x_size & (x_size - 1)) || (y_size & (y_size - 1)) || in_stride < y_size) return TKMK_ERR_INVALID_ARGUMENT;
+    if (bases_form != TKMK_BASES_PLAIN && bases_form != TKMK_BASES_MONTGOMERY && bases_form != TKMK_BASES_CONVERTED) return TKMK_ERR_INVALID_ARGUMENT;
+    if ((uint64_t)x_size * y_size >= (1ull << 31)) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    const uint64_t n = (uint64_t)x_size * y_size;
+    // twiddle tables on the host: w^k or w^-k for k < size, plain integers (the declared root-of-unity convention)
+    auto table = [&](uint32_t size, std::vector<fr_t> &out) -> tkmk_error {
+        out.assign(size, Fr::zero());
+        out[0].l[0] = 1;
+        if (size == 1) return TKMK_SUCCESS;
+        tkmk_fr w_abi;
+        TK_TRY(bls12_381_get_root_of_unity(size, &w_abi));
+        fr_t w = Fr::to_mont(fr_from_abi(w_abi));
+        if (dir == TKMK_NTT_INVERSE) w = Fr::inv(w);
+        fr_t run = Fr::one();
+        for (uint32_t k = 1; k < size; k++) {
+            run = Fr::mul(run, w);
+            out[k] = Fr::from_mont(run);
+        }
+        return TKMK_SUCCESS;
+    };
+    std::vector<fr_t> twx, twy;
+    TK_TRY(table(x_size, twx));
+    TK_TRY(table(y_size, twy));
+    tk_scratch d_twx, d_twy, d_a, d_b;
+    TK_TRY(d_twx.alloc((size_t)x_size * sizeof(fr_t), s));
+    TK_TRY(d_twy.alloc((size_t)y_size * sizeof(fr_t), s));
+    TK_TRY(d_a.alloc(n * sizeof(g1_xyzz_t), s));
+    TK_TRY(d_b.alloc(n * sizeof(g1_xyzz_t), s));
+    TK_HIP(hipMemcpyAsync(d_twx.p, twx.data(), (size_t)x_size * sizeof(fr_t), hipMemcpyHostToDevice, s));
+    TK_HIP(hipMemcpyAsync(d_twy.p, twy.data(), (size_t)y_size * sizeof(fr_t), hipMemcpyHostToDevice, s));
+    // converted records hold x R' (R' = 2^(29 * 14)); the constant that takes them to the saturated Montgomery form is R^2 / R'
+    fq_t rp;
+    for (int j = 0; j < Fq::N; j++) rp.l[j] = bls12_381_fq_params::KSATM[j];   // R' mod p, a plain integer
+    const fq_t conv = Fq::mul(Fq::inv(Fq::to_mont(rp)), Fq::r2());
+    hipLaunchKernelGGL(k_g1ntt_load, tk_div_up(n, 256), 256, 0, s, (const g1_affine_t *)in_dev, in_stride, y_size, n, bases_form, conv, d_a.as<g1_xyzz_t>());
+    g1_xyzz_t *cur = d_a.as<g1_xyzz_t>(), *nxt = d_b.as<g1_xyzz_t>();
+    auto axis = [&](uint32_t len, uint32_t seq_stride, uint32_t batch_stride, uint32_t batch, const fr_t *tw) {
+        for (uint32_t m = len, st = 1; m > 1; m >>= 1, st <<= 1) {
+            g1ntt_stage_t g{m, st, seq_stride, batch_stride, batch, len / m};
+            const uint64_t lanes = (uint64_t)batch * (len / 2);
+            hipLaunchKernelGGL(k_g1ntt_stage, tk_div_up(lanes, 64), 64, 0, s, (const g1_xyzz_t *)cur, nxt, g, tw, lanes);
+            std::swap(cur, nxt);
+        }
+    };
+    axis(y_size, 1, y_size, x_size, d_twy.as<fr_t>());   // along Y inside every row
+    axis(x_size, y_size, 1, y_size, d_twx.as<fr_t>());   // along X inside every column
+    hipLaunchKernelGGL(k_g1ntt_store, tk_div_up(n, 128), 128, 0, s, (const g1_xyzz_t *)cur, n, (g1_affine_t *)out_dev);
+    TK_HIP(hipGetLastError());
+    TK_HIP(hipStreamSynchronize(s));   // the host twiddle vectors and the frame's scratch end with this call
+    return TKMK_SUCCESS;
+}
