@@ -154,6 +154,32 @@ def test_service_equals_python_prover_and_restatement(gpu, oracle, tmp_path, see
         assert (np.asarray(native_points[name]) == np.asarray(prove_ref.g1_of(dlogs[name], g))).all(), name
 
 
+@pytest.mark.parametrize("seed,shape", SHAPES[1:3])
+def test_service_with_lagrange_tables_equals_python_prover(gpu, oracle, tmp_path, monkeypatch, seed, shape):
+    """the evaluation-basis commitments of prove0 (U, V, W, B as (1/N) MSM(evaluations, Lagrange-basis table) + blinding terms): forced
+    on at a small shape by asking for a commit table; the proof must be the Python prover's (coefficient route), byte for byte, and
+    TKMK_PROVER_LAGRANGE=0 must give the same document through the coefficient route of the native side"""
+    import synth_circuit
+    from test_gpu_prove import _stage_crs_file, seeded_mixer
+    from tkmk import proofio, service
+    from tkmk.prove import Prover, run_rounds
+    inst = synth_circuit.build(str(tmp_path), random.Random(seed), **shape)
+    crs_dir, out_dir = str(tmp_path / "crs"), str(tmp_path / "out")
+    sigma, crs, g = _stage_crs_file(gpu, oracle, inst, crs_dir)
+    mixer = seeded_mixer(seed)
+    mixer_path = _mixer_file(tmp_path, mixer)
+    prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, sigma=sigma)
+    points, scalars, _, _, _ = run_rounds(prover, binding)
+    want_doc = proofio.format_proof(points, scalars)
+    monkeypatch.setenv("TKMK_PROVER_TABLE_C", "12")
+    for lagrange in ("1", "0"):
+        monkeypatch.setenv("TKMK_PROVER_LAGRANGE", lagrange)
+        with service.Prover(inst["qap"], crs_dir) as p:
+            for rep in range(2):
+                doc, _ = p.prove(inst["synth"], out_dir, testing_mixer_json=mixer_path)
+                assert doc == want_doc, (lagrange, rep)
+
+
 @pytest.mark.parametrize("order", ["rustc_size_groups", "rustc_align_only", "declared"])
 def test_prove_and_preprocess_from_the_reference_archives(gpu, oracle, tmp_path, order):
     """<crs>/combined_sigma.rkyv and <crs>/sigma_preprocess.rkyv instead of the flat payload: same proof.json / preprocess.json"""

@@ -734,6 +734,27 @@ class Sigma1 {
     }
     // -> affine commitment
     G1Affine encode_poly(DensePolynomialExt &poly) const { return run_jobs({job(poly)})[0]; }
+    // the MSM job of a polynomial given by its rs_x x rs_y EVALUATIONS, over a table that holds the Lagrange-basis points of that grid
+    // (lagrange_of below): all rows, no view; zeros and small values cost the MSM next to nothing
+    tkmk_msm_job_ex job_evals(const DeviceVec<ScalarField> &evals) const {
+        if (evals.len() < rs_x_ * rs_y_) throw Error("evaluation vector shorter than the Lagrange table");
+        tkmk_msm_job_ex j{};
+        j.scalars = evals.ptr();
+        j.bases = xy_powers_.ptr();
+        j.msm_size = (int)(rs_x_ * rs_y_);
+        j.base_table_len = table_len();
+        if (table_c_ && (uint64_t)rs_x_ * rs_y_ * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
+        return j;
+    }
+    // The Lagrange-basis twin of the grid [0, xs) x [0, ys) of this table: N [L_i(tau_x) L_j(tau_y)] G = the inverse NTT over G1 points of
+    // the monomial sub-grid (tkmk_g1_ntt, unscaled), with the same commit table treatment.  commit(P) = (1/N) MSM(evaluations of P, this).
+    Sigma1 lagrange_of(size_t xs, size_t ys) const {
+        if (xs > rs_x_ || ys > rs_y_ || !is_pow2(xs) || !is_pow2(ys)) throw Error("Lagrange table: the grid must be a power-of-two corner of xy_powers");
+        DeviceVec<G1Affine> lam(xs * ys);
+        host_trace("lagrange_of %zu x %zu", xs, ys);
+        check(tkmk_g1_ntt(xy_powers_.ptr(), TKMK_BASES_CONVERTED, (uint32_t)rs_y_, (uint32_t)xs, (uint32_t)ys, TKMK_NTT_INVERSE, lam.ptr(), nullptr), "tkmk_g1_ntt");
+        return Sigma1(std::move(lam), xs, ys, table_c_);
+    }
     // commitments of independent polynomials in one pipelined call
     std::vector<G1Affine> encode_polys(const std::vector<DensePolynomialExt *> &polys) const {
         std::vector<tkmk_msm_job_ex> jobs;

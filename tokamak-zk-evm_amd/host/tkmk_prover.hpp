@@ -124,6 +124,13 @@ struct ProverSigma {
     std::vector<G1Affine> delta_inv_alphak_xh_tx, delta_inv_alpha4_xj_tx, delta_inv_alphak_yi_ty;   // 3x3, 2, 4x3
     G1Affine delta, eta;
     bool binding_tables_converted = false;   // ProverContext keeps the three binding tables in the MSM's resident form
+    // host copies of the few xy_powers entries the blinding terms of U, V, W, B touch: (a, 0) and (0, b) for small a, b and around n, m_I, s_max
+    std::map<std::pair<size_t, size_t>, G1Affine> xy_edge;
+    const G1Affine &xy_at(size_t a, size_t b) const {
+        auto it = xy_edge.find({a, b});
+        if (it == xy_edge.end()) throw Error("xy_powers entry not kept on the host");
+        return it->second;
+    }
     static ProverSigma from_payload(const CrsPayload &crs, const SetupParams &sp, uint32_t table_c = 0) {
         size_t m_i = sp.l_D - sp.l, rs_x = std::max(2 * sp.n, 2 * m_i), rs_y = 2 * sp.s_max;
         auto want = [&](CrsPayload::Section s, size_t pts, const char *name) {
@@ -138,7 +145,17 @@ struct ProverSigma {
         want(CrsPayload::DeltaInvAlphakYiTy, 12, "delta_inv_alphak_yi_ty");
         auto host = [&](CrsPayload::Section s) { return std::vector<G1Affine>(crs.g1(s), crs.g1(s) + crs.points(s)); };
         const G1Affine *singles = crs.g1(CrsPayload::G1Singles);   // G, x, y, delta, eta, lagrange_KL
-        return ProverSigma{Sigma1(crs.upload(CrsPayload::XyPowers), rs_x, rs_y, table_c),
+        std::map<std::pair<size_t, size_t>, G1Affine> edge;
+        {
+            const G1Affine *xy = crs.g1(CrsPayload::XyPowers);
+            for (size_t base : {(size_t)0, (size_t)sp.n, m_i})
+                for (size_t k = 0; k < 4; k++)
+                    if (base + k < rs_x) edge[{base + k, 0}] = xy[(base + k) * rs_y];
+            for (size_t base : {(size_t)0, (size_t)sp.s_max})
+                for (size_t k = 0; k < 4; k++)
+                    if (base + k < rs_y) edge[{0, base + k}] = xy[base + k];
+        }
+        ProverSigma out{Sigma1(crs.upload(CrsPayload::XyPowers), rs_x, rs_y, table_c),
                            crs.upload(CrsPayload::GammaInvOInst),
                            crs.upload(CrsPayload::EtaInvLiOInterAlpha4Kj),
                            crs.upload(CrsPayload::DeltaInvLiOPrv),
@@ -147,7 +164,10 @@ struct ProverSigma {
                            host(CrsPayload::DeltaInvAlphakYiTy),
                            singles[3],
                            singles[4],
-                           false};
+                           false,
+                           {}};
+        out.xy_edge = std::move(edge);
+        return out;
     }
 };
 
@@ -257,6 +277,11 @@ class Prover {
         static std::shared_ptr<const LagrangePolys> make(size_t m_i, size_t s_max);
     };
     std::shared_ptr<const LagrangePolys> lagrange;
+    // Evaluation-basis commitments (a resident context with Lagrange-basis tables): u, v, w and b exist as evaluations on the roots of
+    // unity before they exist as coefficients (read_R1CS_gen_uvwXY, gen_bXY), and those are mostly zeros and small numbers.  With the
+    // tables set, prove0 commits U, V, W, B as (1/N) MSM(evaluations, Lagrange table) + the blinding terms; the points are the same.
+    DeviceVec<ScalarField> u_ev, v_ev, w_ev, b_ev;
+    const Sigma1 *lagrange_n = nullptr, *lagrange_mi = nullptr;   // grids n x s_max (u, v, w) and m_I x s_max (b)
     const LagrangePolys &lagrange_polys() {
         if (!lagrange) lagrange = LagrangePolys::make(m_i, sp.s_max);
         return *lagrange;
@@ -366,9 +391,39 @@ class Prover {
         Poly Q_AY_XY = poly_comb({{one, &q1XY}, {mx.rU_Y, &vXY}, {mx.rV_Y, &uXY}, {minus_one, &rW_Y}, {fr_mul(mx.rU_X, mx.rV_Y), &t_n},
                                   {fr_mul(mx.rU_Y, mx.rV_Y), &t_smax}});
         term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
+        if (lagrange_n && lagrange_mi && u_ev.len() && v_ev.len() && w_ev.len() && b_ev.len()) return prove0_from_evaluations(Q_AX_XY, Q_AY_XY);
         Poly BXY = poly_comb({{one, &bXY}, {one, term_b_zk.get()}});
         auto c = sigma->sigma1.encode_polys({&UXY, &VXY, &WXY, &Q_AX_XY, &Q_AY_XY, &BXY});
         return Proof0{c[0], c[1], c[2], c[3], c[4], c[5]};
+    }
+    // U, V, W, B from the evaluations (same points as the coefficient route above):
+    //   commit(p + sum_k c_k T^k (T^e - 1)) = (1/N) MSM(evaluations of p, Lagrange table) + sum_k c_k ([tau^(e+k)]G - [tau^k]G)
+    Proof0 prove0_from_evaluations(Poly &Q_AX_XY, Poly &Q_AY_XY) {
+        using namespace prover_detail;
+        const Mixer &mx = mixer;
+        const size_t n = sp.n, s_max = sp.s_max;
+        std::vector<G1Affine> c = Sigma1::run_jobs({lagrange_n->job_evals(u_ev), lagrange_n->job_evals(v_ev), lagrange_n->job_evals(w_ev),
+                                                    sigma->sigma1.job(Q_AX_XY), sigma->sigma1.job(Q_AY_XY), lagrange_mi->job_evals(b_ev)});
+        const ScalarField inv_n = fr_inv(fr_mul(fr_from_u32((uint32_t)n), fr_from_u32((uint32_t)s_max)));
+        const ScalarField inv_mi = fr_inv(fr_mul(fr_from_u32((uint32_t)m_i), fr_from_u32((uint32_t)s_max)));
+        using Row = std::vector<std::pair<ScalarField, G1Affine>>;
+        auto vanishing_terms = [&](Row &row, const ScalarField *coef, size_t k_count, size_t exponent, bool x_axis) {
+            for (size_t k = 0; k < k_count; k++) {
+                row.push_back({coef[k], x_axis ? sigma->xy_at(exponent + k, 0) : sigma->xy_at(0, exponent + k)});
+                row.push_back({fr_neg(coef[k]), x_axis ? sigma->xy_at(k, 0) : sigma->xy_at(0, k)});
+            }
+        };
+        Row ru{{inv_n, c[0]}}, rv{{inv_n, c[1]}}, rw{{inv_n, c[2]}}, rb{{inv_mi, c[5]}};
+        vanishing_terms(ru, &mx.rU_X, 1, n, true), vanishing_terms(ru, &mx.rU_Y, 1, s_max, false);
+        vanishing_terms(rv, &mx.rV_X, 1, n, true), vanishing_terms(rv, &mx.rV_Y, 1, s_max, false);
+        vanishing_terms(rw, mx.rW_X.data(), mx.rW_X.size(), n, true), vanishing_terms(rw, mx.rW_Y.data(), mx.rW_Y.size(), s_max, false);
+        vanishing_terms(rb, mx.rB_X.data(), mx.rB_X.size(), m_i, true), vanishing_terms(rb, mx.rB_Y.data(), mx.rB_Y.size(), s_max, false);
+        size_t width = std::max(std::max(ru.size(), rv.size()), std::max(rw.size(), rb.size()));
+        ScalarField zero{};
+        for (Row *r : {&ru, &rv, &rw, &rb})
+            while (r->size() < width) r->push_back({zero, r->front().second});
+        auto uvwb = g1_lincombs({ru, rv, rw, rb});
+        return Proof0{uvwb[0], uvwb[1], uvwb[2], c[3], c[4], uvwb[3]};
     }
 
     // prove1 (lib.rs:1784-1956)

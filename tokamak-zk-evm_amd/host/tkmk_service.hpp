@@ -50,6 +50,8 @@ class ProverContext {
     WireLists iface_, prv_, pub_;
     DeviceVec<ScalarField> s0_identity_, s1_identity_, xp_, yp_;   // w_x^row / w_y^col matrices and the two power tables
     std::shared_ptr<const Prover::LagrangePolys> lagrange_;           // K_last, L_last, K0, KL of prove2 / prove4
+    std::unique_ptr<Sigma1> lagrange_n_, lagrange_mi_own_;            // Lagrange-basis commit tables of the n x s_max and m_I x s_max grids
+    const Sigma1 *lagrange_mi_ = nullptr;                             // (= lagrange_n_ when n == m_I)
 
     ScalarField *pinned_ = nullptr;                                 // witness staging
     uint64_t pinned_cap_ = 0;
@@ -183,6 +185,21 @@ class ProverContext {
         for (DeviceVec<G1Affine> *t : {&c->sigma->gamma_inv_o_inst, &c->sigma->eta_inv_li_o_inter_alpha4_kj, &c->sigma->delta_inv_li_o_prv})
             check(bls12_381_msm_convert_bases(t->ptr(), t->len(), &cfg, t->ptr()), "msm::convert_bases");
         c->sigma->binding_tables_converted = true;
+        // Lagrange-basis twins of the commit table for the grids u, v, w (n x s_max) and b (m_I x s_max) live on: prove0 then commits
+        // them from their evaluations.  Only with a commit table (a context that amortises seconds of one-time work); TKMK_PROVER_LAGRANGE=0
+        // keeps the coefficient route.
+        {
+            const char *e = getenv("TKMK_PROVER_LAGRANGE");
+            const size_t n = c->sp.n, m_i = c->m_i, s_max = c->sp.s_max;
+            if (c->sigma->sigma1.table_c() && !(e && atoi(e) == 0) && is_pow2(n) && is_pow2(m_i) && is_pow2(s_max)) {
+                c->lagrange_n_.reset(new Sigma1(c->sigma->sigma1.lagrange_of(n, s_max)));
+                if (m_i == n) c->lagrange_mi_ = c->lagrange_n_.get();
+                else {
+                    c->lagrange_mi_own_.reset(new Sigma1(c->sigma->sigma1.lagrange_of(m_i, s_max)));
+                    c->lagrange_mi_ = c->lagrange_mi_own_.get();
+                }
+            }
+        }
         host_trace("open: Lagrange polynomials");
         c->lagrange_ = Prover::LagrangePolys::make(c->m_i, c->sp.s_max);
         host_trace("open: done");
@@ -279,6 +296,7 @@ class ProverContext {
             check(tkmk_r1cs_library_eval(lib_, d_vars.ptr(), d_id.ptr(), d_off.ptr(), (uint32_t)P, (uint32_t)n, (uint32_t)s_max, u.ptr(), v.ptr(), w.ptr(), nullptr),
                   "tkmk_r1cs_library_eval");
             p->uXY = Poly::from_rou_evals(u, n, s_max), p->vXY = Poly::from_rou_evals(v, n, s_max), p->wXY = Poly::from_rou_evals(w, n, s_max);
+            if (lagrange_n_) p->u_ev = std::move(u), p->v_ev = std::move(v), p->w_ev = std::move(w);   // prove0 commits from these
         }
         // gen_bXY + the (scalar, CRS row) lists of O_mid / O_prv / O_pub_free, kind by kind
         uint64_t n_mid = 0, n_prv = 0, n_pub = 0;
@@ -314,6 +332,7 @@ class ProverContext {
                   "tkmk_witness_route");
         }
         p->bXY = Poly::from_rou_evals(b_ev, m_i, s_max);
+        if (lagrange_mi_) p->b_ev = std::move(b_ev), p->lagrange_n = lagrange_n_.get(), p->lagrange_mi = lagrange_mi_;
         p->rXY = Poly::zero();
         p->a_free_X = gen_a_free_X(a_pub_user, a_pub_block, sp);
         p->t_n = vanishing(n, true), p->t_mi = vanishing(m_i, true), p->t_smax = vanishing(s_max, false);
