@@ -189,7 +189,10 @@ def main():
                 avg_ms = acc_ms / acc_cnt
                 alg = ALG_BYTES_PER_POINT * stats["msm.points"] / acc_cnt      # per launch: one launch per MSM
                 achieved = alg / (avg_ms * 1e-3) / 1e9
-                mads = stats["msm.points"] * ADDS_PER_POINT * MADS_PER_BUCKET_ADD / (acc_ms * 1e-3)
+                # bucket additions the accumulate launches actually ran: the library counts the sorted-list lengths on the device (zero
+                # digits of sparse / small scalars drop out, a table commit has 13 windows, a plain one 16)
+                adds = stats.get("msm.bucket_additions", 0)
+                mads = adds * MADS_PER_BUCKET_ADD / (acc_ms * 1e-3)
                 out["roofline"] = {"bound": "hbm", "kernel": "k_accumulate_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles("prove_accumulate_configs3" if args.s_max == 1024 else None),
                                    "avg_launch_ms": avg_ms, "launches": acc_cnt, "launches_per_proof": acc_cnt / args.steps,
@@ -197,7 +200,9 @@ def main():
                                    "note": "integer-VALU bound by construction (SURVEY.md §8d: ~375 int mul-adds per algorithmic byte); launches of "
                                            "concurrent streams overlap, so the summed launch time can exceed its share of the wall"}
                 out["valu_roofline"] = {"kernel": "k_accumulate_chunks", "unit": "v_mad_u64_u32 lane-ops/s", "achieved": mads, "peak": MAD_PEAK_PER_S,
-                                        "frac": mads / MAD_PEAK_PER_S}
+                                        "frac": mads / MAD_PEAK_PER_S, "bucket_additions_per_proof": adds / args.steps,
+                                        "note": "additions counted by the library (sorted-list lengths) x 3542 multiply-adds each, over the summed launch "
+                                                "times; launches of concurrent streams overlap, so this understates the rate of a launch running alone"}
             out["hbm_roofline_whole_step"] = {"achieved_GBps": out["work_per_proof"]["algorithmic_bytes"] / (elapsed / args.steps) / 1e9, "peak_GBps": HBM_PEAK_GBS}
             if msm_sharded is not None:
                 out["msm_sharded"] = msm_sharded

@@ -564,12 +564,39 @@ static std::atomic<uint64_t> g_stat[TK_STAT_COUNT];
 void tk_stat_add(int which, uint64_t v) {
     if (which >= 0 && which < TK_STAT_COUNT) g_stat[which].fetch_add(v, std::memory_order_relaxed);
 }
+// bucket additions actually issued (the length of the sorted lists: zero digits of the scalars drop out): counted on the device by a
+// one-thread kernel after every sort, into one resident 64-bit cell; read back on request only
+static unsigned long long *g_dev_entries = nullptr;
+static std::mutex g_dev_entries_mu;
+unsigned long long *tk_stat_device_entries() {
+    std::lock_guard<std::mutex> lk(g_dev_entries_mu);
+    if (!g_dev_entries) {
+        if (hipMalloc((void **)&g_dev_entries, sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_dev_entries, 0, sizeof(unsigned long long));
+    }
+    return g_dev_entries;
+}
 TK_API tkmk_error tkmk_stats_reset(void) {
     for (auto &c : g_stat) c.store(0);
+    std::lock_guard<std::mutex> lk(g_dev_entries_mu);
+    if (g_dev_entries) {
+        TK_HIP(hipDeviceSynchronize());
+        TK_HIP(hipMemset(g_dev_entries, 0, sizeof(unsigned long long)));
+    }
     return TKMK_SUCCESS;
 }
 TK_API tkmk_error tkmk_stats_get(const char *name, uint64_t *value) {
     if (!name || !value) return TKMK_ERR_INVALID_POINTER;
+    if (std::string(name) == "msm.bucket_additions") {
+        std::lock_guard<std::mutex> lk(g_dev_entries_mu);
+        unsigned long long v = 0;
+        if (g_dev_entries) {
+            TK_HIP(hipDeviceSynchronize());
+            TK_HIP(hipMemcpy(&v, g_dev_entries, sizeof v, hipMemcpyDeviceToHost));
+        }
+        *value = v;
+        return TKMK_SUCCESS;
+    }
     static const char *names[TK_STAT_COUNT] = {"msm.points", "msm.calls", "ntt.elements", "ntt.calls"};
     for (int i = 0; i < TK_STAT_COUNT; i++)
         if (std::string(name) == names[i]) {
