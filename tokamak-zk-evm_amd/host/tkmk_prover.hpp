@@ -516,8 +516,10 @@ class Prover {
     }
 
     // prove4 (lib.rs:2356-3206)
+    // test_parts = true also commits Pi_A, Pi_C, Pi_B one by one (Proof4Test: what the reference's testing-mode verifier looks at);
+    // the proof itself carries only their sums
     std::pair<Proof4, Proof4Test> prove4(const Proof3 &proof3, const std::vector<ScalarField> &thetas, const ScalarField &kappa0,
-                                        const ScalarField &chi, const ScalarField &zeta, const ScalarField &kappa1) {
+                                        const ScalarField &chi, const ScalarField &zeta, const ScalarField &kappa1, bool test_parts = false) {
         using namespace prover_detail;
         const Mixer &mx = mixer;
         size_t n = sp.n, s_max = sp.s_max;
@@ -599,10 +601,19 @@ class Prover {
         // N_X is M_X: both numerators are R minus a constant and both are divided by the same X - chi / w_x first, and a constant
         // only moves the remainder of that division, never its quotient (the reference commits the same polynomial twice,
         // lib.rs:2572-2700).  One 2^22-point commitment instead of two; the Y-quotients differ and are both committed.
+        ScalarField k1_4 = fr_mul(k1_2, k1_2), zero{};
+        if (!test_parts) {
+            // Pi_X = Pi_AX + Pi_CX + kappa1^4 Pi_B and Pi_Y = Pi_AY + Pi_CY are the proof's entries (lib.rs:3180-3184): the commitment is
+            // linear, so the three quotient polynomials are added first (one pass) and committed ONCE — the reference commits Pi_AX
+            // (2^23 coefficients), Pi_CX (2^24) and Pi_B apart and adds the points
+            Poly pi_x = Poly::lincomb({Term(one, &std::get<0>(piA)), Term(one, &std::get<0>(piC)), Term(k1_4, &std::get<0>(piB))});
+            Poly pi_y = Poly::lincomb({Term(one, &std::get<1>(piA)), Term(one, &std::get<1>(piC))});
+            auto cc = sigma->sigma1.encode_polys({&pi_x, &pi_y, &std::get<0>(M), &std::get<1>(M), &std::get<1>(N)});
+            return {Proof4{cc[0], cc[1], cc[2], cc[3], cc[2], cc[4]}, Proof4Test{}};
+        }
         auto c = sigma->sigma1.encode_polys({&std::get<0>(piA), &std::get<1>(piA), &std::get<0>(M), &std::get<1>(M), &std::get<1>(N),
                                              &std::get<0>(piC), &std::get<1>(piC), &std::get<0>(piB)});
         const G1Affine &Pi_AX = c[0], &Pi_AY = c[1], &M_X = c[2], &M_Y = c[3], &N_X = c[2], &N_Y = c[4], &Pi_CX = c[5], &Pi_CY = c[6], &Pi_B0 = c[7];
-        ScalarField k1_4 = fr_mul(k1_2, k1_2), zero{};
         auto sums = g1_lincombs({{{k1_4, Pi_B0}, {zero, Pi_B0}, {zero, Pi_B0}},   // encode(pi_B) * kappa1^4 (lib.rs:3180)
                                  {{one, Pi_AX}, {one, Pi_CX}, {k1_4, Pi_B0}},      // lib.rs:3183-3184
                                  {{one, Pi_AY}, {one, Pi_CY}, {zero, Pi_AY}}});
