@@ -204,6 +204,8 @@ class ProverContext {
         c->lagrange_ = Prover::LagrangePolys::make(c->m_i, c->sp.s_max);
         host_trace("open: done");
         check(tkmk_device_synchronize(), "synchronize");
+        check(tkmk_release_scratch(), "release_scratch");   // the one-time transforms' scratch (1.6 GB for the group NTT) is not a proof's
+        check(tkmk_device_synchronize(), "synchronize");
         return c;
     }
 
