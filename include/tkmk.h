@@ -320,6 +320,12 @@ tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, uint32_t
  * --------------------------------------------------------------------------------------------- */
 tkmk_error tkmk_g1_ntt(const tkmk_g1_affine *in_dev, int bases_form, uint32_t in_stride, uint32_t x_size, uint32_t y_size, tkmk_ntt_dir dir,
                        tkmk_g1_affine *out_dev, tkmk_stream stream);
+/* Prefix sums of points: out[j] = sum_{j' <= j} in[idx(j')], idx(j) = j, or (j % rows) * cols + j / rows with `transposed` (the rows x cols
+ * row-major table walked column by column).  With the Lagrange-basis points in the order of prove1's running product (lib.rs:1858-1866) this
+ * is the table over which a PIECEWISE-CONSTANT evaluation vector commits as an MSM of its few jumps: sum_j r_j L_j = sum_j (r_j - r_{j+1}) S_j,
+ * and r jumps only where the copy permutation is not the identity.  in: device, form TKMK_BASES_*; out: device, plain affine; out != in. */
+tkmk_error tkmk_g1_prefix_sums(const tkmk_g1_affine *in_dev, int bases_form, uint32_t rows, uint32_t cols, int transposed,
+                               tkmk_g1_affine *out_dev, tkmk_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * G2 MSM on BLS12-381 (the twist y^2 = x^3 + 4(1 + u) over Fp2 = Fq[u]/(u^2 + 1)) — ICICLE v3's `bls12_381_g2_msm`

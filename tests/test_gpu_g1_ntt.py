@@ -78,3 +78,41 @@ def test_commit_from_evaluations_equals_commit_from_coefficients(gpu, oracle):
     s_ev = gpu.projective_to_affine_bytes(gpu.msm(ev, lam))
     inv_n = oracle.to_bytes([pow(n, R - 2, R)], 32)
     assert (np.asarray(oracle.g1_scalar_mul(inv_n, s_ev)) == from_coeffs).all()
+
+
+@pytest.mark.parametrize("rows,cols,transposed", [(1, 1, False), (5, 3, False), (5, 3, True), (64, 33, True), (300, 70, False), (128, 64, True)])
+def test_g1_prefix_sums_in_the_exponent(gpu, oracle, rows, cols, transposed):
+    n = rows * cols
+    h, pts = _points(gpu, oracle, 700 + n, n)
+    R = oracle.R_MOD
+    hv = oracle.to_ints(h, 32)
+    order = [(j % rows) * cols + j // rows for j in range(n)] if transposed else list(range(n))
+    run, want = 0, []
+    for j in range(n):
+        run = (run + hv[order[j]]) % R
+        want.append(run)
+    want_pts = np.asarray(oracle.g1_batch_scalar_mul(oracle.to_bytes(want, 32), np.tile(oracle.g1_generator(), n)))
+    got = np.asarray(gpu.g1_prefix_sums(pts, rows, cols, transposed=transposed).to_host())
+    assert (got == want_pts).all()
+    conv = gpu.msm_convert_bases(pts, n)
+    assert (np.asarray(gpu.g1_prefix_sums(conv, rows, cols, transposed=transposed, bases_form=gpu.BASES_CONVERTED).to_host()) == want_pts).all()
+
+
+def test_piecewise_constant_vector_commits_through_its_jumps(gpu, oracle):
+    """sum_j r_j L_j == sum_j (r_j - r_{j+1}) S_j with S = prefix sums of L: the identity prove1's commitment of R uses"""
+    n = 4096
+    _, lam = _points(gpu, oracle, 811, n)
+    pre = gpu.g1_prefix_sums(lam, n, 1)
+    R = oracle.R_MOD
+    rng = np.random.default_rng(9)
+    jumps = sorted(int(v) for v in rng.choice(n - 1, 40, replace=False))
+    vals, cur = [], int.from_bytes(rng.bytes(31), "little")
+    for j in range(n):
+        vals.append(cur)
+        if j in jumps:
+            cur = int.from_bytes(rng.bytes(31), "little")
+    diffs = [(vals[j] - (vals[j + 1] if j + 1 < n else 0)) % R for j in range(n)]
+    assert sum(1 for d in diffs if d) <= len(jumps) + 1
+    direct = gpu.projective_to_affine_bytes(gpu.msm(oracle.to_bytes(vals, 32), lam))
+    through = gpu.projective_to_affine_bytes(gpu.msm(oracle.to_bytes(diffs, 32), pre))
+    assert (direct == through).all()

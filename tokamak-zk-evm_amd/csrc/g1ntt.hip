@@ -79,6 +79,67 @@ __global__ __launch_bounds__(128) void k_g1ntt_store(const g1_xyzz_t *__restrict
     tk_store(out + e, a);
 }
 
+// ---- prefix sums of points: out[j] = sum_{j' <= j} in[idx(j')] ---------------------------------------------------------------
+// three phases: runs of PS_RUN elements per lane, a one-workgroup scan of the run totals, the runs again with their offsets
+#define PS_RUN 64
+__device__ __forceinline__ uint64_t ps_index(uint64_t j, uint32_t rows, uint32_t cols, int transposed) {
+    return transposed ? (j % rows) * cols + j / rows : j;
+}
+__device__ __forceinline__ g1_affine_t ps_load(const g1_affine_t *in, uint64_t at, int form, const fq_t &conv) {
+    g1_affine_t p = tk_load(in + at);
+    if (!G1::is_inf(p)) {
+        p.x = Fq::canon(p.x), p.y = Fq::canon(p.y);
+        if (form == TKMK_BASES_PLAIN) p.x = Fq::to_mont(p.x), p.y = Fq::to_mont(p.y);
+        else if (form == TKMK_BASES_CONVERTED) p.x = Fq::mul(p.x, conv), p.y = Fq::mul(p.y, conv);
+    }
+    return p;
+}
+__global__ __launch_bounds__(64) void k_g1ps_runs(const g1_affine_t *__restrict__ in, uint64_t n, uint32_t rows, uint32_t cols, int transposed, int form,
+                                                 fq_t conv, g1_xyzz_t *__restrict__ totals) {
+    uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, lo = L * PS_RUN;
+    if (lo >= n) return;
+    uint64_t hi = lo + PS_RUN < n ? lo + PS_RUN : n;
+    g1_xyzz_t acc = G1::inf();
+    for (uint64_t j = lo; j < hi; j++) acc = G1::add_mixed(acc, ps_load(in, ps_index(j, rows, cols, transposed), form, conv));
+    tk_store(totals + L, acc);
+}
+// exclusive scan of `count` run totals in place, one workgroup of PS_SCAN lanes (count / PS_SCAN totals per lane, an LDS scan of the
+// lane sums in between: 96 KB of the CU's 160)
+#define PS_SCAN 512
+__global__ __launch_bounds__(PS_SCAN) void k_g1ps_scan(g1_xyzz_t *__restrict__ totals, uint64_t count) {
+    extern __shared__ g1_xyzz_t ps_sh[];   // PS_SCAN records
+    const uint32_t t = threadIdx.x;
+    const uint64_t per = (count + PS_SCAN - 1) / PS_SCAN, lo = (uint64_t)t * per < count ? (uint64_t)t * per : count, hi = lo + per < count ? lo + per : count;
+    g1_xyzz_t sum = G1::inf();
+    for (uint64_t k = lo; k < hi; k++) sum = G1::add(sum, tk_load(totals + k));
+    ps_sh[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < PS_SCAN; off <<= 1) {   // inclusive Hillis-Steele over the lane sums
+        g1_xyzz_t v = G1::inf();
+        if (t >= off) v = ps_sh[t - off];
+        __syncthreads();
+        if (t >= off) ps_sh[t] = G1::add(ps_sh[t], v);
+        __syncthreads();
+    }
+    g1_xyzz_t run = t ? ps_sh[t - 1] : G1::inf();
+    for (uint64_t k = lo; k < hi; k++) {
+        g1_xyzz_t v = tk_load(totals + k);
+        tk_store(totals + k, run);
+        run = G1::add(run, v);
+    }
+}
+__global__ __launch_bounds__(64) void k_g1ps_apply(const g1_affine_t *__restrict__ in, uint64_t n, uint32_t rows, uint32_t cols, int transposed, int form,
+                                                  fq_t conv, const g1_xyzz_t *__restrict__ offsets, g1_xyzz_t *__restrict__ out) {
+    uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, lo = L * PS_RUN;
+    if (lo >= n) return;
+    uint64_t hi = lo + PS_RUN < n ? lo + PS_RUN : n;
+    g1_xyzz_t acc = tk_load(offsets + L);
+    for (uint64_t j = lo; j < hi; j++) {
+        acc = G1::add_mixed(acc, ps_load(in, ps_index(j, rows, cols, transposed), form, conv));
+        tk_store(out + j, acc);
+    }
+}
+
 fr_t fr_from_abi(const tkmk_fr &v) {
     fr_t r;
     for (int i = 0; i < 8; i++) r.l[i] = v.limbs[i];
@@ -142,5 +203,36 @@ TK_API tkmk_error tkmk_g1_ntt(const tkmk_g1_affine *in_dev, int bases_form, uint
     hipLaunchKernelGGL(k_g1ntt_store, tk_div_up(n, 128), 128, 0, s, (const g1_xyzz_t *)cur, n, (g1_affine_t *)out_dev);
     TK_HIP(hipGetLastError());
     TK_HIP(hipStreamSynchronize(s));   // the host twiddle vectors and the frame's scratch end with this call
+    return TKMK_SUCCESS;
+}
+
+// out[j] = sum_{j' <= j} in[idx(j')], idx(j) = j, or (j % rows) * cols + j / rows with `transposed` (a rows x cols row-major table walked
+// column by column: the order of prove1's running product, lib.rs:1858-1866).  in: device, rows * cols records of form TKMK_BASES_*;
+// out: device, rows * cols plain affine records.
+TK_API tkmk_error tkmk_g1_prefix_sums(const tkmk_g1_affine *in_dev, int bases_form, uint32_t rows, uint32_t cols, int transposed,
+                                      tkmk_g1_affine *out_dev, tkmk_stream stream) {
+    if (!in_dev || !out_dev) return TKMK_ERR_INVALID_POINTER;
+    if (!rows || !cols || (uint64_t)rows * cols >= (1ull << 31)) return TKMK_ERR_INVALID_ARGUMENT;
+    if (bases_form != TKMK_BASES_PLAIN && bases_form != TKMK_BASES_MONTGOMERY && bases_form != TKMK_BASES_CONVERTED) return TKMK_ERR_INVALID_ARGUMENT;
+    if ((const void *)in_dev == (const void *)out_dev) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    hipStream_t s = tk_stream(stream);
+    tk_frame frame(s);
+    const uint64_t n = (uint64_t)rows * cols, runs = (n + PS_RUN - 1) / PS_RUN;
+    fq_t rp;
+    for (int j = 0; j < Fq::N; j++) rp.l[j] = bls12_381_fq_params::KSATM[j];
+    const fq_t conv = Fq::mul(Fq::inv(Fq::to_mont(rp)), Fq::r2());
+    tk_scratch d_tot, d_out;
+    TK_TRY(d_tot.alloc(runs * sizeof(g1_xyzz_t), s));
+    TK_TRY(d_out.alloc(n * sizeof(g1_xyzz_t), s));
+    static hipError_t attr = hipFuncSetAttribute((const void *)k_g1ps_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PS_SCAN * sizeof(g1_xyzz_t)));
+    TK_HIP(attr);
+    hipLaunchKernelGGL(k_g1ps_runs, tk_div_up(runs, 64), 64, 0, s, (const g1_affine_t *)in_dev, n, rows, cols, transposed, bases_form, conv, d_tot.as<g1_xyzz_t>());
+    hipLaunchKernelGGL(k_g1ps_scan, 1, PS_SCAN, PS_SCAN * sizeof(g1_xyzz_t), s, d_tot.as<g1_xyzz_t>(), runs);
+    hipLaunchKernelGGL(k_g1ps_apply, tk_div_up(runs, 64), 64, 0, s, (const g1_affine_t *)in_dev, n, rows, cols, transposed, bases_form, conv,
+                       (const g1_xyzz_t *)d_tot.p, d_out.as<g1_xyzz_t>());
+    hipLaunchKernelGGL(k_g1ntt_store, tk_div_up(n, 128), 128, 0, s, (const g1_xyzz_t *)d_out.p, n, (g1_affine_t *)out_dev);
+    TK_HIP(hipGetLastError());
+    TK_HIP(hipStreamSynchronize(s));
     return TKMK_SUCCESS;
 }
