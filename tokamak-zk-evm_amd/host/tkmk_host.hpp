@@ -748,12 +748,22 @@ class Sigma1 {
     }
     // The Lagrange-basis twin of the grid [0, xs) x [0, ys) of this table: N [L_i(tau_x) L_j(tau_y)] G = the inverse NTT over G1 points of
     // the monomial sub-grid (tkmk_g1_ntt, unscaled), with the same commit table treatment.  commit(P) = (1/N) MSM(evaluations of P, this).
-    Sigma1 lagrange_of(size_t xs, size_t ys) const {
+    DeviceVec<G1Affine> lagrange_points(size_t xs, size_t ys) const {   // plain affine records, row-major xs x ys
         if (xs > rs_x_ || ys > rs_y_ || !is_pow2(xs) || !is_pow2(ys)) throw Error("Lagrange table: the grid must be a power-of-two corner of xy_powers");
         DeviceVec<G1Affine> lam(xs * ys);
-        host_trace("lagrange_of %zu x %zu", xs, ys);
+        host_trace("lagrange_points %zu x %zu", xs, ys);
         check(tkmk_g1_ntt(xy_powers_.ptr(), TKMK_BASES_CONVERTED, (uint32_t)rs_y_, (uint32_t)xs, (uint32_t)ys, TKMK_NTT_INVERSE, lam.ptr(), nullptr), "tkmk_g1_ntt");
-        return Sigma1(std::move(lam), xs, ys, table_c_);
+        return lam;
+    }
+    Sigma1 lagrange_of(size_t xs, size_t ys) const { return Sigma1(lagrange_points(xs, ys), xs, ys, table_c_); }
+    // The table over which a PIECEWISE-CONSTANT evaluation vector (constant along the column-by-column walk of the xs x ys grid except at
+    // a few jumps) commits as an MSM of its jumps: S_j = sum_{j' <= j} Lambda_{walk(j')}, and sum_j r_j Lambda_walk(j) = sum_j (r_j - r_{j+1}) S_j.
+    // `lagrange` = lagrange_points(xs, ys).  The returned table has xs * ys rows in walk order.
+    Sigma1 lagrange_prefix_of(const DeviceVec<G1Affine> &lagrange, size_t xs, size_t ys) const {
+        DeviceVec<G1Affine> pre(xs * ys);
+        host_trace("lagrange_prefix_of %zu x %zu", xs, ys);
+        check(tkmk_g1_prefix_sums(lagrange.ptr(), TKMK_BASES_PLAIN, (uint32_t)xs, (uint32_t)ys, 1, pre.ptr(), nullptr), "tkmk_g1_prefix_sums");
+        return Sigma1(std::move(pre), xs * ys, 1, table_c_);
     }
     // commitments of independent polynomials in one pipelined call
     std::vector<G1Affine> encode_polys(const std::vector<DensePolynomialExt *> &polys) const {

@@ -282,6 +282,10 @@ class Prover {
     // tables set, prove0 commits U, V, W, B as (1/N) MSM(evaluations, Lagrange table) + the blinding terms; the points are the same.
     DeviceVec<ScalarField> u_ev, v_ev, w_ev, b_ev;
     const Sigma1 *lagrange_n = nullptr, *lagrange_mi = nullptr;   // grids n x s_max (u, v, w) and m_I x s_max (b)
+    // prove1's r is a running product of g / f along the column-by-column walk of the m_I x s_max grid, and g / f = 1 wherever the copy
+    // permutation is the identity: r is constant between the few cells the permutation touches.  Over the prefix sums of the Lagrange
+    // points in walk order it commits as an MSM of its jumps (zero scalars elsewhere, which the MSM skips).
+    const Sigma1 *lagrange_mi_prefix = nullptr;
     const LagrangePolys &lagrange_polys() {
         if (!lagrange) lagrange = LagrangePolys::make(m_i, sp.s_max);
         return *lagrange;
@@ -442,6 +446,19 @@ class Prover {
         check(tkmk_vec_suffix_product(tr.ptr(), cells, sfx.ptr(), nullptr), "tkmk_vec_suffix_product");
         check(bls12_381_matrix_transpose(sfx.ptr(), (uint32_t)s_max, (uint32_t)m_i, &c, tr.ptr()), "transpose");
         rXY = Poly::from_rou_evals(tr, m_i, s_max);
+        if (lagrange_mi_prefix && cells >= 2) {
+            // jumps of r along the walk: d_j = r_j - r_{j+1} (d_last = r_last), zero wherever g / f = 1
+            DeviceVec<ScalarField> d(cells);
+            check(bls12_381_vector_sub(sfx.ptr(), sfx.ptr() + 1, cells - 1, &c, d.ptr()), "vector_sub");
+            check(tkmk_memcpy_d2d(d.ptr() + (cells - 1), sfx.ptr() + (cells - 1), sizeof(ScalarField)), "memcpy");
+            G1Affine core = Sigma1::run_jobs({lagrange_mi_prefix->job_evals(d)})[0];
+            const ScalarField inv_cells = fr_inv(fr_mul(fr_from_u32((uint32_t)m_i), fr_from_u32((uint32_t)s_max)));
+            const Mixer &mx = mixer;
+            std::vector<std::pair<ScalarField, G1Affine>> row = {{inv_cells, core},
+                                                                 {mx.rR_X, sigma->xy_at(m_i, 0)}, {fr_neg(mx.rR_X), sigma->xy_at(0, 0)},
+                                                                 {mx.rR_Y, sigma->xy_at(0, s_max)}, {fr_neg(mx.rR_Y), sigma->xy_at(0, 0)}};
+            return Proof1{prover_detail::g1_lincombs({row})[0]};
+        }
         Poly RXY = blinded_R();
         return Proof1{sigma->sigma1.encode_poly(RXY)};
     }

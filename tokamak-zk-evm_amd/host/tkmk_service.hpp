@@ -51,6 +51,7 @@ class ProverContext {
     DeviceVec<ScalarField> s0_identity_, s1_identity_, xp_, yp_;   // w_x^row / w_y^col matrices and the two power tables
     std::shared_ptr<const Prover::LagrangePolys> lagrange_;           // K_last, L_last, K0, KL of prove2 / prove4
     std::unique_ptr<Sigma1> lagrange_n_, lagrange_mi_own_;            // Lagrange-basis commit tables of the n x s_max and m_I x s_max grids
+    std::unique_ptr<Sigma1> lagrange_mi_prefix_;                      // prefix sums of the m_I x s_max one in prove1's walk order
     const Sigma1 *lagrange_mi_ = nullptr;                             // (= lagrange_n_ when n == m_I)
 
     ScalarField *pinned_ = nullptr;                                 // witness staging
@@ -192,11 +193,16 @@ class ProverContext {
             const char *e = getenv("TKMK_PROVER_LAGRANGE");
             const size_t n = c->sp.n, m_i = c->m_i, s_max = c->sp.s_max;
             if (c->sigma->sigma1.table_c() && !(e && atoi(e) == 0) && is_pow2(n) && is_pow2(m_i) && is_pow2(s_max)) {
-                c->lagrange_n_.reset(new Sigma1(c->sigma->sigma1.lagrange_of(n, s_max)));
-                if (m_i == n) c->lagrange_mi_ = c->lagrange_n_.get();
-                else {
-                    c->lagrange_mi_own_.reset(new Sigma1(c->sigma->sigma1.lagrange_of(m_i, s_max)));
+                const Sigma1 &s1 = c->sigma->sigma1;
+                DeviceVec<G1Affine> lam_mi = s1.lagrange_points(m_i, s_max);
+                c->lagrange_mi_prefix_.reset(new Sigma1(s1.lagrange_prefix_of(lam_mi, m_i, s_max)));
+                if (m_i == n) {
+                    c->lagrange_n_.reset(new Sigma1(std::move(lam_mi), m_i, s_max, s1.table_c()));
+                    c->lagrange_mi_ = c->lagrange_n_.get();
+                } else {
+                    c->lagrange_mi_own_.reset(new Sigma1(std::move(lam_mi), m_i, s_max, s1.table_c()));
                     c->lagrange_mi_ = c->lagrange_mi_own_.get();
+                    c->lagrange_n_.reset(new Sigma1(s1.lagrange_of(n, s_max)));
                 }
             }
         }
@@ -334,7 +340,7 @@ class ProverContext {
                   "tkmk_witness_route");
         }
         p->bXY = Poly::from_rou_evals(b_ev, m_i, s_max);
-        if (lagrange_mi_) p->b_ev = std::move(b_ev), p->lagrange_n = lagrange_n_.get(), p->lagrange_mi = lagrange_mi_;
+        if (lagrange_mi_) p->b_ev = std::move(b_ev), p->lagrange_n = lagrange_n_.get(), p->lagrange_mi = lagrange_mi_, p->lagrange_mi_prefix = lagrange_mi_prefix_.get();
         p->rXY = Poly::zero();
         p->a_free_X = gen_a_free_X(a_pub_user, a_pub_block, sp);
         p->t_n = vanishing(n, true), p->t_mi = vanishing(m_i, true), p->t_smax = vanishing(s_max, false);
