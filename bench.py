@@ -170,7 +170,9 @@ def main():
                 "dtype": "u32 limbs (255-bit Fr / 381-bit Fq modular integer arithmetic)",
                 "data": "synthetic",
                 "config": {"workload": "full prove (Prover::init + prove0..prove4 + proof.json) per GPU, BASELINE.json configs[3]: " + files["workload"] +
-                                       "; synthesizer documents read from files every step, CRS + subcircuit library resident in HBM",
+                                       "; synthesizer documents read from files every step; resident in HBM (untimed, open_context_s): the CRS with its commit "
+                                       "table, the Lagrange-basis tables derived from it, the subcircuit library; the proof bytes are those of the reference's "
+                                       "algorithm (DESIGN.md section 4 lists the algebraically equal forms used)",
                            "constraint_slots_per_proof": slots, "r1cs_rows_per_proof": files["r1cs_rows"], "proofs_per_step": world,
                            "host_side": "native C++ (libtkmk_prover.so over the C ABI of libtkmk_hip.so)",
                            "sharding": "independent proofs per GPU" if world > 1 else "none"},
