@@ -77,7 +77,7 @@ def test_production_shape_python_testing_mode_commit_identity_and_equality_with_
     del prover
     want_doc = proofio.format_proof(points, scalars)
     mixer_path = _hex_mixer(mixer, os.path.join(f["tmp"], "mixer.json"))
-    with service.Prover(f["qap"], f["crs"]) as p:
+    with service.Prover(f["qap"], f["crs"], testing=True) as p:
         doc, _ = p.prove(f["synth"], None, testing_mixer_json=mixer_path)
     assert doc == want_doc
 
@@ -95,7 +95,7 @@ def test_configs3_native_proof_verifies_with_pairings_and_commit_identity(gpu):
         out = os.path.join(files["tmp"], "out")
         mixer = random_mixer(random.Random(4096))
         mixer_path = _hex_mixer(mixer, os.path.join(files["tmp"], "mixer.json"))
-        with service.Prover(files["qap"], files["crs"]) as p:
+        with service.Prover(files["qap"], files["crs"], testing=True) as p:
             doc, tm = p.prove(files["synth"], out, testing_mixer_json=mixer_path)
         assert verify_files.verify(files["qap"], files["synth"], files["crs"], out)
         assert not verify_files.verify(files["qap"], files["synth"], files["crs"], out, tamper_public_input=True)

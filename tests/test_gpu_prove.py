@@ -241,7 +241,11 @@ def test_native_prove_binary(gpu, oracle, tmp_path, seed, shape):
         docs = json.load(open(pv_path))
         json.dump([{"variables": d["variables"], "note": "x", "subcircuitId": d["subcircuitId"], "k": 7} for d in docs], open(pv_path, "w"), indent=1)
     cmd = [binary, "--crs", crs_dir, "--synthesizer-stat", inst["synth"], "--output", out_dir, "--subcircuit-library", inst["qap"]]
+    # fixed blinding scalars exist only in the testing-mode build (the reference's compile-time `testing-mode` feature):
+    # the production binary refuses the flag before touching the GPU
     r = subprocess.run(cmd + ["--testing-mixer", mixer_path], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "testing-mode build" in r.stderr
+    r = subprocess.run([binary + "-testing"] + cmd[1:] + ["--testing-mixer", mixer_path], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     assert "NOT zero-knowledge" in r.stderr                       # the testing hook announces itself
     native_points, native_scalars = proofio.recover_proof(json.load(open(os.path.join(out_dir, "proof.json"))))
@@ -359,6 +363,51 @@ def test_native_pipeline_setup_preprocess_prove_then_verify_with_pairings(gpu, o
     assert prove_ref.verify_snark_pairing(points, scalars, ch, sp, crs_g1, pre_points, sigma2, a_eval, kappa2)
     # the same files with one public input changed do not verify
     assert not prove_ref.verify_snark_pairing(points, scalars, ch, sp, crs_g1, pre_points, sigma2, (a_eval + 1) % oracle.R_MOD, kappa2)
+
+
+def test_binaries_under_the_cli_argv(gpu, tmp_path):
+    """tokamak-cli's runtime layout and EXACTLY the argv it sends (packages/cli/src/cli.ts:537-546 `backendOutputArgs`,
+    runtime.ts:465-485,1840-1848): <runtime>/bin/{trusted-setup,preprocess,prove}, resources under <runtime>/resource, no
+    --subcircuit-library anywhere.  The library is found next to the installation (host/tkmk_args.hpp); preprocess.json equals the
+    one made with the flag given, proof.json verifies with pairings from the files alone."""
+    import shutil
+    import subprocess
+    import synth_circuit
+    import verify_files
+    pkg = os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd")
+    rt = tmp_path / "runtime"
+    (rt / "bin").mkdir(parents=True)
+    for name in ("trusted-setup", "preprocess", "prove"):
+        shutil.copy(os.path.join(pkg, "bin", name), rt / "bin" / name)
+    os.symlink(os.path.join(pkg, "libtkmk_hip.so"), rt / "libtkmk_hip.so")          # the binaries' rpath is $ORIGIN/..
+    inst = synth_circuit.build(str(tmp_path / "work"), random.Random(83), s_max=8, n_gate_kinds=2, used_placements=8, bit_fraction=0.4)
+    res = rt / "resource"
+    shutil.copytree(inst["qap"], res / "qap-compiler" / "library")
+    dirs = {k: res / k / "output" for k in ("setup", "synthesizer", "preprocess", "prove")}
+    shutil.copytree(inst["synth"], dirs["synthesizer"])
+    for k in ("setup", "preprocess", "prove"):
+        dirs[k].mkdir(parents=True)
+    env = {k: v for k, v in os.environ.items() if k != "TKMK_SUBCIRCUIT_LIBRARY"}
+    env["HOME"] = str(tmp_path / "home")                                            # no cache of a release binary to fall back on
+
+    def backend_output_args(out):                                                   # cli.ts:537-546, verbatim
+        return ["--crs", str(dirs["setup"]), "--synthesizer-stat", str(dirs["synthesizer"]), "--output", str(out)]
+    for cmd in ([str(rt / "bin" / "trusted-setup"), "--output", str(dirs["setup"]), "--fixed-tau"],
+                [str(rt / "bin" / "preprocess")] + backend_output_args(dirs["preprocess"]),
+                [str(rt / "bin" / "prove")] + backend_output_args(dirs["prove"])):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (cmd, r.stdout, r.stderr)
+    assert os.path.exists(dirs["setup"] / "combined_sigma.rkyv") and os.path.exists(dirs["setup"] / "sigma_preprocess.rkyv")
+    # the same preprocess.json as with the library named explicitly (the round-2 invocation)
+    explicit = tmp_path / "explicit"
+    explicit.mkdir()
+    r = subprocess.run([os.path.join(pkg, "bin", "preprocess")] + backend_output_args(explicit) + ["--subcircuit-library=" + inst["qap"]],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    assert json.load(open(explicit / "preprocess.json")) == json.load(open(dirs["preprocess"] / "preprocess.json"))
+    shutil.copy(dirs["preprocess"] / "preprocess.json", dirs["prove"] / "preprocess.json")
+    assert verify_files.verify(inst["qap"], str(dirs["synthesizer"]), str(dirs["setup"]), str(dirs["prove"]))
+    assert not verify_files.verify(inst["qap"], str(dirs["synthesizer"]), str(dirs["setup"]), str(dirs["prove"]), tamper_public_input=True)
 
 
 def test_prove_cli_files_in_files_out(gpu, oracle, tmp_path):

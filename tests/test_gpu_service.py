@@ -127,7 +127,7 @@ def test_service_equals_python_prover_and_restatement(gpu, oracle, tmp_path, see
     prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, sigma=sigma)
     points, scalars, _, _, _ = run_rounds(prover, binding)
     want_doc = proofio.format_proof(points, scalars)
-    with service.Prover(inst["qap"], crs_dir) as p:
+    with service.Prover(inst["qap"], crs_dir, testing=True) as p:
         assert p.crs_source == "combined_sigma.tkcrs"
         for rep in range(2):                                          # the context is reusable: same inputs, same proof
             doc, tm = p.prove(inst["synth"], out_dir, testing_mixer_json=mixer_path)
@@ -174,7 +174,7 @@ def test_service_with_lagrange_tables_equals_python_prover(gpu, oracle, tmp_path
     monkeypatch.setenv("TKMK_PROVER_TABLE_C", "12")
     for lagrange in ("1", "0"):
         monkeypatch.setenv("TKMK_PROVER_LAGRANGE", lagrange)
-        with service.Prover(inst["qap"], crs_dir) as p:
+        with service.Prover(inst["qap"], crs_dir, testing=True) as p:
             for rep in range(2):
                 doc, _ = p.prove(inst["synth"], out_dir, testing_mixer_json=mixer_path)
                 assert doc == want_doc, (lagrange, rep)
@@ -196,9 +196,9 @@ def test_prove_and_preprocess_from_the_reference_archives(gpu, oracle, tmp_path,
     open(os.path.join(arch_dir, "combined_sigma.rkyv"), "wb").write(rkyv.encode_combined_sigma(sections, rkyv.rows_for(sp), order))
     open(os.path.join(arch_dir, "sigma_preprocess.rkyv"), "wb").write(rkyv.encode_sigma_preprocess(sections["xy_powers"], sections["gamma_inv_o_inst"]))
     mixer_path = _mixer_file(tmp_path, seeded_mixer(61))
-    with service.Prover(inst["qap"], flat_dir) as p:
+    with service.Prover(inst["qap"], flat_dir, testing=True) as p:
         want, _ = p.prove(inst["synth"], None, testing_mixer_json=mixer_path)
-    with service.Prover(inst["qap"], arch_dir) as p:
+    with service.Prover(inst["qap"], arch_dir, testing=True) as p:
         assert p.crs_source == "combined_sigma.rkyv"
         got, _ = p.prove(inst["synth"], None, testing_mixer_json=mixer_path)
     assert got == want
@@ -206,7 +206,7 @@ def test_prove_and_preprocess_from_the_reference_archives(gpu, oracle, tmp_path,
     os.makedirs(out_dir)
     bins = os.path.join(ROOT, "tokamak-zk-evm_amd", "bin")
     args = ["--crs", arch_dir, "--synthesizer-stat", inst["synth"], "--output", out_dir, "--subcircuit-library", inst["qap"]]
-    r = subprocess.run([os.path.join(bins, "prove")] + args + ["--testing-mixer", mixer_path], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([os.path.join(bins, "prove-testing")] + args + ["--testing-mixer", mixer_path], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     assert "combined_sigma.rkyv" in r.stdout and json.load(open(os.path.join(out_dir, "proof.json"))) == want
     r = subprocess.run([os.path.join(bins, "preprocess")] + args, capture_output=True, text=True, timeout=600)

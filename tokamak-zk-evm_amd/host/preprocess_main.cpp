@@ -1,5 +1,7 @@
 // preprocess_main.cpp — native `preprocess` with the reference binary's argument surface (packages/backend/preprocess/src/main.rs:12-63):
-//   preprocess --crs DIR --synthesizer-stat DIR --output DIR --subcircuit-library DIR
+//   preprocess --crs DIR --synthesizer-stat DIR --output DIR [--subcircuit-library DIR]
+// tokamak-cli spawns it with the first three flags only (packages/cli/src/cli.ts:537-546); the library is then resolved the way
+// host/tkmk_args.hpp describes (the reference's release build embeds it: libs/src/subcircuit_library.rs:41-58).
 // reads <lib>/setupParams.json, <synth>/permutation.json, <synth>/instance.json and the reference string <crs>/sigma_preprocess.rkyv
 // (the reference's archive: preprocess/src/main.rs:47-53; host/tkmk_rkyv.hpp) — or <crs>/combined_sigma.tkcrs / combined_sigma.rkyv
 // when that is what the directory holds; writes <out>/preprocess.json.  Exit code 0 on success; any failure prints the reason
@@ -8,28 +10,34 @@
 #include <cstring>
 #include <string>
 
+#include "tkmk_args.hpp"
 #include "tkmk_crs_load.hpp"
 
 using namespace tkmk;
 
+static const char *USAGE =
+    "Usage: preprocess --crs <PATH> --synthesizer-stat <PATH> --output <PATH> [--subcircuit-library <PATH>]\n"
+    "  --crs               CRS output directory containing preprocess setup artifacts\n"
+    "  --synthesizer-stat  Synthesizer output directory containing preprocess inputs\n"
+    "  --output            Output directory for preprocess.json\n"
+    "  --subcircuit-library  Subcircuit library directory produced by the QAP compiler (default: see host/tkmk_args.hpp)\n";
+
 int main(int argc, char **argv) {
-    std::string crs_dir, synth_dir, out_dir, lib_dir;
-    for (int i = 1; i + 1 < argc; i += 2) {
-        std::string k = argv[i], v = argv[i + 1];
-        if (k == "--crs") crs_dir = v;
-        else if (k == "--synthesizer-stat") synth_dir = v;
-        else if (k == "--output") out_dir = v;
-        else if (k == "--subcircuit-library") lib_dir = v;
-        else {
-            fprintf(stderr, "unknown argument %s\n", k.c_str());
-            return 2;
-        }
+    args::Spec spec{{"--crs", "--synthesizer-stat", "--output", "--subcircuit-library"}, {}};
+    args::Parsed a = args::parse(argc, argv, spec);
+    if (a.help) {
+        fputs(USAGE, stdout);
+        return 0;
     }
-    if (crs_dir.empty() || synth_dir.empty() || out_dir.empty() || lib_dir.empty()) {
-        fprintf(stderr, "usage: preprocess --crs DIR --synthesizer-stat DIR --output DIR --subcircuit-library DIR\n");
+    for (const char *need : {"--crs", "--synthesizer-stat", "--output"})
+        if (a.error.empty() && !a.has(need)) a.error = std::string("the following required arguments were not provided: ") + need + " <PATH>";
+    if (!a.error.empty()) {
+        fprintf(stderr, "error: %s\n\n%s", a.error.c_str(), USAGE);
         return 2;
     }
+    const std::string crs_dir = a.get("--crs"), synth_dir = a.get("--synthesizer-stat"), out_dir = a.get("--output");
     try {
+        const std::string lib_dir = args::resolve_subcircuit_library(a);
         int ndev = 0;
         if (tkmk_device_count(&ndev) != TKMK_SUCCESS || ndev < 1) throw Error("no HIP device: the MI355X backend has no CPU fallback");
         check(tkmk_set_device(0), "set_device");   // check_device(): device id 0 (libs/src/utils/mod.rs:88-110)

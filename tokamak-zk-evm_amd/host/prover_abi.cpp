@@ -1,4 +1,6 @@
 // prover_abi.cpp — libtkmk_prover.so: the C ABI of include/tkmk_prover.h over host/tkmk_service.hpp (ProverContext).
+// Built twice: libtkmk_prover.so (production: blinding scalars always from getrandom(), a testing_mixer_json argument is refused)
+// and, with -DTKMK_TESTING_MODE, libtkmk_prover_testing.so for the differential tests (the reference's `testing-mode` feature).
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -48,7 +50,13 @@ TKP_API tkmk_error tkmk_prover_prove(tkmk_prover *p, const char *synthesizer_dir
     if (!p || !synthesizer_dir) return TKMK_ERR_INVALID_POINTER;
     if (proof_json_out) *proof_json_out = nullptr;
     return guarded([&] {
+#ifdef TKMK_TESTING_MODE
         Mixer mixer = testing_mixer_json ? mixer_from_json(json::read_file(testing_mixer_json)) : Mixer::random();
+#else
+        // the reference gates fixed blinding scalars behind the compile-time feature `testing-mode`; so does this library
+        if (testing_mixer_json) throw Error("tkmk_prover_prove: testing_mixer_json needs the testing-mode build (libtkmk_prover_testing.so); this library always draws its blinding scalars from getrandom()");
+        Mixer mixer = Mixer::random();
+#endif
         ProveTiming tm;
         Proof proof = p->ctx->prove(synthesizer_dir, output_dir ? output_dir : "", mixer, &tm);
         if (timing) {

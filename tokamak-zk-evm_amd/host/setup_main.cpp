@@ -1,5 +1,7 @@
 // setup_main.cpp — native trusted setup with the reference binary's argument surface (packages/backend/setup/trusted-setup/src/main.rs:27-46):
-//   trusted-setup --subcircuit-library DIR --output DIR [--fixed-tau] [--format both|rkyv|tkcrs]
+//   trusted-setup --output DIR [--fixed-tau] [--subcircuit-library DIR] [--format both|rkyv|tkcrs]
+// tokamak-cli spawns it as `trusted-setup --output DIR --fixed-tau` (packages/cli/src/runtime.ts:1840-1848); without the flag the
+// library is resolved the way host/tkmk_args.hpp describes.
 // reads <lib>/setupParams.json, <lib>/subcircuitInfo.json, <lib>/r1cs/subcircuit{id}.r1cs; writes the reference's containers
 // <out>/combined_sigma.rkyv and <out>/sigma_preprocess.rkyv (write_final_crs_artifacts, libs/src/iotools/mod.rs:271-300; host/tkmk_rkyv.hpp)
 // and <out>/combined_sigma.tkcrs (the flat TKCRS001 payload the reference derives from its archive: tkmk/crs.py — the fast path of
@@ -12,6 +14,7 @@
 #include <random>
 #include <string>
 
+#include "tkmk_args.hpp"
 #include "tkmk_json.hpp"
 #include "tkmk_setup.hpp"
 
@@ -46,27 +49,30 @@ static G1Affine g1_from_hex(const std::string &x, const std::string &y) {
     return p;
 }
 
+static const char *USAGE =
+    "Usage: trusted-setup --output <PATH> [--fixed-tau] [--subcircuit-library <PATH>] [--format both|rkyv|tkcrs]\n"
+    "  --output            Output directory for combined_sigma.rkyv, sigma_preprocess.rkyv, combined_sigma.tkcrs\n"
+    "  --fixed-tau         Use the hardcoded testing generators and tau\n"
+    "  --subcircuit-library  Subcircuit library directory produced by the QAP compiler (default: see host/tkmk_args.hpp)\n";
+
 int main(int argc, char **argv) {
-    std::string out_dir, lib_dir;
-    bool fixed_tau = false;
-    std::string format = "both";
-    for (int i = 1; i < argc; i++) {
-        std::string k = argv[i];
-        if (k == "--fixed-tau") fixed_tau = true;
-        else if (k == "--format" && i + 1 < argc) format = argv[++i];
-        else if (k == "--output" && i + 1 < argc) out_dir = argv[++i];
-        else if (k == "--subcircuit-library" && i + 1 < argc) lib_dir = argv[++i];
-        else {
-            fprintf(stderr, "unknown argument %s\n", k.c_str());
-            return 2;
-        }
+    args::Spec spec{{"--output", "--subcircuit-library", "--format"}, {"--fixed-tau"}};
+    args::Parsed a = args::parse(argc, argv, spec);
+    if (a.help) {
+        fputs(USAGE, stdout);
+        return 0;
     }
-    if (out_dir.empty() || lib_dir.empty() || (format != "both" && format != "rkyv" && format != "tkcrs")) {
-        fprintf(stderr, "usage: trusted-setup --subcircuit-library DIR --output DIR [--fixed-tau] [--format both|rkyv|tkcrs]\n");
+    if (a.error.empty() && !a.has("--output")) a.error = "the following required arguments were not provided: --output <PATH>";
+    const std::string format = a.get("--format", "both"), out_dir = a.get("--output");
+    if (a.error.empty() && format != "both" && format != "rkyv" && format != "tkcrs") a.error = "invalid value '" + format + "' for '--format'";
+    if (!a.error.empty()) {
+        fprintf(stderr, "error: %s\n\n%s", a.error.c_str(), USAGE);
         return 2;
     }
+    const bool fixed_tau = a.flag("--fixed-tau");
     try {
         double t0 = Prover_now();
+        const std::string lib_dir = args::resolve_subcircuit_library(a);
         int ndev = 0;
         if (tkmk_device_count(&ndev) != TKMK_SUCCESS || ndev < 1) throw Error("no HIP device: the MI355X backend has no CPU fallback");
         check(tkmk_set_device(0), "set_device");

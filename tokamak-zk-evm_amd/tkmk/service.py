@@ -10,7 +10,10 @@ import os
 import tkmk
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libtkmk_prover.so")
-_lib = None
+# the -DTKMK_TESTING_MODE build of the same source: accepts fixed blinding scalars (the reference's `testing-mode` feature);
+# the production library refuses them
+TESTING_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libtkmk_prover_testing.so")
+_libs = {}
 
 # every symbol include/tkmk_prover.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["tkmk_prover_open", "tkmk_prover_prove", "tkmk_prover_close", "tkmk_prover_free_string", "tkmk_prover_last_error",
@@ -28,60 +31,65 @@ class ProveTiming(ctypes.Structure):
         return d
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError("libtkmk_prover.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+def lib(testing=False):
+    path = TESTING_LIB_PATH if testing else LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise ImportError(os.path.basename(path) + " is not built (run __graft_entry__.build()); there is no CPU fallback")
         tkmk.lib()                                  # libtkmk_hip.so first (the prover library links against it)
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.tkmk_prover_last_error.restype = ctypes.c_char_p
-        _lib.tkmk_prover_crs_source.restype = ctypes.c_char_p
-        _lib.tkmk_prover_crs_source.argtypes = [ctypes.c_void_p]
-        _lib.tkmk_prover_free_string.argtypes = [ctypes.c_void_p]
-        _lib.tkmk_prover_close.argtypes = [ctypes.c_void_p]
-    return _lib
+        l = ctypes.CDLL(path)
+        l.tkmk_prover_last_error.restype = ctypes.c_char_p
+        l.tkmk_prover_crs_source.restype = ctypes.c_char_p
+        l.tkmk_prover_crs_source.argtypes = [ctypes.c_void_p]
+        l.tkmk_prover_free_string.argtypes = [ctypes.c_void_p]
+        l.tkmk_prover_close.argtypes = [ctypes.c_void_p]
+        _libs[path] = l
+    return _libs[path]
 
 
 class ProverError(RuntimeError):
-    def __init__(self, code, where):
+    def __init__(self, code, where, testing=False):
         self.code = code
-        super().__init__("%s failed: %s (tkmk_error %d)" % (where, lib().tkmk_prover_last_error().decode(), code))
+        super().__init__("%s failed: %s (tkmk_error %d)" % (where, lib(testing).tkmk_prover_last_error().decode(), code))
 
 
 class Prover:
-    """with Prover(lib_dir, crs_dir) as p: proof, timing = p.prove(synth_dir, out_dir)"""
+    """with Prover(lib_dir, crs_dir) as p: proof, timing = p.prove(synth_dir, out_dir)
+    testing=True binds libtkmk_prover_testing.so, the only build that takes `testing_mixer_json`."""
 
-    def __init__(self, subcircuit_library_dir, crs_dir):
+    def __init__(self, subcircuit_library_dir, crs_dir, testing=False):
         h = ctypes.c_void_p()
-        code = lib().tkmk_prover_open(os.fsencode(subcircuit_library_dir), os.fsencode(crs_dir), ctypes.byref(h))
+        self._h = None
+        self._lib = lib(testing)
+        self.testing = testing
+        code = self._lib.tkmk_prover_open(os.fsencode(subcircuit_library_dir), os.fsencode(crs_dir), ctypes.byref(h))
         if code != 0:
-            raise ProverError(code, "tkmk_prover_open")
+            raise ProverError(code, "tkmk_prover_open", testing)
         self._h = h
 
     @property
     def crs_source(self):
-        return lib().tkmk_prover_crs_source(self._h).decode()
+        return self._lib.tkmk_prover_crs_source(self._h).decode()
 
     def prove(self, synthesizer_dir, output_dir=None, testing_mixer_json=None, want_json=True):
         """-> (proof.json document as a dict or None, timing dict).  testing_mixer_json: a file with fixed blinding scalars, for
         differential tests only"""
         tm = ProveTiming()
         doc = ctypes.c_void_p()
-        code = lib().tkmk_prover_prove(self._h, os.fsencode(synthesizer_dir), None if output_dir is None else os.fsencode(output_dir),
+        code = self._lib.tkmk_prover_prove(self._h, os.fsencode(synthesizer_dir), None if output_dir is None else os.fsencode(output_dir),
                                        None if testing_mixer_json is None else os.fsencode(testing_mixer_json), ctypes.byref(tm),
                                        ctypes.byref(doc) if want_json else None)
         if code != 0:
-            raise ProverError(code, "tkmk_prover_prove")
+            raise ProverError(code, "tkmk_prover_prove", self.testing)
         out = None
         if want_json:
             out = json.loads(ctypes.string_at(doc.value).decode())
-            lib().tkmk_prover_free_string(doc)
+            self._lib.tkmk_prover_free_string(doc)
         return out, tm.as_dict()
 
     def close(self):
         if self._h:
-            lib().tkmk_prover_close(self._h)
+            self._lib.tkmk_prover_close(self._h)
             self._h = None
 
     def __enter__(self):

@@ -155,7 +155,7 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
                "--subcircuit-library", inst["qap"]]
         os.makedirs(os.path.join(tmp, "out"))
         if compare:
-            r = subprocess.run(cmd + ["--testing-mixer", os.path.join(tmp, "mixer.json")], capture_output=True, text=True, timeout=900)
+            r = subprocess.run([binary + "-testing"] + cmd[1:] + ["--testing-mixer", os.path.join(tmp, "mixer.json")], capture_output=True, text=True, timeout=900)
             if r.returncode != 0:
                 raise RuntimeError(r.stderr)
             same = json.load(open(os.path.join(tmp, "out", "proof.json"))) == want

@@ -53,7 +53,7 @@ for seed in range(first, first + cases):
         os.makedirs(os.path.join(d, "out"))
         hx = lambda v: [hx(e) for e in v] if isinstance(v, list) else "0x%x" % v      # noqa: E731
         json.dump({k: hx(v) for k, v in mixer.items()}, open(os.path.join(d, "mixer.json"), "w"))
-        r = subprocess.run([os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "prove"), "--crs", os.path.join(d, "crs"), "--synthesizer-stat", inst["synth"],
+        r = subprocess.run([os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "prove-testing"), "--crs", os.path.join(d, "crs"), "--synthesizer-stat", inst["synth"],
                             "--output", os.path.join(d, "out"), "--subcircuit-library", inst["qap"], "--testing-mixer", os.path.join(d, "mixer.json")],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (seed, shape, r.stderr)
