@@ -187,7 +187,8 @@ tkmk_error tkmk_msm_multi(const tkmk_msm_job *jobs, int n_jobs, const tkmk_msm_c
  * bases_form says what `bases` holds: TKMK_BASES_PLAIN / _MONTGOMERY as in tkmk_msm_config, or TKMK_BASES_CONVERTED = a
  * table that went through bls12_381_msm_convert_bases once (the CRS is fixed for its lifetime; the per-call conversion of
  * bls12_381_msm is then skipped).  Scalars and bases must be on the device (cfg->are_*_on_device = true).
- * base_table_len = number of records behind `bases` (0 = unchecked for strided views; required with base_index, where an
+ * base_table_len = number of records behind `bases` (0 = unchecked for strided views; with base_index it must be > 0 — a job
+ * that leaves it 0 is refused with TKMK_ERR_INVALID_ARGUMENT — and an
  * entry >= base_table_len makes the call return TKMK_ERR_INVALID_ARGUMENT — the read is clamped on the device, never
  * issued out of bounds).  results[j] is bit-identical to bls12_381_msm on the gathered operands. */
 #define TKMK_BASES_PLAIN 0
@@ -537,9 +538,11 @@ tkmk_error tkmk_witness_route(const tkmk_fr *vars_dev, const uint64_t *var_offse
                               uint32_t matrix_stride, tkmk_fr *scalars_out_dev, uint32_t *index_out_dev, uint32_t index_inner,
                               int index_add_slot, tkmk_stream stream);
 /* out_dev[dst_idx_dev[i]] = table_dev[src_idx_dev[i]], i < n; dst indices must be distinct — Permutation::to_poly's redirects
- * s0[row][col] = w_x^X, s1[row][col] = w_y^Y (libs/src/iotools/mod.rs:438-448) */
-tkmk_error tkmk_fr_scatter_table(const tkmk_fr *table_dev, const uint32_t *src_idx_dev, const uint32_t *dst_idx_dev, uint64_t n,
-                                 tkmk_fr *out_dev, tkmk_stream stream);
+ * s0[row][col] = w_x^X, s1[row][col] = w_y^Y (libs/src/iotools/mod.rs:438-448).  table_len / out_len = elements behind the two
+ * arrays: an entry with src >= table_len or dst >= out_len is skipped on the device (never dereferenced) and the call returns
+ * TKMK_ERR_INVALID_ARGUMENT after the valid entries were written (the reference indexes a Vec and panics). */
+tkmk_error tkmk_fr_scatter_table(const tkmk_fr *table_dev, uint64_t table_len, const uint32_t *src_idx_dev, const uint32_t *dst_idx_dev,
+                                 uint64_t n, tkmk_fr *out_dev, uint64_t out_len, tkmk_stream stream);
 /* pinned host memory for staging (HostSlice buffers the reference uploads from are pageable; pinned staging reaches link rate) */
 tkmk_error tkmk_host_malloc(void **ptr, size_t bytes);
 tkmk_error tkmk_host_free(void *ptr);

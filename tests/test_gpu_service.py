@@ -96,6 +96,10 @@ def test_msm_multi_ex_index_lists_and_sizes(gpu, oracle):
     d_bad = tk.DeviceBuffer.from_host(np.array([1, table_pts, 2, 3], np.uint32).view(np.uint8))
     with pytest.raises(tk.TkmkError):
         tk.msm_multi_ex([dict(scalars=d_sc, bases=d_conv, n=4, base_index=d_bad, table_len=table_pts)], bases_form=tk.BASES_CONVERTED)
+    # an index list without the table's length would be gathered unchecked: refused (1 and 4 points: host-resolved and pipeline paths)
+    for n_pts in (1, 4):
+        with pytest.raises(tk.TkmkError):
+            tk.msm_multi_ex([dict(scalars=d_sc, bases=d_conv, n=n_pts, base_index=d_idx, table_len=0)], bases_form=tk.BASES_CONVERTED)
 
 
 # ------------------------------------------------------------------------------------------------ the resident prover

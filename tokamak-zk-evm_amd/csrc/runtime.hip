@@ -518,40 +518,61 @@ void tk_prof::mark(const char *name) {
     (void)hipEventRecord(e, s);
     ev.emplace_back(name, e);
 }
+static void prof_account_and_destroy(std::vector<std::pair<std::string, hipEvent_t>> &list) {
+    for (size_t i = 1; i < list.size(); i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, list[i - 1].second, list[i].second) != hipSuccess) continue;
+        auto &slot = g_prof[list[i].first];
+        slot.first += ms;
+        slot.second += 1;
+    }
+    for (auto &e : list) (void)hipEventDestroy(e.second);
+    list.clear();
+}
+// lists whose last event has completed are accounted without waiting (hipEventQuery); past a cap the oldest are waited for, so
+// a resident process that profiles for hours and never polls holds a bounded number of events
+static constexpr size_t PROF_PENDING_CAP = 256;
+static void prof_drain_locked(bool wait_all) {
+    size_t kept = 0;
+    for (size_t k = 0; k < g_prof_pending.size(); k++) {
+        auto &list = g_prof_pending[k];
+        if (list.empty()) continue;
+        bool must = wait_all || g_prof_pending.size() - k > PROF_PENDING_CAP;
+        if (must) (void)hipEventSynchronize(list.back().second);
+        if (must || hipEventQuery(list.back().second) == hipSuccess) {
+            prof_account_and_destroy(list);
+        } else {
+            if (kept != k) g_prof_pending[kept] = std::move(list);
+            kept++;
+        }
+    }
+    g_prof_pending.resize(kept);
+}
 void tk_prof::finish() {
     if (!on || ev.size() < 2) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_pending.push_back(std::move(ev));
     ev.clear();
-}
-static void prof_drain_locked() {
-    for (auto &list : g_prof_pending) {
-        if (!list.empty()) (void)hipEventSynchronize(list.back().second);
-        for (size_t i = 1; i < list.size(); i++) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, list[i - 1].second, list[i].second) != hipSuccess) continue;
-            auto &slot = g_prof[list[i].first];
-            slot.first += ms;
-            slot.second += 1;
-        }
-        for (auto &e : list) (void)hipEventDestroy(e.second);
-    }
-    g_prof_pending.clear();
+    if (g_prof_pending.size() >= 32) prof_drain_locked(false);
 }
 TK_API tkmk_error tkmk_profile_enable(int on) {
     g_prof_on = on != 0;
+    if (!g_prof_on) {       // switching off accounts what is pending: nothing stays parked in a process that stops profiling
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        prof_drain_locked(true);
+    }
     return TKMK_SUCCESS;
 }
 TK_API tkmk_error tkmk_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    prof_drain_locked();
+    prof_drain_locked(true);
     g_prof.clear();
     return TKMK_SUCCESS;
 }
 TK_API tkmk_error tkmk_profile_get(const char *name, double *sum_ms, int *count) {
     if (!name || !sum_ms || !count) return TKMK_ERR_INVALID_POINTER;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    prof_drain_locked();
+    prof_drain_locked(true);
     auto it = g_prof.find(name);
     *sum_ms = it == g_prof.end() ? 0.0 : it->second.first;
     *count = it == g_prof.end() ? 0 : it->second.second;

@@ -183,21 +183,36 @@ TK_API tkmk_error tkmk_witness_route(const tkmk_fr *vars_dev, const uint64_t *va
 }
 
 // out[dst_idx[i]] = table[src_idx[i]], i < n: distinct dst_idx required (the caller resolves duplicates: last writer wins in the
-// reference's serial loop)
-__global__ __launch_bounds__(256) void k_fr_scatter_table(const fr_t *__restrict__ table, const uint32_t *__restrict__ src_idx,
-                                                         const uint32_t *__restrict__ dst_idx, uint64_t n, fr_t *__restrict__ out) {
+// reference's serial loop).  An index past its array is never dereferenced: the entry is skipped and the call reports it.
+__global__ __launch_bounds__(256) void k_fr_scatter_table(const fr_t *__restrict__ table, uint64_t table_len, const uint32_t *__restrict__ src_idx,
+                                                         const uint32_t *__restrict__ dst_idx, uint64_t n, fr_t *__restrict__ out, uint64_t out_len,
+                                                         uint32_t *__restrict__ bad) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) tk_store(out + dst_idx[i], tk_load(table + src_idx[i]));
+    if (i >= n) return;
+    const uint32_t sidx = src_idx[i], didx = dst_idx[i];
+    if (sidx >= table_len || didx >= out_len) {
+        *bad = 1u;
+        return;
+    }
+    tk_store(out + didx, tk_load(table + sidx));
 }
-TK_API tkmk_error tkmk_fr_scatter_table(const tkmk_fr *table_dev, const uint32_t *src_idx_dev, const uint32_t *dst_idx_dev, uint64_t n,
-                                        tkmk_fr *out_dev, tkmk_stream stream) {
+TK_API tkmk_error tkmk_fr_scatter_table(const tkmk_fr *table_dev, uint64_t table_len, const uint32_t *src_idx_dev, const uint32_t *dst_idx_dev,
+                                        uint64_t n, tkmk_fr *out_dev, uint64_t out_len, tkmk_stream stream) {
     if (n == 0) return TKMK_SUCCESS;
     if (!table_dev || !src_idx_dev || !dst_idx_dev || !out_dev) return TKMK_ERR_INVALID_POINTER;
     TK_TRY(tk_require_device());
     hipStream_t s = tk_stream(stream);
-    hipLaunchKernelGGL(k_fr_scatter_table, tk_div_up(n, 256), 256, 0, s, (const fr_t *)table_dev, src_idx_dev, dst_idx_dev, n, (fr_t *)out_dev);
+    tk_frame frame(s);
+    tk_scratch d_bad;
+    TK_TRY(d_bad.alloc(4, s));
+    TK_HIP(hipMemsetAsync(d_bad.p, 0, 4, s));
+    hipLaunchKernelGGL(k_fr_scatter_table, tk_div_up(n, 256), 256, 0, s, (const fr_t *)table_dev, table_len, src_idx_dev, dst_idx_dev, n,
+                       (fr_t *)out_dev, out_len, d_bad.as<uint32_t>());
     TK_HIP(hipGetLastError());
-    return TKMK_SUCCESS;
+    uint32_t bad = 0;
+    TK_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    TK_HIP(hipStreamSynchronize(s));
+    return bad ? TKMK_ERR_INVALID_ARGUMENT : TKMK_SUCCESS;
 }
 
 // pinned (page-locked) host memory: the parsed witness is written here by the parser threads and uploaded in one copy

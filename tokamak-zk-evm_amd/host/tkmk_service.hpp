@@ -258,8 +258,8 @@ class ProverContext {
             DeviceVec<ScalarField> e0 = s0_identity_.clone(), e1 = s1_identity_.clone();
             if (!dst.empty()) {
                 d_dst = DeviceVec<uint32_t>::from_host(dst), d_x = DeviceVec<uint32_t>::from_host(srcx), d_y = DeviceVec<uint32_t>::from_host(srcy);
-                check(tkmk_fr_scatter_table(xp_.ptr(), d_x.ptr(), d_dst.ptr(), dst.size(), e0.ptr(), nullptr), "tkmk_fr_scatter_table");
-                check(tkmk_fr_scatter_table(yp_.ptr(), d_y.ptr(), d_dst.ptr(), dst.size(), e1.ptr(), nullptr), "tkmk_fr_scatter_table");
+                check(tkmk_fr_scatter_table(xp_.ptr(), xp_.len(), d_x.ptr(), d_dst.ptr(), dst.size(), e0.ptr(), e0.len(), nullptr), "tkmk_fr_scatter_table");
+                check(tkmk_fr_scatter_table(yp_.ptr(), yp_.len(), d_y.ptr(), d_dst.ptr(), dst.size(), e1.ptr(), e1.len(), nullptr), "tkmk_fr_scatter_table");
             }
             p->s0XY = Poly::from_rou_evals(e0, m_i, s_max), p->s1XY = Poly::from_rou_evals(e1, m_i, s_max);
         }

@@ -62,3 +62,91 @@ def permutation_to_poly(perm_raw, m_i, s_max):
         s0[rows, cols] = xb[col("X")]
         s1[rows, cols] = yb[col("Y")]
     return (DensePolynomialExt.from_rou_evals(s0.reshape(-1), m_i, s_max), DensePolynomialExt.from_rou_evals(s1.reshape(-1), m_i, s_max))
+
+
+# ---- thin bindings of the device-side entries of Prover::init (include/tkmk.h "Witness side of the path"); the native host side
+# (host/tkmk_service.hpp) is their product caller, tests/test_gpu_witness.py checks each on its own ----
+import ctypes
+
+
+class R1csLibrary:
+    """tkmk_r1cs_library_create / _eval / _destroy: csr_per_sub = [(A, B, C)] with each matrix a (row_ptr u32, wire u32, coeff bytes)
+    triple (tkmk.r1cs.R1csBinary.csr()); n_rows / n_wires per subcircuit kind"""
+
+    def __init__(self, csr_per_sub, n_rows, n_wires):
+        n_sub = len(csr_per_sub)
+        self._keep = []
+        rp = (ctypes.c_void_p * (3 * n_sub))()
+        wi = (ctypes.c_void_p * (3 * n_sub))()
+        co = (ctypes.c_void_p * (3 * n_sub))()
+        for s, mats in enumerate(csr_per_sub):
+            for m, (ptr, wires, coeff) in enumerate(mats):
+                a = np.ascontiguousarray(ptr, np.uint32)
+                b = np.ascontiguousarray(wires, np.uint32)
+                c = np.ascontiguousarray(coeff, np.uint8)
+                self._keep += [a, b, c]
+                rp[3 * s + m] = a.ctypes.data
+                wi[3 * s + m] = b.ctypes.data if b.size else None
+                co[3 * s + m] = c.ctypes.data if c.size else None
+        nr = np.ascontiguousarray(n_rows, np.uint32)
+        nw = np.ascontiguousarray(n_wires, np.uint32)
+        self._h = ctypes.c_void_p()
+        tkmk._check(tkmk.lib().tkmk_r1cs_library_create(ctypes.c_uint32(n_sub), tkmk._p(nr.view(np.uint8)), tkmk._p(nw.view(np.uint8)), rp, wi, co,
+                                                        ctypes.byref(self._h)), "tkmk_r1cs_library_create")
+
+    def eval(self, vars_dev, placement_ids, placement_var_offsets, n, s_max):
+        """-> (u, v, w) host bytes, n x s_max evaluation matrices, element (row, placement)"""
+        ids = np.ascontiguousarray(placement_ids, np.uint32)
+        off = np.ascontiguousarray(placement_var_offsets, np.uint64)
+        d_ids = tkmk.DeviceBuffer.from_host(ids.view(np.uint8)) if ids.size else None
+        d_off = tkmk.DeviceBuffer.from_host(off.view(np.uint8)) if off.size else None
+        outs = [tkmk.DeviceBuffer(32 * n * s_max) for _ in range(3)]
+        tkmk._check(tkmk.lib().tkmk_r1cs_library_eval(self._h, tkmk._p(vars_dev), None if d_ids is None else tkmk._p(d_ids), None if d_off is None else tkmk._p(d_off),
+                                                      ctypes.c_uint32(ids.size), ctypes.c_uint32(n), ctypes.c_uint32(s_max), tkmk._p(outs[0]), tkmk._p(outs[1]),
+                                                      tkmk._p(outs[2]), None), "tkmk_r1cs_library_eval")
+        tkmk.synchronize()
+        return tuple(o.to_host() for o in outs)
+
+    def close(self):
+        if self._h:
+            tkmk.lib().tkmk_r1cs_library_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def witness_route(vars_dev, var_offsets, slots, list_wire, list_row, matrix_dev=None, matrix_stride=0, want_lists=False, index_inner=1,
+                  index_add_slot=False):
+    """tkmk_witness_route for the placements of one subcircuit kind -> (scalars bytes, index u32) when want_lists, else None"""
+    off = np.ascontiguousarray(var_offsets, np.uint64)
+    sl = np.ascontiguousarray(slots, np.uint32)
+    lw = np.ascontiguousarray(list_wire, np.uint32)
+    lr = np.ascontiguousarray(list_row, np.uint32)
+    dev = lambda a: tkmk.DeviceBuffer.from_host(a.view(np.uint8)) if a.size else None     # noqa: E731
+    d_off, d_sl, d_lw, d_lr = dev(off), dev(sl), dev(lw), dev(lr)
+    total = off.size * lw.size
+    d_sc = tkmk.DeviceBuffer(32 * max(total, 1)) if want_lists else None
+    d_ix = tkmk.DeviceBuffer(4 * max(total, 1)) if want_lists else None
+    ptr = lambda b: None if b is None else tkmk._p(b)                                       # noqa: E731
+    tkmk._check(tkmk.lib().tkmk_witness_route(tkmk._p(vars_dev), ptr(d_off), ptr(d_sl), ctypes.c_uint32(off.size), ptr(d_lw), ptr(d_lr),
+                                              ctypes.c_uint32(lw.size), ptr(matrix_dev), ctypes.c_uint32(matrix_stride), ptr(d_sc), ptr(d_ix),
+                                              ctypes.c_uint32(index_inner), ctypes.c_int(1 if index_add_slot else 0), None), "tkmk_witness_route")
+    tkmk.synchronize()
+    if not want_lists:
+        return None
+    return d_sc.to_host()[:32 * total], d_ix.to_host()[:4 * total].view(np.uint32).copy()
+
+
+def fr_scatter_table(table_dev, table_len, src_idx, dst_idx, out_dev, out_len):
+    """tkmk_fr_scatter_table: out[dst[i]] = table[src[i]]"""
+    src = np.ascontiguousarray(src_idx, np.uint32)
+    dst = np.ascontiguousarray(dst_idx, np.uint32)
+    d_src = tkmk.DeviceBuffer.from_host(src.view(np.uint8)) if src.size else None
+    d_dst = tkmk.DeviceBuffer.from_host(dst.view(np.uint8)) if dst.size else None
+    tkmk._check(tkmk.lib().tkmk_fr_scatter_table(tkmk._p(table_dev), ctypes.c_uint64(table_len), None if d_src is None else tkmk._p(d_src),
+                                                 None if d_dst is None else tkmk._p(d_dst), ctypes.c_uint64(src.size), tkmk._p(out_dev),
+                                                 ctypes.c_uint64(out_len), None), "tkmk_fr_scatter_table")
