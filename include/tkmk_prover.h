@@ -46,6 +46,20 @@ tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const char *crs_
  * a proof made with known blinding scalars is not zero-knowledge. */
 tkmk_error tkmk_prover_prove(tkmk_prover *p, const char *synthesizer_dir, const char *output_dir, const char *testing_mixer_json,
                              tkmk_prove_timing *timing, char **proof_json_out);
+/* The same with two switches for parity work and a record of what every commitment ran over.
+ * flags: TKMK_PROVE_TEST_PARTS        prove4 commits Pi_AX, Pi_AY, Pi_CX, Pi_CY, Pi_B, M_X, N_X one by one and adds the points — the
+ *                                     reference's own commit list (prove/src/lib.rs:2572-3184) — where the default adds the quotient
+ *                                     polynomials first and commits Pi_X, Pi_Y once and N_X not at all (N_X = M_X);
+ *        TKMK_PROVE_COEFFICIENT_BASIS U, V, W, B, R are committed from their coefficients (the reference's encode_poly) although the
+ *                                     context holds the Lagrange-basis tables.
+ * Neither changes a byte of the proof.  commit_boxes_json_out (optional, malloc'ed, tkmk_prover_free_string): a JSON array
+ * [{"name", "x", "y", "basis": "coeff" | "evals"}] in commit order — (x_degree + 1) x (y_degree + 1) of encode_poly
+ * (libs/src/iotools/mod.rs:2055-2060), the `msm=AxB` column of the reference's timing reports
+ * (prove/optimization/timing.local.cpu.current.md "Encode Details"); pinned by tests/golden/encode_dims.json. */
+#define TKMK_PROVE_TEST_PARTS 1
+#define TKMK_PROVE_COEFFICIENT_BASIS 2
+tkmk_error tkmk_prover_prove_ex(tkmk_prover *p, const char *synthesizer_dir, const char *output_dir, const char *testing_mixer_json, int flags,
+                                tkmk_prove_timing *timing, char **proof_json_out, char **commit_boxes_json_out);
 tkmk_error tkmk_prover_close(tkmk_prover *p);
 void tkmk_prover_free_string(char *s);
 const char *tkmk_prover_last_error(void);   /* message of the last failed call on this thread */

@@ -13,7 +13,12 @@ circuit.  The exponent restatement (tests/prove_ref.py) cannot run at these size
     (R1CS satisfaction of u*v = w, Lemma 3 / copy constraints, quotient identities at a random point, zero Ruffini remainders:
     prove/src/lib.rs:916-1019, 1472-1545, 2591-2600, 3087-3096) and three of its commitments equal [P(tau_x, tau_y)]G (the commit
     identity of setup/trusted-setup/src/main.rs:236-246);
-  * the native prover and that Python prover produce the SAME proof.json for the same blinding scalars (production shape)."""
+  * the native prover and that Python prover produce the SAME proof.json for the same blinding scalars (production shape);
+  * the degree box of EVERY commitment of a production-shape proof — (x_degree + 1) x (y_degree + 1), what encode_poly runs its MSM
+    over — equals the one the reference's own timing build recorded for its production run (tests/golden/encode_dims.json, made by
+    tests/golden/make_encode_dims.py from prove/optimization/timing.local.cpu.current.md:241-261): the one output-shaped record the
+    reference holds for this path.  Python prover (reference forms) and native prover (reference commit list: TEST_PARTS +
+    COEFFICIENT_BASIS) both."""
 import json
 import os
 import random
@@ -33,6 +38,30 @@ def production_files(gpu):
     files = prove_bench.stage_files(s_max=256, placements=166)
     yield files
     shutil.rmtree(files["tmp"], ignore_errors=True)
+
+
+# Commit order of the reference's rounds = of tkmk/prove.py (init: lib.rs:1086-1105; prove0 :1600-1782; prove1 :1935-1950; prove2
+# :2240-2268; prove4 :2520-3184)
+COMMIT_ORDER = ["A_free", "U", "V", "W", "Q_AX", "Q_AY", "B", "R", "Q_CX", "Q_CY", "Pi_AX", "Pi_AY", "M_X", "M_Y", "N_X", "N_Y", "Pi_CX", "Pi_CY", "Pi_B"]
+
+
+def _assert_boxes_equal_the_reference_table(boxes, sp, who):
+    """boxes: {name: (x, y)}.  Every one of the 19 rows is compared; nothing is skipped.  ONE row is held to the reference's SOURCE
+    instead of its table, and the reason is stated here rather than hidden: B.  The table says 4825 x 258 (x_degree = l_D = 4824),
+    but the source the table ships with builds B = bXY + rB_X(X) t_{m_I}(X) + rB_Y(Y) t_{s_max}(Y) with
+    low_degree_x_times_vanishing(&rB_X, l_D - l) (prove/src/lib.rs:1746-1754, :48-57) and bXY of X-degree < m_I
+    (libs/src/polynomial_structures/mod.rs:154-160), i.e. x_degree = m_I + 1 = 4097 -> 4098 rows, and the verifier divides by
+    t_{m_I} too (verify-rust/src/lib.rs) — the report was evidently written by an earlier revision whose blinding term had the
+    exponent l_D - 1.  The y side of the same row (258 = s_max + 2) does agree and is asserted.  All other 18 rows match exactly."""
+    golden = json.load(open(os.path.join(HERE, "golden", "encode_dims.json")))
+    assert golden["setup_params"] == {k: sp[k] for k in golden["setup_params"]}, "the fixture circuit is not the production shape"
+    want = {k: (v["x"], v["y"]) for k, v in golden["boxes"].items()}
+    assert sorted(want) == sorted(COMMIT_ORDER) and sorted(boxes) == sorted(COMMIT_ORDER), (who, sorted(boxes))
+    m_i = sp["l_D"] - sp["l"]
+    assert want["B"] == (sp["l_D"] + 1, sp["s_max"] + 2)                  # the table's row, as shipped
+    want["B"] = (m_i + 2, sp["s_max"] + 2)                                # the source's value for the same row (see above)
+    diff = {k: (boxes[k], want[k]) for k in COMMIT_ORDER if tuple(boxes[k]) != want[k]}
+    assert not diff, (who, diff)
 
 
 def _hex_mixer(mixer, path):
@@ -65,8 +94,21 @@ def test_production_shape_python_testing_mode_commit_identity_and_equality_with_
     sigma1, tables = crsmod.load_sigma1(sections, sp)
     singles = {k: np.array(crsmod.single_g1(sections, k)) for k in ("delta", "eta")}
     mixer = random_mixer(random.Random(2024))
-    prover, binding = Prover.init(f["qap"], f["synth"], None, mixer=mixer, testing_mode=True, sigma=(sigma1, tables, singles))   # Lemma 3 etc. inside
-    points, scalars, _, _, _ = run_rounds(prover, binding)                                                                      # the other assertions inside
+    from tkmk.sigma import Sigma1
+    py_boxes, gather = [], Sigma1._gather
+
+    def logged_gather(self, poly):                      # encode_poly's degree box, in commit order
+        job = gather(self, poly)
+        py_boxes.append((poly.x_degree + 1, poly.y_degree + 1))
+        return job
+    Sigma1._gather = logged_gather
+    try:
+        prover, binding = Prover.init(f["qap"], f["synth"], None, mixer=mixer, testing_mode=True, sigma=(sigma1, tables, singles))   # Lemma 3 etc. inside
+        points, scalars, _, _, _ = run_rounds(prover, binding)                                                                      # the other assertions inside
+    finally:
+        Sigma1._gather = gather
+    assert len(py_boxes) == len(COMMIT_ORDER)
+    _assert_boxes_equal_the_reference_table(dict(zip(COMMIT_ORDER, py_boxes)), sp, "python prover (reference forms)")
     g = np.array(crsmod.single_g1(sections, "G"))
     mx = prover.mixer
     for name, poly in (("B", prover.bXY + prover.cache["term_b_zk"]),
@@ -79,7 +121,17 @@ def test_production_shape_python_testing_mode_commit_identity_and_equality_with_
     mixer_path = _hex_mixer(mixer, os.path.join(f["tmp"], "mixer.json"))
     with service.Prover(f["qap"], f["crs"], testing=True) as p:
         doc, _ = p.prove(f["synth"], None, testing_mixer_json=mixer_path)
-    assert doc == want_doc
+        assert doc == want_doc
+        # the native prover on the reference's commit list: the same 19 boxes, the same proof
+        doc_parts, _, boxes = p.prove(f["synth"], None, testing_mixer_json=mixer_path, test_parts=True, coefficient_basis=True, want_boxes=True)
+        assert doc_parts == want_doc
+        assert all(b["basis"] == "coeff" for b in boxes) and [b["name"] for b in boxes if b["name"] == "N_X"] == ["N_X"]
+        _assert_boxes_equal_the_reference_table({b["name"]: (b["x"], b["y"]) for b in boxes}, sp, "native prover (TEST_PARTS | COEFFICIENT_BASIS)")
+        # and what the default path commits instead: U, V, W, B, R over whole evaluation grids, Pi_X / Pi_Y once, N_X not at all
+        _, _, fast = p.prove(f["synth"], None, testing_mixer_json=mixer_path, want_boxes=True)
+        names = [b["name"] for b in fast]
+        assert "N_X" not in names and "Pi_X" in names and "Pi_AX" not in names
+        assert {b["name"] for b in fast if b["basis"] == "evals"} == {"U", "V", "W", "B", "R"}
 
 
 def test_configs3_native_proof_verifies_with_pairings_and_commit_identity(gpu):

@@ -45,10 +45,29 @@ TKP_API tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const ch
     });
 }
 
+static char *dup_string(const std::string &doc) {
+    char *s = (char *)std::malloc(doc.size() + 1);
+    if (!s) throw Error("out of memory");
+    std::memcpy(s, doc.c_str(), doc.size() + 1);
+    return s;
+}
+
 TKP_API tkmk_error tkmk_prover_prove(tkmk_prover *p, const char *synthesizer_dir, const char *output_dir, const char *testing_mixer_json,
                                      tkmk_prove_timing *timing, char **proof_json_out) {
+    return tkmk_prover_prove_ex(p, synthesizer_dir, output_dir, testing_mixer_json, 0, timing, proof_json_out, nullptr);
+}
+
+TKP_API tkmk_error tkmk_prover_prove_ex(tkmk_prover *p, const char *synthesizer_dir, const char *output_dir, const char *testing_mixer_json, int flags,
+                                        tkmk_prove_timing *timing, char **proof_json_out, char **commit_boxes_json_out) {
     if (!p || !synthesizer_dir) return TKMK_ERR_INVALID_POINTER;
+    if (flags & ~(TKMK_PROVE_TEST_PARTS | TKMK_PROVE_COEFFICIENT_BASIS)) return TKMK_ERR_INVALID_ARGUMENT;
     if (proof_json_out) *proof_json_out = nullptr;
+    if (commit_boxes_json_out) *commit_boxes_json_out = nullptr;
+    std::vector<CommitBox> boxes;
+    struct SinkGuard {   // the sink is thread-local and must not outlive `boxes`
+        explicit SinkGuard(std::vector<CommitBox> *s) { commit_box_sink() = s; }
+        ~SinkGuard() { commit_box_sink() = nullptr; }
+    } sink_guard(commit_boxes_json_out ? &boxes : nullptr);
     return guarded([&] {
 #ifdef TKMK_TESTING_MODE
         Mixer mixer = testing_mixer_json ? mixer_from_json(json::read_file(testing_mixer_json)) : Mixer::random();
@@ -58,18 +77,19 @@ TKP_API tkmk_error tkmk_prover_prove(tkmk_prover *p, const char *synthesizer_dir
         Mixer mixer = Mixer::random();
 #endif
         ProveTiming tm;
-        Proof proof = p->ctx->prove(synthesizer_dir, output_dir ? output_dir : "", mixer, &tm);
+        Proof proof = p->ctx->prove(synthesizer_dir, output_dir ? output_dir : "", mixer, &tm, flags);
         if (timing) {
             timing->parse_s = tm.parse, timing->upload_s = tm.upload, timing->build_s = tm.build, timing->binding_s = tm.binding;
             timing->init_s = tm.init, timing->write_s = tm.write, timing->total_s = tm.total;
             for (int k = 0; k < 5; k++) timing->prove_s[k] = tm.prove[k];
         }
-        if (proof_json_out) {
-            std::string doc = proof.to_json();
-            char *s = (char *)std::malloc(doc.size() + 1);
-            if (!s) throw Error("out of memory");
-            std::memcpy(s, doc.c_str(), doc.size() + 1);
-            *proof_json_out = s;
+        if (proof_json_out) *proof_json_out = dup_string(proof.to_json());
+        if (commit_boxes_json_out) {
+            std::string doc = "[";
+            for (size_t k = 0; k < boxes.size(); k++)
+                doc += std::string(k ? ", " : "") + "{\"name\": \"" + boxes[k].name + "\", \"x\": " + std::to_string(boxes[k].x) + ", \"y\": " +
+                       std::to_string(boxes[k].y) + ", \"basis\": \"" + boxes[k].basis + "\"}";
+            *commit_boxes_json_out = dup_string(doc + "]");
         }
     });
 }

@@ -656,6 +656,19 @@ class PolyExpr {
 // per-call base conversion of bls12_381_msm is paid once here; and a commit reads the coefficient box and the matching CRS
 // sub-grid through strided VIEWS (tkmk_msm_multi_ex), where the reference copies both, point by point, before every MSM
 // (iotools/mod.rs:2061-2088).
+// What a commit actually ran over: the (x_degree + 1) x (y_degree + 1) coefficient box of encode_poly (iotools/mod.rs:2055-2060; the
+// `msm=AxB` dims of the reference's timing reports, prove/optimization/timing.local.cpu.current.md "Encode Details"), or the whole
+// evaluation grid of a Lagrange-basis commit.  Off unless a sink is installed (tkmk_prover_prove_ex's commit_boxes_json_out).
+struct CommitBox {
+    std::string name;
+    size_t x, y;
+    const char *basis;   // "coeff" | "evals"
+};
+inline std::vector<CommitBox> *&commit_box_sink() {
+    static thread_local std::vector<CommitBox> *sink = nullptr;
+    return sink;
+}
+
 class Sigma1 {
     DeviceVec<G1Affine> xy_powers_;   // level 0: the table in resident form; with table_c_: levels 1 .. table_factor_ - 1 behind it
     size_t rs_x_, rs_y_;
@@ -689,10 +702,11 @@ class Sigma1 {
     size_t table_len() const { return rs_x_ * rs_y_; }
     uint32_t table_c() const { return table_c_; }
     // the MSM job of one commit: coefficient box x CRS sub-grid, both as views (msm_size 0 for the zero polynomial)
-    tkmk_msm_job_ex job(DensePolynomialExt &poly) const {
+    tkmk_msm_job_ex job(DensePolynomialExt &poly, const char *name = nullptr) const {
         poly.optimize_size();
         size_t tx = (size_t)(poly.x_degree + 1), ty = (size_t)(poly.y_degree + 1);
         if (tx > rs_x_ || ty > rs_y_) throw Error("Insufficient length of sigma.sigma_1.xy_powers");
+        if (auto *sink = commit_box_sink()) sink->push_back({name ? name : "?", tx, ty, "coeff"});
         tkmk_msm_job_ex j{};
         j.scalars = poly.poly.ptr();
         j.bases = xy_powers_.ptr();
@@ -733,11 +747,12 @@ class Sigma1 {
         return out;
     }
     // -> affine commitment
-    G1Affine encode_poly(DensePolynomialExt &poly) const { return run_jobs({job(poly)})[0]; }
+    G1Affine encode_poly(DensePolynomialExt &poly, const char *name = nullptr) const { return run_jobs({job(poly, name)})[0]; }
     // the MSM job of a polynomial given by its rs_x x rs_y EVALUATIONS, over a table that holds the Lagrange-basis points of that grid
     // (lagrange_of below): all rows, no view; zeros and small values cost the MSM next to nothing
-    tkmk_msm_job_ex job_evals(const DeviceVec<ScalarField> &evals) const {
+    tkmk_msm_job_ex job_evals(const DeviceVec<ScalarField> &evals, const char *name = nullptr) const {
         if (evals.len() < rs_x_ * rs_y_) throw Error("evaluation vector shorter than the Lagrange table");
+        if (auto *sink = commit_box_sink()) sink->push_back({name ? name : "?", rs_x_, rs_y_, "evals"});
         tkmk_msm_job_ex j{};
         j.scalars = evals.ptr();
         j.bases = xy_powers_.ptr();
@@ -766,9 +781,9 @@ class Sigma1 {
         return Sigma1(std::move(pre), xs * ys, 1, table_c_);
     }
     // commitments of independent polynomials in one pipelined call
-    std::vector<G1Affine> encode_polys(const std::vector<DensePolynomialExt *> &polys) const {
+    std::vector<G1Affine> encode_polys(const std::vector<DensePolynomialExt *> &polys, const std::vector<const char *> &names = {}) const {
         std::vector<tkmk_msm_job_ex> jobs;
-        for (DensePolynomialExt *p : polys) jobs.push_back(job(*p));
+        for (size_t k = 0; k < polys.size(); k++) jobs.push_back(job(*polys[k], k < names.size() ? names[k] : nullptr));
         return run_jobs(jobs);
     }
 };

@@ -333,7 +333,7 @@ class Prover {
         double t1 = now();
         const Mixer &mx = mixer;
         Binding b;
-        b.A_free = sigma.sigma1.encode_poly(p->a_free_X);
+        b.A_free = sigma.sigma1.encode_poly(p->a_free_X, "A_free");
         b.O_pub_free = encode_O_pub_free(sigma.gamma_inv_o_inst, in.pv, in.infos);
         G1Affine O_mid_core = encode_O_mid_no_zk(sigma.eta_inv_li_o_inter_alpha4_kj, in.pv, in.infos, sp);
         G1Affine O_prv_core = encode_O_prv_no_zk(sigma.delta_inv_li_o_prv, in.pv, in.infos, sp);
@@ -397,7 +397,7 @@ class Prover {
         term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
         if (lagrange_n && lagrange_mi && u_ev.len() && v_ev.len() && w_ev.len() && b_ev.len()) return prove0_from_evaluations(Q_AX_XY, Q_AY_XY);
         Poly BXY = poly_comb({{one, &bXY}, {one, term_b_zk.get()}});
-        auto c = sigma->sigma1.encode_polys({&UXY, &VXY, &WXY, &Q_AX_XY, &Q_AY_XY, &BXY});
+        auto c = sigma->sigma1.encode_polys({&UXY, &VXY, &WXY, &Q_AX_XY, &Q_AY_XY, &BXY}, {"U", "V", "W", "Q_AX", "Q_AY", "B"});
         return Proof0{c[0], c[1], c[2], c[3], c[4], c[5]};
     }
     // U, V, W, B from the evaluations (same points as the coefficient route above):
@@ -406,8 +406,8 @@ class Prover {
         using namespace prover_detail;
         const Mixer &mx = mixer;
         const size_t n = sp.n, s_max = sp.s_max;
-        std::vector<G1Affine> c = Sigma1::run_jobs({lagrange_n->job_evals(u_ev), lagrange_n->job_evals(v_ev), lagrange_n->job_evals(w_ev),
-                                                    sigma->sigma1.job(Q_AX_XY), sigma->sigma1.job(Q_AY_XY), lagrange_mi->job_evals(b_ev)});
+        std::vector<G1Affine> c = Sigma1::run_jobs({lagrange_n->job_evals(u_ev, "U"), lagrange_n->job_evals(v_ev, "V"), lagrange_n->job_evals(w_ev, "W"),
+                                                    sigma->sigma1.job(Q_AX_XY, "Q_AX"), sigma->sigma1.job(Q_AY_XY, "Q_AY"), lagrange_mi->job_evals(b_ev, "B")});
         const ScalarField inv_n = fr_inv(fr_mul(fr_from_u32((uint32_t)n), fr_from_u32((uint32_t)s_max)));
         const ScalarField inv_mi = fr_inv(fr_mul(fr_from_u32((uint32_t)m_i), fr_from_u32((uint32_t)s_max)));
         using Row = std::vector<std::pair<ScalarField, G1Affine>>;
@@ -451,7 +451,7 @@ class Prover {
             DeviceVec<ScalarField> d(cells);
             check(bls12_381_vector_sub(sfx.ptr(), sfx.ptr() + 1, cells - 1, &c, d.ptr()), "vector_sub");
             check(tkmk_memcpy_d2d(d.ptr() + (cells - 1), sfx.ptr() + (cells - 1), sizeof(ScalarField)), "memcpy");
-            G1Affine core = Sigma1::run_jobs({lagrange_mi_prefix->job_evals(d)})[0];
+            G1Affine core = Sigma1::run_jobs({lagrange_mi_prefix->job_evals(d, "R")})[0];
             const ScalarField inv_cells = fr_inv(fr_mul(fr_from_u32((uint32_t)m_i), fr_from_u32((uint32_t)s_max)));
             const Mixer &mx = mixer;
             std::vector<std::pair<ScalarField, G1Affine>> row = {{inv_cells, core},
@@ -460,7 +460,7 @@ class Prover {
             return Proof1{prover_detail::g1_lincombs({row})[0]};
         }
         Poly RXY = blinded_R();
-        return Proof1{sigma->sigma1.encode_poly(RXY)};
+        return Proof1{sigma->sigma1.encode_poly(RXY, "R")};
     }
 
     // prove2 (lib.rs:1958-2270)
@@ -515,7 +515,7 @@ class Prover {
         };
         Poly Q_CX_XY = q_c(q2XY, mx.rB_X, mx.rR_X, true);
         Poly Q_CY_XY = q_c(q3XY, mx.rB_Y, mx.rR_Y, false);
-        auto c = sigma->sigma1.encode_polys({&Q_CX_XY, &Q_CY_XY});
+        auto c = sigma->sigma1.encode_polys({&Q_CX_XY, &Q_CY_XY}, {"Q_CX", "Q_CY"});
         return Proof2{c[0], c[1]};
     }
 
@@ -625,11 +625,14 @@ class Prover {
             // (2^23 coefficients), Pi_CX (2^24) and Pi_B apart and adds the points
             Poly pi_x = Poly::lincomb({Term(one, &std::get<0>(piA)), Term(one, &std::get<0>(piC)), Term(k1_4, &std::get<0>(piB))});
             Poly pi_y = Poly::lincomb({Term(one, &std::get<1>(piA)), Term(one, &std::get<1>(piC))});
-            auto cc = sigma->sigma1.encode_polys({&pi_x, &pi_y, &std::get<0>(M), &std::get<1>(M), &std::get<1>(N)});
+            auto cc = sigma->sigma1.encode_polys({&pi_x, &pi_y, &std::get<0>(M), &std::get<1>(M), &std::get<1>(N)}, {"Pi_X", "Pi_Y", "M_X", "M_Y", "N_Y"});
             return {Proof4{cc[0], cc[1], cc[2], cc[3], cc[2], cc[4]}, Proof4Test{}};
         }
+        // the reference's own commit list (lib.rs:2572-3184); N_X is committed too here so that its box is on record next to M_X's
         auto c = sigma->sigma1.encode_polys({&std::get<0>(piA), &std::get<1>(piA), &std::get<0>(M), &std::get<1>(M), &std::get<1>(N),
-                                             &std::get<0>(piC), &std::get<1>(piC), &std::get<0>(piB)});
+                                             &std::get<0>(piC), &std::get<1>(piC), &std::get<0>(piB), &std::get<0>(N)},
+                                            {"Pi_AX", "Pi_AY", "M_X", "M_Y", "N_Y", "Pi_CX", "Pi_CY", "Pi_B", "N_X"});
+        if (std::memcmp(&c[8], &c[2], sizeof(G1Affine)) != 0) throw Error("prove4: N_X differs from M_X");   // the identity the fast path relies on
         const G1Affine &Pi_AX = c[0], &Pi_AY = c[1], &M_X = c[2], &M_Y = c[3], &N_X = c[2], &N_Y = c[4], &Pi_CX = c[5], &Pi_CY = c[6], &Pi_B0 = c[7];
         auto sums = g1_lincombs({{{k1_4, Pi_B0}, {zero, Pi_B0}, {zero, Pi_B0}},   // encode(pi_B) * kappa1^4 (lib.rs:3180)
                                  {{one, Pi_AX}, {one, Pi_CX}, {k1_4, Pi_B0}},      // lib.rs:3183-3184
@@ -648,7 +651,7 @@ inline std::shared_ptr<const Prover::LagrangePolys> Prover::LagrangePolys::make(
 }
 
 // the round loop of prove/src/main.rs:47-76
-inline Proof run_rounds(Prover &prover, const Binding &binding, std::map<std::string, double> *times = nullptr) {
+inline Proof run_rounds(Prover &prover, const Binding &binding, std::map<std::string, double> *times = nullptr, bool test_parts = false) {
     TranscriptManager manager;
     auto timed = [&](const char *name, const std::function<void()> &fn) {
         double t = Prover::now();
@@ -673,7 +676,7 @@ inline Proof run_rounds(Prover &prover, const Binding &binding, std::map<std::st
     const Proof3 &p3 = proof.proof3;
     manager.add_proof3(p3.V_eval, p3.R_eval, p3.R_omegaX_eval, p3.R_omegaX_omegaY_eval);
     ScalarField kappa1 = manager.get_kappa1();
-    timed("prove4", [&] { proof.proof4 = prover.prove4(p3, thetas, kappa0, cz.first, cz.second, kappa1).first; });
+    timed("prove4", [&] { proof.proof4 = prover.prove4(p3, thetas, kappa0, cz.first, cz.second, kappa1, test_parts).first; });
     return proof;
 }
 

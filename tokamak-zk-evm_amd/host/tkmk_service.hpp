@@ -356,7 +356,7 @@ class ProverContext {
             j.scalars = sc.ptr(), j.bases = table.ptr(), j.msm_size = (int)cnt, j.base_index = ix.ptr(), j.base_table_len = table.len();
             return j;
         };
-        std::vector<G1Affine> cm = Sigma1::run_jobs({sigma->sigma1.job(p->a_free_X), indexed(pub_sc, pub_ix, n_pub, sigma->gamma_inv_o_inst),
+        std::vector<G1Affine> cm = Sigma1::run_jobs({sigma->sigma1.job(p->a_free_X, "A_free"), indexed(pub_sc, pub_ix, n_pub, sigma->gamma_inv_o_inst),
                                                      indexed(mid_sc, mid_ix, n_mid, sigma->eta_inv_li_o_inter_alpha4_kj),
                                                      indexed(prv_sc, prv_ix, n_prv, sigma->delta_inv_li_o_prv)});
         b.A_free = cm[0], b.O_pub_free = cm[1];
@@ -381,12 +381,16 @@ class ProverContext {
     }
 
     // main() of prove/src/main.rs:27-97 after check_device: init, five rounds, <out_dir>/proof.json
-    Proof prove(const std::string &synth_dir, const std::string &out_dir, const Mixer &mixer, ProveTiming *timing = nullptr) {
+    // flags (include/tkmk_prover.h): TKMK_PROVE_TEST_PARTS = the reference's commit list in prove4 (Pi_AX, Pi_CX, Pi_B, M_X, N_X one by
+    // one), TKMK_PROVE_COEFFICIENT_BASIS = U, V, W, B, R committed from coefficients although the Lagrange tables are resident.  Neither
+    // changes a byte of the proof.
+    Proof prove(const std::string &synth_dir, const std::string &out_dir, const Mixer &mixer, ProveTiming *timing = nullptr, int flags = 0) {
         ProveTiming tm;
         const double t0 = Prover::now();
         auto pb = init(synth_dir, mixer, tm);
+        if (flags & 2) pb.first->lagrange_n = pb.first->lagrange_mi = pb.first->lagrange_mi_prefix = nullptr;
         std::map<std::string, double> times;
-        Proof proof = run_rounds(*pb.first, pb.second, &times);
+        Proof proof = run_rounds(*pb.first, pb.second, &times, (flags & 1) != 0);
         int k = 0;
         for (const char *name : {"prove0", "prove1", "prove2", "prove3", "prove4"}) tm.prove[k++] = times[name];
         const double tw = Prover::now();

@@ -14,9 +14,10 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 # the production library refuses them
 TESTING_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libtkmk_prover_testing.so")
 _libs = {}
+TEST_PARTS, COEFFICIENT_BASIS = 1, 2        # TKMK_PROVE_* of include/tkmk_prover.h
 
 # every symbol include/tkmk_prover.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ["tkmk_prover_open", "tkmk_prover_prove", "tkmk_prover_close", "tkmk_prover_free_string", "tkmk_prover_last_error",
+SYMBOLS = ["tkmk_prover_open", "tkmk_prover_prove", "tkmk_prover_prove_ex", "tkmk_prover_close", "tkmk_prover_free_string", "tkmk_prover_last_error",
            "tkmk_prover_crs_source"]
 
 
@@ -71,20 +72,27 @@ class Prover:
     def crs_source(self):
         return self._lib.tkmk_prover_crs_source(self._h).decode()
 
-    def prove(self, synthesizer_dir, output_dir=None, testing_mixer_json=None, want_json=True):
-        """-> (proof.json document as a dict or None, timing dict).  testing_mixer_json: a file with fixed blinding scalars, for
-        differential tests only"""
+    def prove(self, synthesizer_dir, output_dir=None, testing_mixer_json=None, want_json=True, test_parts=False, coefficient_basis=False,
+              want_boxes=False):
+        """-> (proof.json document as a dict or None, timing dict[, commit boxes]).  testing_mixer_json: a file with fixed blinding
+        scalars, for differential tests only.  test_parts / coefficient_basis / want_boxes: tkmk_prover_prove_ex's flags and its record
+        of the (x_degree + 1) x (y_degree + 1) box of every commitment"""
         tm = ProveTiming()
-        doc = ctypes.c_void_p()
-        code = self._lib.tkmk_prover_prove(self._h, os.fsencode(synthesizer_dir), None if output_dir is None else os.fsencode(output_dir),
-                                       None if testing_mixer_json is None else os.fsencode(testing_mixer_json), ctypes.byref(tm),
-                                       ctypes.byref(doc) if want_json else None)
+        doc, boxes = ctypes.c_void_p(), ctypes.c_void_p()
+        flags = (TEST_PARTS if test_parts else 0) | (COEFFICIENT_BASIS if coefficient_basis else 0)
+        code = self._lib.tkmk_prover_prove_ex(self._h, os.fsencode(synthesizer_dir), None if output_dir is None else os.fsencode(output_dir),
+                                              None if testing_mixer_json is None else os.fsencode(testing_mixer_json), ctypes.c_int(flags), ctypes.byref(tm),
+                                              ctypes.byref(doc) if want_json else None, ctypes.byref(boxes) if want_boxes else None)
         if code != 0:
-            raise ProverError(code, "tkmk_prover_prove", self.testing)
+            raise ProverError(code, "tkmk_prover_prove_ex", self.testing)
         out = None
         if want_json:
             out = json.loads(ctypes.string_at(doc.value).decode())
             self._lib.tkmk_prover_free_string(doc)
+        if want_boxes:
+            b = json.loads(ctypes.string_at(boxes.value).decode())
+            self._lib.tkmk_prover_free_string(boxes)
+            return out, tm.as_dict(), b
         return out, tm.as_dict()
 
     def close(self):
