@@ -19,9 +19,14 @@ host/tkmk_service.hpp, C++ over the C ABI of libtkmk_hip.so).  Nothing inside th
               configs[4]'s shape as a secondary: a point-sharded MSM with one RCCL all_gather of the 144-byte partial results.
 value = constraint slots proved per second by the whole job = 2^22 * N * steps / max-over-ranks elapsed.
 
-roofline (same JSON line): the dominant kernel of a proof, k_accumulate_chunks (bucket accumulation of every MSM): HIP events on
-the launch streams over the timed region (tkmk_profile_*: recorded without synchronising), algorithmic bytes = 128 B per committed
-point (scalar + base read once) / summed launch time, against 8 TB/s; `traffic` from the committed
+roofline (same JSON line): the dominant kernel of a proof, k_accumulate_chunks (bucket accumulation of every MSM).  Its launch
+duration is measured live with HIP events recorded on the launch stream (tkmk_profile_*: recorded without synchronising) in a
+SERIALISED PROFILING PASS run right after the timed region: the same proofs with the multi-MSM pipeline narrowed to one internal
+stream (tkmk_msm_set_pipeline_streams(1)), so that no two kernels of a commit batch overlap and a section's time is the kernel's own
+— what `rocprofv3 --kernel-trace --stats` reports per launch (profiles/r03_prove_configs3_kernel_stats_1stream.csv is the same
+command with TKMK_MSM_STREAMS=1).  In the timed region itself three streams time-slice the device: events there bracket queueing
+behind the other streams' kernels, so those figures are kept apart and labelled queue_inclusive.  algorithmic bytes = 128 B per
+committed point (scalar + base read once) / launch time, against 8 TB/s; `traffic` from the committed
 rocprofv3 PMC summary (profiles/traffic.json).  The kernel is integer-VALU bound by construction; valu_roofline gives the
 fraction of the measured v_mad_u64_u32 rate.
 cpu_baseline: the oracle (a C port — the reference's Rust + ICICLE CPU prover cannot be built offline) on a bounded sample: one
@@ -30,6 +35,8 @@ MSM points / NTT elements: a LOWER bound on CPU prove time (polynomial bookkeepi
 
 Secondary objects (N = 1; each records {"error": ...} instead of costing the line if it fails):
   production_2p20  the reference's production shape (s_max = 256, 166 placements; published walls 45.70 s CPU / 21.08 s CUDA)
+  bin_prove_cold   the one-shot binary, process start -> proof.json (device init, CRS load, proof: what prove/src/main.rs:28-84 times
+                   and the reference's published walls include), configs[3] from .tkcrs; production shape from .tkcrs and from .rkyv
   msm_2p24         BASELINE.json configs[1]: 2^24-point G1 MSM, BLS12-381 and (as worded) BN254
   msm_2p28_one_gpu BASELINE.json configs[4]'s operands on one GPU: a rank's 2^25-point shard and the whole 2^28-point MSM
   ntt              BASELINE.json configs[2]: 256 x 2^20 scalar-field NTTs, and the production _biNTT
@@ -56,6 +63,19 @@ ADDS_PER_POINT = 16              # SURVEY.md §8d cfg 2: N * ceil(b/c) at c = 16
 ALG_BYTES_PER_POINT = 32 + 96    # each scalar and base read once
 ALG_BYTES_PER_NTT_ELEMENT = 64   # read once, written once
 SEED = 0x746F6B616D616B00
+SECTIONS = ("convert_bases", "digits", "hist", "scan", "scatter", "prepare", "accumulate", "combine", "reduce_segments", "reduce_windows")
+
+
+def _read_sections(tkmk, proofs):
+    """per-proof section times of the event profiler since the last reset -> ({name: {ms_per_proof, launches_per_proof}}, ntt ms per proof,
+    (accumulate ms, launches))"""
+    sections = {}
+    for name in SECTIONS:
+        ms, cnt = tkmk.profile_get("msm." + name)
+        if cnt:
+            sections[name] = {"ms_per_proof": round(ms / proofs, 3), "launches_per_proof": cnt / proofs}
+    ntt_ms = sum(tkmk.profile_get("ntt.pass%d" % k)[0] for k in range(8))
+    return sections, ntt_ms / proofs, tkmk.profile_get("msm.accumulate")
 
 
 def main():
@@ -71,6 +91,8 @@ def main():
     ap.add_argument("--msm-sharded-logn", type=int, default=25)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --dist-backend gloo)")
+    ap.add_argument("--no-serial-pass", action="store_true", help="skip the serialised profiling pass (for a rocprofv3 run whose kernel "
+                    "statistics should hold the timed region's launches only); the roofline then carries the queue-inclusive event times")
     ap.add_argument("--workdir", default=None, help="where the staged files go (default: a fresh temporary directory)")
     args = ap.parse_args()
 
@@ -140,13 +162,33 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         stats = tkmk.native_stats()
-        sections = {}
-        for name in ("convert_bases", "digits", "hist", "scan", "scatter", "accumulate", "combine", "reduce_segments", "reduce_windows"):
-            ms, cnt = tkmk.profile_get("msm." + name)
-            if cnt:
-                sections[name] = {"ms_per_proof": round(ms / args.steps, 3), "launches_per_proof": cnt / args.steps}
-        ntt_ms = sum(tkmk.profile_get("ntt.pass%d" % k)[0] for k in range(8))
-        acc_ms, acc_cnt = tkmk.profile_get("msm.accumulate")
+        q_sections, q_ntt_ms, (q_acc_ms, q_acc_cnt) = _read_sections(tkmk, args.steps)      # queue-inclusive: three streams in flight
+        # ---- serialised profiling pass (untimed for the headline): the same proofs, one internal stream, every kernel alone ----
+        streams_default = tkmk.msm_get_pipeline_streams()
+        serial = not args.no_serial_pass and streams_default > 1
+        if serial:
+            ser_proofs = max(1, min(args.steps, 3))
+            tkmk.msm_set_pipeline_streams(1)
+            step()
+            tkmk.profile_enable(True)
+            tkmk.profile_reset()
+            tkmk.native_stats_reset()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(ser_proofs):
+                step()
+            barrier()
+            ser_elapsed = time.perf_counter() - t1
+            tkmk.profile_enable(False)
+            ser_stats = tkmk.native_stats()
+            sections, ntt_ms, (acc_ms, acc_cnt) = _read_sections(tkmk, ser_proofs)
+            tkmk.msm_set_pipeline_streams(0)
+        else:       # one stream throughout (TKMK_MSM_STREAMS=1): the timed region is already serialised; or the pass was declined
+            ser_proofs, ser_elapsed, ser_stats = args.steps, elapsed, stats
+            sections, ntt_ms, (acc_ms, acc_cnt) = q_sections, q_ntt_ms, (q_acc_ms, q_acc_cnt)
+        measured_in = ("serialised profiling pass (1 internal stream): launch duration of the kernel running alone" if serial else
+                       "timed region, 1 internal stream: launch duration of the kernel running alone" if streams_default == 1 else
+                       "timed region, %d internal streams: QUEUE-INCLUSIVE event times, not kernel durations" % streams_default)
         prover.close()
 
         msm_sharded = None
@@ -185,26 +227,36 @@ def main():
                 "work_per_proof": {"msm_points": points_per_proof, "msm_calls": stats["msm.calls"] / args.steps,
                                    "ntt_elements": stats["ntt.elements"] / args.steps, "ntt_calls": stats["ntt.calls"] / args.steps,
                                    "algorithmic_bytes": ALG_BYTES_PER_POINT * points_per_proof + ALG_BYTES_PER_NTT_ELEMENT * stats["ntt.elements"] / args.steps},
-                "kernel_ms_per_proof": dict(sections, ntt_passes=round(ntt_ms / args.steps, 3)),
+                # kernel times of one proof, each kernel running alone (serialised pass: one internal stream); their sum is below that
+                # pass's own step time (the rest is polynomial passes that are not bracketed, host phases and launch gaps)
+                "kernel_ms_per_proof": dict(sections, ntt_passes=round(ntt_ms, 3)),
+                "serialised_pass": {"ran": serial, "pipeline_streams": 1 if serial else streams_default, "proofs": ser_proofs, "ms_per_step": ser_elapsed / ser_proofs * 1e3,
+                                    "bracketed_kernels_ms_per_proof": round(sum(v["ms_per_proof"] for v in sections.values()) + ntt_ms, 3),
+                                    "note": "untimed for the headline; same proofs with tkmk_msm_set_pipeline_streams(1): section times are "
+                                            "kernel durations as rocprofv3 reports them (profiles/r03_prove_configs3_kernel_stats_1stream.csv)"},
+                "kernel_ms_per_proof_queue_inclusive": dict(q_sections, ntt_passes=round(q_ntt_ms, 3), pipeline_streams=streams_default,
+                                                            note="HIP events in the timed region: with several streams in flight an event pair "
+                                                                 "also brackets the wait behind the other streams' kernels; NOT kernel time"),
             }
             if acc_cnt:
                 avg_ms = acc_ms / acc_cnt
-                alg = ALG_BYTES_PER_POINT * stats["msm.points"] / acc_cnt      # per launch: one launch per MSM
+                alg = ALG_BYTES_PER_POINT * ser_stats["msm.points"] / acc_cnt      # per launch: one launch per MSM
                 achieved = alg / (avg_ms * 1e-3) / 1e9
                 # bucket additions the accumulate launches actually ran: the library counts the sorted-list lengths on the device (zero
                 # digits of sparse / small scalars drop out, a table commit has 13 windows, a plain one 16)
-                adds = stats.get("msm.bucket_additions", 0)
+                adds = ser_stats.get("msm.bucket_additions", 0)
                 mads = adds * MADS_PER_BUCKET_ADD / (acc_ms * 1e-3)
                 out["roofline"] = {"bound": "hbm", "kernel": "k_accumulate_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles("prove_accumulate_configs3" if args.s_max == 1024 else None),
-                                   "avg_launch_ms": avg_ms, "launches": acc_cnt, "launches_per_proof": acc_cnt / args.steps,
-                                   "algorithmic_bytes_per_launch": alg, "share_of_step": (acc_ms / args.steps) / (elapsed / args.steps * 1e3),
-                                   "note": "integer-VALU bound by construction (SURVEY.md §8d: ~375 int mul-adds per algorithmic byte); launches of "
-                                           "concurrent streams overlap, so the summed launch time can exceed its share of the wall"}
+                                   "avg_launch_ms": avg_ms, "launches": acc_cnt, "launches_per_proof": acc_cnt / ser_proofs,
+                                   "algorithmic_bytes_per_launch": alg, "share_of_step": (acc_ms / ser_proofs) / (elapsed / args.steps * 1e3),
+                                   "measured_in": measured_in,
+                                   "queue_inclusive_avg_launch_ms": (q_acc_ms / q_acc_cnt) if q_acc_cnt else None,
+                                   "note": "integer-VALU bound by construction (SURVEY.md §8d: ~375 int mul-adds per algorithmic byte)"}
                 out["valu_roofline"] = {"kernel": "k_accumulate_chunks", "unit": "v_mad_u64_u32 lane-ops/s", "achieved": mads, "peak": MAD_PEAK_PER_S,
-                                        "frac": mads / MAD_PEAK_PER_S, "bucket_additions_per_proof": adds / args.steps,
-                                        "note": "additions counted by the library (sorted-list lengths) x 3542 multiply-adds each, over the summed launch "
-                                                "times; launches of concurrent streams overlap, so this understates the rate of a launch running alone"}
+                                        "frac": mads / MAD_PEAK_PER_S, "bucket_additions_per_proof": adds / ser_proofs,
+                                        "note": "additions counted by the library (sorted-list lengths) x 3542 multiply-adds each, over the launch "
+                                                "durations of the serialised pass (each launch alone on the device)"}
             out["hbm_roofline_whole_step"] = {"achieved_GBps": out["work_per_proof"]["algorithmic_bytes"] / (elapsed / args.steps) / 1e9, "peak_GBps": HBM_PEAK_GBS}
             if msm_sharded is not None:
                 out["msm_sharded"] = msm_sharded
@@ -220,6 +272,7 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 leg("cpu_baseline", lambda: _cpu_baseline(tkmk, out["work_per_proof"], slots, elapsed / args.steps))
             if world == 1 and not args.no_secondary:
+                leg("bin_prove_cold", lambda: _cold_leg(prove_bench, files, args.s_max))
                 leg("production_2p20", lambda: _production_leg(prove_bench))
                 tkmk.release_scratch()
                 leg("msm_2p24", lambda: _msm_leg(tkmk))
@@ -317,6 +370,53 @@ def _production_leg(prove_bench):
     return {"workload": r["workload"], "constraints_per_s": r["constraint_slots_per_s"], "r1cs_rows_per_s": r["r1cs_rows_per_s"],
             "per_proof_s": r["median"], "init_fraction": r["init_fraction"], "open_context_s": r["open_context_s"],
             "reference_wall_s": {"cpu": 45.70, "cuda": 21.08, "note": "other hardware (BASELINE.md §1)"}}
+
+
+def _cold_runs(files, crs_dir, reps=2):
+    """bin/prove as tokamak-cli would spawn it (plus the library flag: the files live in a scratch directory), wall from fork to exit"""
+    import re
+    import subprocess
+    out_dir = os.path.join(files["tmp"], "out_cold")
+    os.makedirs(out_dir, exist_ok=True)
+    cmd = [os.path.join(ROOT, "tokamak-zk-evm_amd", "bin", "prove"), "--crs", crs_dir, "--synthesizer-stat", files["synth"], "--output", out_dir,
+           "--subcircuit-library", files["qap"]]
+    walls, own = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        walls.append(time.perf_counter() - t0)
+        if r.returncode != 0 or not os.path.exists(os.path.join(out_dir, "proof.json")):
+            raise RuntimeError("bin/prove failed: " + r.stderr[-400:])
+        own = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"^([a-z0-9. ]+?)\s+([0-9.]+) s", r.stdout, re.M)}
+    return {"wall_s": round(min(walls), 3), "walls_s": [round(w, 3) for w in walls], "binary_breakdown_s": own}
+
+
+def _cold_leg(prove_bench, files, s_max):
+    """The like-for-like of the reference's published walls (prove/src/main.rs:28-84: total_start before check_device and the CRS
+    load): ONE process per proof — device initialisation, subcircuit library + CRS from files into HBM (no commit table, no Lagrange
+    tables: they pay only for a resident prover), the proof, proof.json."""
+    import tkmk
+    from tkmk import crs as crsmod
+    from tkmk import rkyv
+    res = {"what": "bin/prove, process start -> exit (fork + device init + CRS load + Prover::init + prove0..4 + proof.json); best of 2 (page cache warm)"}
+    res["configs3_2p22" if s_max == 1024 else "headline_shape"] = dict(_cold_runs(files, files["crs"]), crs="combined_sigma.tkcrs (%.2f GB)" % (files["crs_payload_bytes"] / 1e9))
+    prod = prove_bench.stage_files(s_max=256, placements=166)
+    try:
+        tkmk.release_scratch()
+        res["production_2p20_tkcrs"] = dict(_cold_runs(prod, prod["crs"]), crs="combined_sigma.tkcrs (%.2f GB)" % (prod["crs_payload_bytes"] / 1e9))
+        # the reference's own container for the same reference string (32-bit relative pointers: only below 2 GiB, i.e. not configs[3])
+        arch = os.path.join(prod["tmp"], "crs_rkyv")
+        os.makedirs(arch)
+        sections = crsmod.read_payload(os.path.join(prod["crs"], "combined_sigma.tkcrs"))
+        blob = rkyv.encode_combined_sigma(sections, rkyv.rows_for(prod["setup_params"]), "rustc_size_groups")
+        open(os.path.join(arch, "combined_sigma.rkyv"), "wb").write(blob)
+        del sections
+        res["production_2p20_rkyv"] = dict(_cold_runs(prod, arch), crs="combined_sigma.rkyv (%.2f GB)" % (len(blob) / 1e9))
+        del blob
+        res["reference_wall_s"] = {"cpu": 45.70, "cuda": 21.08, "note": "production shape, other hardware (BASELINE.md §1)"}
+    finally:
+        shutil.rmtree(prod["tmp"], ignore_errors=True)
+    return res
 
 
 def _msm_leg(tkmk):

@@ -556,6 +556,12 @@ tkmk_error tkmk_host_free(void *ptr);
  * tkmk_stats_*: what the library was asked to do since the last reset — "msm.points", "msm.calls", "ntt.elements",
  * "ntt.calls" — for the algorithmic-byte figures of the roofline report (128 B per point, 64 B per element).
  * --------------------------------------------------------------------------------------------- */
+/* Independent MSMs of one tkmk_msm_multi[_ex] call run round-robin on n internal streams (default 3, environment TKMK_MSM_STREAMS;
+ * 1..8; 0 restores the default).  n = 1 issues every kernel of the batch in order on one stream: no two kernels of the batch
+ * overlap, so event-bracketed section times and rocprofv3 kernel durations are those of each kernel running alone — the form
+ * bench.py's profiling pass and profiles/r03_*_1stream.csv use.  Results never depend on n. */
+tkmk_error tkmk_msm_set_pipeline_streams(int n);
+int tkmk_msm_get_pipeline_streams(void);
 tkmk_error tkmk_profile_enable(int on);
 tkmk_error tkmk_profile_reset(void);
 tkmk_error tkmk_profile_get(const char *name, double *sum_ms, int *count);

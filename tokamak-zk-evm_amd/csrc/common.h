@@ -48,6 +48,9 @@ struct tk_frame {
     tk_frame(const tk_frame &) = delete;
     tk_frame &operator=(const tk_frame &) = delete;
 };
+// internal streams the pipelined MSM entries spread independent jobs over (runtime.hip; 1 = every kernel of a batch in issue order
+// on one stream: the serialised form the profiling passes use)
+uint32_t tk_msm_pipeline_streams();
 struct tk_scratch {
     void *p = nullptr;
     tkmk_error alloc(size_t bytes, hipStream_t stream);  // valid until the enclosing tk_frame ends

@@ -579,6 +579,25 @@ TK_API tkmk_error tkmk_profile_get(const char *name, double *sum_ms, int *count)
     return TKMK_SUCCESS;
 }
 
+// ---- pipeline width of the multi-MSM entries ----
+static std::atomic<int> g_msm_streams{0};   // 0 = not resolved yet
+uint32_t tk_msm_pipeline_streams() {
+    int v = g_msm_streams.load(std::memory_order_relaxed);
+    if (v == 0) {
+        const char *e = getenv("TKMK_MSM_STREAMS");
+        v = e ? atoi(e) : 3;
+        v = v < 1 ? 1 : v > 8 ? 8 : v;
+        g_msm_streams.store(v, std::memory_order_relaxed);
+    }
+    return (uint32_t)v;
+}
+TK_API tkmk_error tkmk_msm_set_pipeline_streams(int n) {
+    if (n < 0 || n > 8) return TKMK_ERR_INVALID_ARGUMENT;
+    g_msm_streams.store(n, std::memory_order_relaxed);   // 0: back to TKMK_MSM_STREAMS / the default
+    return TKMK_SUCCESS;
+}
+TK_API int tkmk_msm_get_pipeline_streams(void) { return (int)tk_msm_pipeline_streams(); }
+
 // ---- work counters: what the library was asked to do since the last reset (bench.py turns them into algorithmic bytes:
 // 128 B per MSM point, 64 B per NTT element) ----
 static std::atomic<uint64_t> g_stat[TK_STAT_COUNT];

@@ -94,7 +94,7 @@ SYMBOLS = [
     "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_mul_ones_x", "tkmk_poly_expr_eval", "tkmk_poly_expr_eval_views", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
     "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini", "tkmk_r1cs_eval_rows",
     "tkmk_msm_multi_ex", "bls12_381_msm_convert_bases", "tkmk_r1cs_library_create", "tkmk_r1cs_library_destroy", "tkmk_r1cs_library_eval",
-    "tkmk_witness_route", "tkmk_fr_scatter_table", "tkmk_host_malloc", "tkmk_host_free", "tkmk_stats_reset", "tkmk_stats_get",
+    "tkmk_witness_route", "tkmk_fr_scatter_table", "tkmk_msm_set_pipeline_streams", "tkmk_msm_get_pipeline_streams", "tkmk_host_malloc", "tkmk_host_free", "tkmk_stats_reset", "tkmk_stats_get",
     "bls12_381_ntt_domain_size", "bn254_ntt_domain_size", "tkmk_poly_lincomb", "tkmk_bintt_padded", "tkmk_diag_device_switch", "tkmk_diag_gather_probe",
     "bls12_381_generate_random_affine_points", "bls12_381_generate_scalars", "bls12_381_polynomial_add", "bls12_381_polynomial_clone", "bls12_381_polynomial_coeffs_device_ptr", "bls12_381_polynomial_copy_coeffs", "bls12_381_polynomial_create_from_coefficients", "bls12_381_polynomial_create_from_rou_evaluations", "bls12_381_polynomial_degree", "bls12_381_polynomial_delete", "bls12_381_polynomial_divide", "bls12_381_polynomial_evaluate", "bls12_381_polynomial_get_coeff", "bls12_381_polynomial_multiply", "bls12_381_polynomial_multiply_by_scalar", "bls12_381_polynomial_nof_coeffs", "bls12_381_polynomial_slice", "bls12_381_polynomial_subtract", "bls12_381_vector_accumulate",
 ]
@@ -582,6 +582,15 @@ def profile_enable(on=True):
 
 def profile_reset():
     _check(lib().tkmk_profile_reset(), "tkmk_profile_reset")
+
+
+def msm_set_pipeline_streams(n):
+    """internal streams of the multi-MSM entries (1 = serialised: every kernel alone on the device; 0 = default)"""
+    _check(lib().tkmk_msm_set_pipeline_streams(int(n)), "tkmk_msm_set_pipeline_streams")
+
+
+def msm_get_pipeline_streams():
+    return int(lib().tkmk_msm_get_pipeline_streams())
 
 
 def profile_get(name):
