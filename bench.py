@@ -247,7 +247,7 @@ def main():
                 adds = ser_stats.get("msm.bucket_additions", 0)
                 mads = adds * MADS_PER_BUCKET_ADD / (acc_ms * 1e-3)
                 out["roofline"] = {"bound": "hbm", "kernel": "k_accumulate_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles("prove_accumulate_configs3" if args.s_max == 1024 else None),
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles("prove_accumulate_configs3_r03" if args.s_max == 1024 else None),
                                    "avg_launch_ms": avg_ms, "launches": acc_cnt, "launches_per_proof": acc_cnt / ser_proofs,
                                    "algorithmic_bytes_per_launch": alg, "share_of_step": (acc_ms / ser_proofs) / (elapsed / args.steps * 1e3),
                                    "measured_in": measured_in,

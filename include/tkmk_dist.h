@@ -3,9 +3,16 @@
  * packages/backend/libs/src/utils/mod.rs:88-110), so there is no reference interface to replace; the entry points take the same
  * operands as their single-GPU twins in tkmk.h (bls12_381_msm, tkmk_bintt) plus a communicator.
  *
- * Collectives run through RCCL (xGMI between the GPUs of a node) on DEVICE buffers — nothing is staged through the host around
- * them.  The communicator is bootstrapped like NCCL's: rank 0 calls tkmk_comm_unique_id, hands the 128 bytes to the other ranks
+ * Collectives run through RCCL (xGMI between the GPUs of a node) on DEVICE buffers, and what they deliver is consumed on the device
+ * (the gathered partial results are converted and summed by device kernels; only the final 144-byte result goes to the host).
+ * The communicator is bootstrapped like NCCL's: rank 0 calls tkmk_comm_unique_id, hands the 128 bytes to the other ranks
  * over any channel the host already has (a file, MPI, torch.distributed, a socket), and every rank calls tkmk_comm_init.
+ *
+ * LOOPBACK transport (tkmk_comm_init_loopback): world_size VIRTUAL ranks inside one process on one GPU, one host thread per rank;
+ * all_gather / all_to_all are device-to-device copies between the ranks' buffers behind a rendezvous, and the ranks take turns on the
+ * device.  Same entry points, same code below the transport: this is how the G >= 2 index algebra of every entry (pack / place of
+ * the transpose, gather + sum of partials, empty and infinite partials) runs on a one-GPU box (tests/test_gpu_dist.py).  Not a
+ * production path: it adds no capacity.
  *
  * WHY all_gather + add and not a "bucket-sum reduce": RCCL has no reduction operator over 1152-bit group elements, and reducing
  * the 16 x 2^15 bucket sets of every rank (100 MB per GPU) would move 10^5 times more data than the 144-byte partial RESULTS
@@ -25,16 +32,28 @@ typedef struct tkmk_comm tkmk_comm;
 tkmk_error tkmk_comm_unique_id(uint8_t id[TKMK_COMM_ID_BYTES]);                 /* rank 0 only */
 /* collective over all ranks; uses the calling thread's current device (tkmk_set_device) */
 tkmk_error tkmk_comm_init(const uint8_t id[TKMK_COMM_ID_BYTES], int world_size, int rank, tkmk_comm **out);
+/* world_size communicators (rank r in out_comms[r]) over the loopback transport; each is used from its own host thread, every
+ * collective entry must be called by all of them, each is released with tkmk_comm_destroy */
+tkmk_error tkmk_comm_init_loopback(int world_size, tkmk_comm **out_comms);
+int tkmk_comm_is_loopback(const tkmk_comm *comm);
 tkmk_error tkmk_comm_destroy(tkmk_comm *comm);
 int tkmk_comm_rank(const tkmk_comm *comm);
 int tkmk_comm_size(const tkmk_comm *comm);
 const char *tkmk_dist_last_error(void);
 
 /* One MSM whose points are sharded over the ranks: this rank holds msm_size points (scalars / bases as in bls12_381_msm, host or
- * device per cfg).  Every rank gets the full result (canonical projective, host).  Exchange: ONE ncclAllGather of the 144-byte
- * partial results (device to device), then every rank adds the world_size partials. */
+ * device per cfg; msm_size may be 0 on some ranks).  Every rank gets the full result (canonical projective, host).  Exchange: ONE
+ * ncclAllGather of the 144-byte partial results (device to device), then every rank adds the world_size partials on the device. */
 tkmk_error tkmk_msm_sharded(tkmk_comm *comm, const tkmk_fr *scalars, const tkmk_g1_affine *bases, int msm_size, const tkmk_msm_config *cfg,
                             tkmk_g1_projective *result);
+
+/* A BATCH of MSMs over views of row-sharded resident tables — the commit batch of one prover round:
+ * jobs / cfg / bases_form exactly as tkmk_msm_multi_ex, each rank describing ITS share of every job (its rows of the table, the
+ * matching strided view of the replicated scalars; a job may be empty on a rank).  Every rank runs its share through the pipelined
+ * single-GPU entry, ONE ncclAllGather carries n_jobs x 144 bytes per rank, the world_size partials of every job are summed on the
+ * device; every rank gets all n_jobs results (canonical projective, host). */
+tkmk_error tkmk_msm_multi_ex_sharded(tkmk_comm *comm, const tkmk_msm_job_ex *jobs, int n_jobs, const tkmk_msm_config *cfg, int bases_form,
+                                     tkmk_g1_projective *results);
 
 /* One x_size x y_size bivariate NTT sharded over the ranks (both sizes multiples of world_size).
  *   in : this rank's x-slab, rows [rank * x_size / G, (rank + 1) * x_size / G) of the matrix (element (ix, iy) at ix * y_size + iy): device

@@ -522,6 +522,19 @@ def msm_convert_bases(bases, n=None, points_montgomery=False, out=None):
     return out
 
 
+def msm_job_ex_array(jobs):
+    """the tkmk_msm_job_ex array of a job list (see msm_multi_ex); "scalars" / "bases" may carry a byte offset into their buffer as
+    "scalar_offset" / "base_offset" (a rank's share of a view starts inside the table)"""
+    arr = (MsmJobEx * max(len(jobs), 1))()
+    for k, j in enumerate(jobs):
+        sv, bv, ix = j.get("scalar_view") or (0, 0), j.get("base_view") or (0, 0), j.get("base_index")
+        STATS["msm_points"] += int(j["n"])
+        tc, tf = j.get("table", (0, 0))                  # (c, factor) of a precomputed table (msm_precompute_bases over the whole table)
+        arr[k] = MsmJobEx(_p(j["scalars"]).value + int(j.get("scalar_offset", 0)), _p(j["bases"]).value + int(j.get("base_offset", 0)), int(j["n"]),
+                          sv[0], sv[1], bv[0], bv[1], None if ix is None else _p(ix).value, int(j.get("table_len", 0)), int(tc), int(tf))
+    return arr
+
+
 def msm_multi_ex(jobs, bases_form=BASES_PLAIN, c=0, bitsize=0, stream=None):
     """jobs = [dict(scalars=DeviceBuffer, bases=DeviceBuffer, n=points, scalar_view=(cols, stride) | None,
     base_view=(cols, stride) | None, base_index=DeviceBuffer of u32 | None, table_len=records behind bases)];
@@ -531,13 +544,7 @@ def msm_multi_ex(jobs, bases_form=BASES_PLAIN, c=0, bitsize=0, stream=None):
     cfg.c, cfg.bitsize, cfg.stream_handle = c, bitsize, stream
     if not jobs:
         return np.empty(0, np.uint8)
-    arr = (MsmJobEx * len(jobs))()
-    for k, j in enumerate(jobs):
-        sv, bv, ix = j.get("scalar_view") or (0, 0), j.get("base_view") or (0, 0), j.get("base_index")
-        STATS["msm_points"] += int(j["n"])
-        tc, tf = j.get("table", (0, 0))                  # (c, factor) of a precomputed table (msm_precompute_bases over the whole table)
-        arr[k] = MsmJobEx(_p(j["scalars"]).value, _p(j["bases"]).value, int(j["n"]), sv[0], sv[1], bv[0], bv[1],
-                          None if ix is None else _p(ix).value, int(j.get("table_len", 0)), int(tc), int(tf))
+    arr = msm_job_ex_array(jobs)
     out = np.empty(144 * len(jobs), np.uint8)
     _check(lib().tkmk_msm_multi_ex(arr, len(jobs), ctypes.byref(cfg), int(bases_form), _p(out)), "tkmk_msm_multi_ex")
     return out

@@ -13,8 +13,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 _lib = None
 
 # every symbol include/tkmk_dist.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ["tkmk_comm_unique_id", "tkmk_comm_init", "tkmk_comm_destroy", "tkmk_comm_rank", "tkmk_comm_size", "tkmk_dist_last_error",
-           "tkmk_msm_sharded", "tkmk_bintt_sharded"]
+SYMBOLS = ["tkmk_comm_unique_id", "tkmk_comm_init", "tkmk_comm_init_loopback", "tkmk_comm_is_loopback", "tkmk_comm_destroy", "tkmk_comm_rank",
+           "tkmk_comm_size", "tkmk_dist_last_error", "tkmk_msm_sharded", "tkmk_msm_multi_ex_sharded", "tkmk_bintt_sharded"]
 
 
 def lib():
@@ -28,6 +28,7 @@ def lib():
         _lib.tkmk_comm_destroy.argtypes = [ctypes.c_void_p]
         _lib.tkmk_comm_rank.argtypes = [ctypes.c_void_p]
         _lib.tkmk_comm_size.argtypes = [ctypes.c_void_p]
+        _lib.tkmk_comm_is_loopback.argtypes = [ctypes.c_void_p]
     return _lib
 
 
@@ -49,12 +50,29 @@ def unique_id():
 
 
 class Comm:
-    def __init__(self, comm_id, world, rank):
-        h = ctypes.c_void_p()
-        buf = (ctypes.c_uint8 * 128)(*comm_id)
-        _check(lib().tkmk_comm_init(buf, int(world), int(rank), ctypes.byref(h)), "tkmk_comm_init")
+    def __init__(self, comm_id, world, rank, _handle=None):
+        if _handle is None:
+            h = ctypes.c_void_p()
+            buf = (ctypes.c_uint8 * 128)(*comm_id)
+            _check(lib().tkmk_comm_init(buf, int(world), int(rank), ctypes.byref(h)), "tkmk_comm_init")
+        else:
+            h = _handle
         self._h = h
         self.world, self.rank = world, rank
+
+    @property
+    def handle(self):
+        return self._h
+
+    def msm_multi_ex_sharded(self, jobs, bases_form=tkmk.BASES_CONVERTED, c=0, bitsize=0):
+        """jobs as tkmk.msm_multi_ex, each describing THIS rank's share -> len(jobs) full results (144-byte canonical projective)"""
+        cfg = tkmk.lib().tkmk_msm_default_config()
+        cfg.are_scalars_on_device = cfg.are_points_on_device = True
+        cfg.c, cfg.bitsize = c, bitsize
+        arr = tkmk.msm_job_ex_array(jobs)
+        out = np.empty(144 * len(jobs), np.uint8)
+        _check(lib().tkmk_msm_multi_ex_sharded(self._h, arr, len(jobs), ctypes.byref(cfg), int(bases_form), tkmk._p(out)), "tkmk_msm_multi_ex_sharded")
+        return out
 
     def msm_sharded(self, scalars, bases, n=None):
         """this rank's shard (host arrays or DeviceBuffers) -> the full result, 144-byte canonical projective, on every rank"""
@@ -65,9 +83,9 @@ class Comm:
         _check(lib().tkmk_msm_sharded(self._h, tkmk._p(scalars), tkmk._p(bases), int(n), ctypes.byref(cfg), tkmk._p(out)), "tkmk_msm_sharded")
         return out
 
-    def bintt_sharded(self, slab, x_size, y_size, inverse=False, coset_x=None, coset_y=None):
+    def bintt_sharded(self, slab, x_size, y_size, inverse=False, coset_x=None, coset_y=None, out=None):
         """slab: DeviceBuffer with this rank's x-slab (overwritten) -> DeviceBuffer with this rank's y-slab"""
-        out = tkmk.DeviceBuffer(32 * x_size * (y_size // self.world))
+        out = tkmk.DeviceBuffer(32 * x_size * (y_size // self.world)) if out is None else out
         _check(lib().tkmk_bintt_sharded(self._h, tkmk._p(slab), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size), 1 if inverse else 0,
                                         tkmk._p(coset_x), tkmk._p(coset_y), tkmk._p(out)), "tkmk_bintt_sharded")
         return out
@@ -82,6 +100,36 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def loopback_comms(world):
+    """world communicators over the LOOPBACK transport (virtual ranks in this process on this GPU; test transport): use each from its
+    own thread (run_ranks)"""
+    arr = (ctypes.c_void_p * world)()
+    _check(lib().tkmk_comm_init_loopback(int(world), arr), "tkmk_comm_init_loopback")
+    return [Comm(None, world, r, _handle=ctypes.c_void_p(arr[r])) for r in range(world)]
+
+
+def run_ranks(comms, fn):
+    """fn(comm) on one host thread per virtual rank (ctypes releases the GIL inside the entries) -> [fn's result per rank]; the first
+    exception of any rank is re-raised after all threads have ended"""
+    import threading
+    res, err = [None] * len(comms), [None] * len(comms)
+
+    def body(k):
+        try:
+            res[k] = fn(comms[k])
+        except BaseException as e:      # noqa: BLE001
+            err[k] = e
+    threads = [threading.Thread(target=body, args=(k,)) for k in range(len(comms))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return res
 
 
 def comm_from_torch(dist):
