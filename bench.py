@@ -15,8 +15,10 @@ host/tkmk_service.hpp, C++ over the C ABI of libtkmk_hip.so).  Nothing inside th
               library as device CSR, the NTT domain — loaded once by tkmk_prover_open, untimed (the contract's "inputs already
               resident in HBM"); DESIGN.md section 5 gives the cold-start figures (process start, CRS load) separately
   N > 1     : every rank proves on its own GPU (independent proofs: weak scaling, no data-path collective; rank 0 stages the
-              files, all ranks read them); the collective is only the timing barrier / max.  --msm-sharded adds BASELINE.json
-              configs[4]'s shape as a secondary: a point-sharded MSM with one RCCL all_gather of the 144-byte partial results.
+              files, all ranks read them); the collective is only the timing barrier / max.  --one-proof instead has the N GPUs prove ONE
+              circuit together (include/tkmk_prover.h tkmk_prover_open_sharded: every commit table and commitment sharded by grid row, one
+              RCCL all-gather of 144 bytes per commitment of a round; strong scaling: value = 2^22 / time per proof).  --msm-sharded adds
+              BASELINE.json configs[4]'s shape as a secondary: a point-sharded MSM with one RCCL all_gather of the 144-byte partial results.
 value = constraint slots proved per second by the whole job = 2^22 * N * steps / max-over-ranks elapsed.
 
 roofline (same JSON line): the dominant kernel of a proof, k_accumulate_chunks (bucket accumulation of every MSM).  Its launch
@@ -87,6 +89,8 @@ def main():
     ap.add_argument("--placements", type=int, default=None, help="used placements (default: all s_max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip production_2p20 / msm_2p24 / ntt / msm_2p28_one_gpu")
+    ap.add_argument("--one-proof", action="store_true", help="N > 1: the N GPUs prove ONE circuit together (tkmk_prover_open_sharded: commit tables and "
+                    "commitments sharded by grid row, one all-gather per round) instead of N independent proofs; value = 2^22 / time per proof, scaling strong")
     ap.add_argument("--msm-sharded", action="store_true", help="N > 1: also time the point-sharded MSM of BASELINE.json configs[4] (2^25 points per rank)")
     ap.add_argument("--msm-sharded-logn", type=int, default=25)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
@@ -139,8 +143,16 @@ def main():
     slots = files["constraint_slots"]
     try:
         t = time.perf_counter()
-        prover = service.Prover(files["qap"], files["crs"])            # circuit-static state -> HBM, once
+        one_proof = args.one_proof and world > 1
+        if one_proof and comm_device != "cuda":
+            raise SystemExit("--one-proof runs over libtkmk_dist.so (RCCL): needs --dist-backend nccl")
+        shard_comm = None
+        if one_proof:
+            from tkmk import dist as tkdist
+            shard_comm = tkdist.comm_from_torch(dist)
+        prover = service.Prover(files["qap"], files["crs"], comm=shard_comm)      # circuit-static state -> HBM, once (sharded: 1/N of the tables)
         open_s = time.perf_counter() - t
+        jobs_in_flight = 1 if one_proof else world                                # proofs a step completes
         out_dir = os.path.join(files["tmp"], "out_rank%d" % rank)
 
         def step():
@@ -190,6 +202,8 @@ def main():
                        "timed region, 1 internal stream: launch duration of the kernel running alone" if streams_default == 1 else
                        "timed region, %d internal streams: QUEUE-INCLUSIVE event times, not kernel durations" % streams_default)
         prover.close()
+        if shard_comm is not None:
+            shard_comm.close()
 
         msm_sharded = None
         if dist is not None and world > 1 and args.msm_sharded:         # every rank takes part
@@ -200,14 +214,14 @@ def main():
             points_per_proof = stats["msm.points"] / args.steps
             out = {
                 "metric": "constraints/sec (prove step)",
-                "value": slots * world * args.steps / elapsed,
+                "value": slots * jobs_in_flight * args.steps / elapsed,
                 "unit": "constraints/s",
                 "n_gpus": world,
                 "steps": args.steps,
                 "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True,
-                "scaling": "weak",
+                "scaling": "strong" if one_proof else "weak",
                 "vs_baseline": None,
                 "dtype": "u32 limbs (255-bit Fr / 381-bit Fq modular integer arithmetic)",
                 "data": "synthetic",
@@ -215,10 +229,12 @@ def main():
                                        "; synthesizer documents read from files every step; resident in HBM (untimed, open_context_s): the CRS with its commit "
                                        "table, the Lagrange-basis tables derived from it, the subcircuit library; the proof bytes are those of the reference's "
                                        "algorithm (DESIGN.md section 4 lists the algebraically equal forms used)",
-                           "constraint_slots_per_proof": slots, "r1cs_rows_per_proof": files["r1cs_rows"], "proofs_per_step": world,
+                           "constraint_slots_per_proof": slots, "r1cs_rows_per_proof": files["r1cs_rows"], "proofs_per_step": jobs_in_flight,
                            "host_side": "native C++ (libtkmk_prover.so over the C ABI of libtkmk_hip.so)",
-                           "sharding": "independent proofs per GPU" if world > 1 else "none"},
-                "r1cs_rows_per_s": files["r1cs_rows"] * world * args.steps / elapsed,
+                           "sharding": ("ONE proof over %d GPUs (tkmk_prover_open_sharded): commit tables and commitments sharded by grid row, one "
+                                        "all-gather of 144 B per commitment of a round; inputs, polynomial arithmetic and transcript replicated" % world) if one_proof
+                           else "independent proofs per GPU" if world > 1 else "none"},
+                "r1cs_rows_per_s": files["r1cs_rows"] * jobs_in_flight * args.steps / elapsed,
                 "per_proof_s": {k: round(v, 5) for k, v in med.items()},
                 "init_fraction": round(med["init_s"] / med["total_s"], 3),
                 "open_context_s": round(open_s, 3),

@@ -36,6 +36,13 @@ tkmk_error tkmk_comm_init(const uint8_t id[TKMK_COMM_ID_BYTES], int world_size, 
  * collective entry must be called by all of them, each is released with tkmk_comm_destroy */
 tkmk_error tkmk_comm_init_loopback(int world_size, tkmk_comm **out_comms);
 int tkmk_comm_is_loopback(const tkmk_comm *comm);
+/* Loopback only (a no-op on an RCCL communicator): a caller that issues device work of its own between collective entries — the
+ * sharded prover does — takes the device turn for the whole span (acquire = 1) and hands it back at the end (acquire = 0); the
+ * entries give it up only while they wait for their peers. */
+tkmk_error tkmk_comm_device_turn(tkmk_comm *comm, int acquire);
+/* buf (host, bytes) of rank `root` -> buf of every rank: the few replicated host values a sharded computation must agree on (the
+ * prover's blinding scalars).  One all-gather of `bytes` per rank. */
+tkmk_error tkmk_comm_broadcast_host(tkmk_comm *comm, void *buf, size_t bytes, int root);
 tkmk_error tkmk_comm_destroy(tkmk_comm *comm);
 int tkmk_comm_rank(const tkmk_comm *comm);
 int tkmk_comm_size(const tkmk_comm *comm);

@@ -40,6 +40,19 @@ typedef struct {          /* seconds */
  * configs[3]) so that every large commit costs 13 instead of 16 bucket additions per point; commitments are bit-identical either
  * way.  Environment: TKMK_PROVER_TABLE_C=0 disables the table, 13..20 picks another window width. */
 tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const char *crs_dir, tkmk_prover **out);
+/* ONE proof over the G GPUs of a node (the reference is single-device, so nothing is replaced): rank
+ * r of the communicator `comm` (a tkmk_comm of include/tkmk_dist.h, made by the host: one process per GPU over RCCL) keeps the grid rows
+ * ix = r mod G of every commit table — xy_powers, the Lagrange-basis tables and their prefix sums: resident HBM and the table expansion
+ * at open divide by G — and commits its rows of every polynomial; inputs, polynomial arithmetic and the Fiat-Shamir transcript are
+ * replicated (every rank reads the same files and computes the same challenges), so the only exchange is ONE all-gather of 144 bytes
+ * per commitment of a round (tkmk_msm_multi_ex_sharded) plus one broadcast of rank 0's blinding scalars per proof.  Every rank must
+ * call _open_sharded and then every _prove / _prove_ex with the same arguments; every rank gets the same proof, byte for byte the one
+ * the single-GPU context gives for the same blinding scalars (tests/test_gpu_sharded_prover.py, over the loopback transport).  The
+ * binding tables stay replicated: their index-list commitments are split by list position.  What is NOT divided: the per-proof
+ * polynomial arithmetic (replicated) and, at open, the group transforms behind the Lagrange-basis tables (every rank runs them over
+ * the whole grid and keeps its rows).  libtkmk_dist.so must be in the process (it is: the host made `comm` with it). */
+tkmk_error tkmk_prover_open_sharded(void *comm, const char *subcircuit_library_dir, const char *crs_dir, tkmk_prover **out);
+int tkmk_prover_world_size(const tkmk_prover *p);   /* 1 for a context made by tkmk_prover_open */
 /* output_dir may be NULL (no file is written); proof_json_out (optional) receives a malloc'ed copy of the document, to be
  * released with tkmk_prover_free_string.  testing_mixer_json: NULL in production (blinding scalars from getrandom());
  * a path to a JSON document with fixed blinding scalars makes the proof deterministic — for differential tests only,

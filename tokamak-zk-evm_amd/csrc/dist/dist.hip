@@ -50,6 +50,7 @@ struct tkmk_comm {
     std::shared_ptr<loop_group> loop;     // loopback transport
     int world = 1, rank = 0;
     hipStream_t stream = nullptr;
+    bool turn_held_by_caller = false;     // loopback: the calling thread took the device turn itself (tkmk_comm_device_turn)
 };
 
 static thread_local std::string g_err;
@@ -76,9 +77,15 @@ static tkmk_error fail(tkmk_error code, const std::string &msg) {
 // the calling rank's turn on the device (no-op for RCCL: one process per GPU)
 struct device_turn {
     loop_group *g;
-    bool held = false;
-    explicit device_turn(tkmk_comm *c) : g(c->loop.get()) { take(); }
-    ~device_turn() { give(); }
+    bool held = false, callers = false;
+    explicit device_turn(tkmk_comm *c) : g(c->loop.get()), callers(c->turn_held_by_caller) {
+        if (callers) held = true;   // a caller that spans several entries (the sharded prover) already holds it
+        else take();
+    }
+    ~device_turn() {
+        if (callers) take();   // hand it back the way it came
+        else give();
+    }
     void take() {
         if (g && !held) g->device_turn.lock(), held = true;
     }
@@ -187,6 +194,31 @@ TKD_API tkmk_error tkmk_comm_destroy(tkmk_comm *c) {
 TKD_API int tkmk_comm_rank(const tkmk_comm *c) { return c ? c->rank : -1; }
 TKD_API int tkmk_comm_size(const tkmk_comm *c) { return c ? c->world : 0; }
 TKD_API int tkmk_comm_is_loopback(const tkmk_comm *c) { return c && c->loop ? 1 : 0; }
+TKD_API tkmk_error tkmk_comm_device_turn(tkmk_comm *c, int acquire) {
+    if (!c) return TKMK_ERR_INVALID_POINTER;
+    if (!c->loop) return TKMK_SUCCESS;   // one process per GPU: the device is this rank's alone
+    if (acquire && !c->turn_held_by_caller) c->loop->device_turn.lock(), c->turn_held_by_caller = true;
+    else if (!acquire && c->turn_held_by_caller) c->turn_held_by_caller = false, c->loop->device_turn.unlock();
+    return TKMK_SUCCESS;
+}
+TKD_API tkmk_error tkmk_comm_broadcast_host(tkmk_comm *c, void *buf, size_t bytes, int root) {
+    if (!c || (!buf && bytes)) return TKMK_ERR_INVALID_POINTER;
+    if (root < 0 || root >= c->world) return TKMK_ERR_INVALID_ARGUMENT;
+    if (bytes == 0 || c->world == 1) return TKMK_SUCCESS;
+    device_turn turn(c);
+    void *d_send = nullptr, *d_all = nullptr;
+    TKD_TRY(tkmk_malloc(&d_send, bytes));
+    tkmk_error e = tkmk_malloc(&d_all, bytes * (size_t)c->world);
+    if (e == TKMK_SUCCESS) e = tkmk_memcpy_h2d(d_send, buf, bytes);
+    if (e != TKMK_SUCCESS) {   // cannot take part: fail before a peer waits (allocation of a few bytes)
+        (void)tkmk_free(d_send), (void)tkmk_free(d_all);
+        return fail(e, "tkmk_comm_broadcast_host: staging");
+    }
+    e = transport_all_gather(c, turn, d_send, d_all, bytes);
+    if (e == TKMK_SUCCESS) e = tkmk_memcpy_d2h(buf, (const uint8_t *)d_all + (size_t)root * bytes, bytes);
+    (void)tkmk_free(d_send), (void)tkmk_free(d_all);
+    return e;
+}
 
 // gathered[q][j] (canonical projective partials of rank q, job j: (x, y, 1) or (0, 1, 0)) -> affine[j][q] ((0, 0) = infinity): the
 // operand layout of a batch of n_jobs MSMs with world points each

@@ -1,6 +1,8 @@
 // prover_abi.cpp — libtkmk_prover.so: the C ABI of include/tkmk_prover.h over host/tkmk_service.hpp (ProverContext).
 // Built twice: libtkmk_prover.so (production: blinding scalars always from getrandom(), a testing_mixer_json argument is refused)
 // and, with -DTKMK_TESTING_MODE, libtkmk_prover_testing.so for the differential tests (the reference's `testing-mode` feature).
+#include <dlfcn.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -51,6 +53,53 @@ static char *dup_string(const std::string &doc) {
     std::memcpy(s, doc.c_str(), doc.size() + 1);
     return s;
 }
+
+// the entries of libtkmk_dist.so a sharded context calls, resolved at run time: the prover library itself does not link RCCL, and the
+// host that made the communicator has the library in the process already
+static ShardLink link_for(void *comm) {
+    void *h = dlopen("libtkmk_dist.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) {   // not loaded under that name: next to this library
+        Dl_info info;
+        if (dladdr((void *)&link_for, &info) && info.dli_fname) {
+            std::string dir = info.dli_fname;
+            size_t s = dir.rfind('/');
+            dir = s == std::string::npos ? "." : dir.substr(0, s);
+            h = dlopen((dir + "/libtkmk_dist.so").c_str(), RTLD_NOW);
+        }
+    }
+    if (!h) throw Error("tkmk_prover_open_sharded: libtkmk_dist.so is not loaded and was not found next to libtkmk_prover.so");
+    ShardLink l;
+    l.comm = comm;
+    auto sym = [&](const char *name) {
+        void *p = dlsym(h, name);
+        if (!p) throw Error(std::string("tkmk_prover_open_sharded: libtkmk_dist.so lacks ") + name);
+        return p;
+    };
+    l.multi_ex_sharded = (decltype(l.multi_ex_sharded))sym("tkmk_msm_multi_ex_sharded");
+    l.broadcast_host = (decltype(l.broadcast_host))sym("tkmk_comm_broadcast_host");
+    l.device_turn = (decltype(l.device_turn))sym("tkmk_comm_device_turn");
+    int world = ((int (*)(const void *))sym("tkmk_comm_size"))(comm), rank = ((int (*)(const void *))sym("tkmk_comm_rank"))(comm);
+    if (world < 1 || rank < 0 || rank >= world) throw Error("tkmk_prover_open_sharded: invalid communicator");
+    l.shard = Shard{(uint32_t)world, (uint32_t)rank};
+    return l;
+}
+
+TKP_API tkmk_error tkmk_prover_open_sharded(void *comm, const char *subcircuit_library_dir, const char *crs_dir, tkmk_prover **out) {
+    if (!comm || !subcircuit_library_dir || !crs_dir || !out) return TKMK_ERR_INVALID_POINTER;
+    return guarded([&] {
+        int ndev = 0;
+        if (tkmk_device_count(&ndev) != TKMK_SUCCESS || ndev < 1) throw Error(TKMK_ERR_NO_DEVICE, "tkmk_prover_open_sharded: no HIP device (the MI355X backend has no CPU fallback)");
+        ShardLink link = link_for(comm);
+        std::string crs = crs_dir;
+        std::unique_ptr<tkmk_prover> p(new tkmk_prover());
+        std::unique_ptr<Sigma1> whole;
+        p->ctx = ProverContext::open(
+            subcircuit_library_dir, crs,
+            [&](const SetupParams &sp, std::string &source) { return load_prover_sigma(crs, sp, source, resident_table_c(sp), link.shard, &whole); }, link, &whole);
+        *out = p.release();
+    });
+}
+TKP_API int tkmk_prover_world_size(const tkmk_prover *p) { return p && p->ctx->link ? (int)p->ctx->link.shard.world : 1; }
 
 TKP_API tkmk_error tkmk_prover_prove(tkmk_prover *p, const char *synthesizer_dir, const char *output_dir, const char *testing_mixer_json,
                                      tkmk_prove_timing *timing, char **proof_json_out) {

@@ -47,10 +47,11 @@ inline CrsPayload load_combined_sigma(const std::string &crs_dir, const SetupPar
 }
 // table_c: window width of the precomputed commit table (0 = none): worth its one-time cost (seconds) and memory (13 x xy_powers at
 // 20 bits) only for a prover that stays resident
-inline std::unique_ptr<ProverSigma> load_prover_sigma(const std::string &crs_dir, const SetupParams &sp, std::string &source, uint32_t table_c = 0) {
+inline std::unique_ptr<ProverSigma> load_prover_sigma(const std::string &crs_dir, const SetupParams &sp, std::string &source, uint32_t table_c = 0,
+                                                      Shard shard = Shard{}, std::unique_ptr<Sigma1> *whole_grid = nullptr) {
     CrsPayload crs = load_combined_sigma(crs_dir, sp);
     source = crs.container;
-    return std::unique_ptr<ProverSigma>(new ProverSigma(ProverSigma::from_payload(crs, sp, table_c)));
+    return std::unique_ptr<ProverSigma>(new ProverSigma(ProverSigma::from_payload(crs, sp, table_c, shard, whole_grid)));
 }
 // the resident prover's default: 20-bit windows once xy_powers is large enough for the wide sort to pay (>= 2^20 points);
 // TKMK_PROVER_TABLE_C = 0 turns the table off, 13..20 picks another width

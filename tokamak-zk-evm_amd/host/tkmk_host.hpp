@@ -669,10 +669,31 @@ inline std::vector<CommitBox> *&commit_box_sink() {
     return sink;
 }
 
+// One proof over G GPUs: every commit table is sharded by GRID ROW, interleaved — rank r of G holds
+// the rows ix = r mod G — so that any coefficient box [0, tx) x [0, ty) splits evenly whatever its height, and a rank's share of a
+// commit is again a strided view: rows r, r + G, ... of the (replicated) coefficient matrix against the rank's own rows.
+struct Shard {
+    uint32_t world = 1, rank = 0;
+    size_t rows_of(size_t total) const { return total > rank ? (total - rank + world - 1) / world : 0; }   // |{ix < total : ix = rank mod world}|
+};
+// The commit batches of a sharded prover go through its communicator (tkmk_msm_multi_ex_sharded of libtkmk_dist.so: every rank runs
+// its share, ONE all-gather of 144 bytes per commit, the partials summed on the device).  Installed per host thread by the sharded
+// context for the span of a call; absent, batches run on this GPU alone.
+struct CommitComm {
+    void *comm = nullptr;
+    tkmk_error (*multi_ex_sharded)(void *comm, const tkmk_msm_job_ex *jobs, int n_jobs, const tkmk_msm_config *cfg, int bases_form, tkmk_g1_projective *results) = nullptr;
+};
+inline CommitComm &commit_comm() {
+    static thread_local CommitComm c;
+    return c;
+}
+
 class Sigma1 {
     DeviceVec<G1Affine> xy_powers_;   // level 0: the table in resident form; with table_c_: levels 1 .. table_factor_ - 1 behind it
-    size_t rs_x_, rs_y_;
+    size_t rs_x_, rs_y_;              // the GRID (all ranks' rows); this rank holds local_rows_ of its rs_x_ rows
     uint32_t table_c_ = 0, table_factor_ = 0;
+    Shard shard_;
+    size_t local_rows_;
 
   public:
     // xy_powers[i*rs_y + j] = [tau_x^i tau_y^j]G (plain affine records);  rs_x = max(2n, 2(l_D - l)), rs_y = 2 s_max.
@@ -680,8 +701,12 @@ class Sigma1 {
     // multiples (ICICLE's msm_precompute_bases, MSMConfig::precompute_factor — left at 1 by the reference), so that every large
     // commit runs as ONE bucket set with table_c-bit windows: 13 instead of 16 bucket additions per point at table_c = 20.
     // HBM: windows x the table (2^24 points at table_c = 20: 21 GB of the 288).
-    Sigma1(DeviceVec<G1Affine> &&xy_powers, size_t rs_x_size, size_t rs_y_size, uint32_t table_c = 0) : xy_powers_(std::move(xy_powers)), rs_x_(rs_x_size), rs_y_(rs_y_size) {
-        if (xy_powers_.len() != rs_x_ * rs_y_) throw Error("xy_powers has the wrong length");
+    // shard.world > 1: `xy_powers` holds THIS RANK'S rows only (rows_of_grid(...) below cuts them out of a whole grid), row-major
+    // local_rows x rs_y; rs_x_size stays the grid's height.
+    Sigma1(DeviceVec<G1Affine> &&xy_powers, size_t rs_x_size, size_t rs_y_size, uint32_t table_c = 0, Shard shard = Shard{})
+        : xy_powers_(std::move(xy_powers)), rs_x_(rs_x_size), rs_y_(rs_y_size), shard_(shard), local_rows_(shard.rows_of(rs_x_size)) {
+        if (shard_.world < 1 || shard_.rank >= shard_.world) throw Error("Sigma1: invalid shard");
+        if (xy_powers_.len() != local_rows_ * rs_y_) throw Error("xy_powers has the wrong length");
         tkmk_msm_config cfg = tkmk_msm_default_config();
         cfg.are_points_on_device = cfg.are_results_on_device = true;
         if (table_c >= 2 && xy_powers_.len() >= 2) {
@@ -699,7 +724,19 @@ class Sigma1 {
     }
     size_t rs_x() const { return rs_x_; }
     size_t rs_y() const { return rs_y_; }
-    size_t table_len() const { return rs_x_ * rs_y_; }
+    size_t table_len() const { return local_rows_ * rs_y_; }   // rows of one table level on THIS rank
+    const Shard &shard() const { return shard_; }
+    // rows r, r + G, ... of a row-major rs_x x rs_y grid of points: what rank r of G keeps (one strided copy on the device)
+    static DeviceVec<G1Affine> rows_of_grid(const DeviceVec<G1Affine> &grid, size_t rs_x, size_t rs_y, Shard shard) {
+        if (grid.len() != rs_x * rs_y) throw Error("rows_of_grid: the grid has the wrong length");
+        const size_t rows = shard.rows_of(rs_x);
+        DeviceVec<G1Affine> out(rows * rs_y);
+        if (rows)
+            check(tkmk_memcpy_2d_d2d(out.ptr(), rs_y * sizeof(G1Affine), grid.ptr() + (size_t)shard.rank * rs_y, (size_t)shard.world * rs_y * sizeof(G1Affine),
+                                     rs_y * sizeof(G1Affine), rows),
+                  "rows_of_grid");
+        return out;
+    }
     uint32_t table_c() const { return table_c_; }
     // the MSM job of one commit: coefficient box x CRS sub-grid, both as views (msm_size 0 for the zero polynomial)
     tkmk_msm_job_ex job(DensePolynomialExt &poly, const char *name = nullptr) const {
@@ -707,17 +744,20 @@ class Sigma1 {
         size_t tx = (size_t)(poly.x_degree + 1), ty = (size_t)(poly.y_degree + 1);
         if (tx > rs_x_ || ty > rs_y_) throw Error("Insufficient length of sigma.sigma_1.xy_powers");
         if (auto *sink = commit_box_sink()) sink->push_back({name ? name : "?", tx, ty, "coeff"});
+        // this rank's rows of the box: grid rows r, r + G, ... < tx = rows 0 .. mine - 1 of the local table; the same rows of the
+        // coefficient matrix through a stride of G rows (world = 1: the whole box, stride = the matrix's own)
+        const size_t mine = shard_.rows_of(tx);
         tkmk_msm_job_ex j{};
-        j.scalars = poly.poly.ptr();
+        j.scalars = poly.poly.ptr() + (size_t)shard_.rank * poly.y_size;
         j.bases = xy_powers_.ptr();
-        j.msm_size = (int)(tx * ty);
-        j.scalar_cols = (uint32_t)ty, j.scalar_stride = (uint32_t)poly.y_size;
+        j.msm_size = (int)(mine * ty);
+        j.scalar_cols = (uint32_t)ty, j.scalar_stride = (uint32_t)(poly.y_size * shard_.world);
         j.base_cols = (uint32_t)ty, j.base_stride = (uint32_t)rs_y_;
         j.base_index = nullptr;
         j.base_table_len = table_len();
         // large commits through the expanded table; small ones (the wide windows' two-pass sort needs 2^18 entries, and a 2^19-bucket
         // reduction is not worth paying for a few thousand points) through level 0 with the ordinary multi-window path
-        if (table_c_ && (uint64_t)tx * ty * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
+        if (table_c_ && (uint64_t)mine * ty * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
         return j;
     }
     static G1Affine to_affine(const tkmk_g1_projective &res) {
@@ -741,7 +781,9 @@ class Sigma1 {
             for (auto &j : jobs) d += " " + std::to_string(j.msm_size) + (j.table_c ? "t" : "") + (j.base_index ? "i" : "");
             host_trace("commit batch of %zu:%s", jobs.size(), d.c_str());
         }
-        check(tkmk_msm_multi_ex(jobs.data(), (int)jobs.size(), &cfg, TKMK_BASES_CONVERTED, res.data()), "tkmk_msm_multi_ex");
+        const CommitComm &cc = commit_comm();
+        if (cc.comm) check(cc.multi_ex_sharded(cc.comm, jobs.data(), (int)jobs.size(), &cfg, TKMK_BASES_CONVERTED, res.data()), "tkmk_msm_multi_ex_sharded");
+        else check(tkmk_msm_multi_ex(jobs.data(), (int)jobs.size(), &cfg, TKMK_BASES_CONVERTED, res.data()), "tkmk_msm_multi_ex");
         std::vector<G1Affine> out;
         for (auto &r : res) out.push_back(to_affine(r));
         return out;
@@ -754,16 +796,18 @@ class Sigma1 {
         if (evals.len() < rs_x_ * rs_y_) throw Error("evaluation vector shorter than the Lagrange table");
         if (auto *sink = commit_box_sink()) sink->push_back({name ? name : "?", rs_x_, rs_y_, "evals"});
         tkmk_msm_job_ex j{};
-        j.scalars = evals.ptr();
+        j.scalars = evals.ptr() + (size_t)shard_.rank * rs_y_;
         j.bases = xy_powers_.ptr();
-        j.msm_size = (int)(rs_x_ * rs_y_);
+        j.msm_size = (int)(local_rows_ * rs_y_);
+        if (shard_.world > 1) j.scalar_cols = (uint32_t)rs_y_, j.scalar_stride = (uint32_t)(rs_y_ * shard_.world);   // grid rows r, r + G, ...; the local table is contiguous
         j.base_table_len = table_len();
-        if (table_c_ && (uint64_t)rs_x_ * rs_y_ * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
+        if (table_c_ && (uint64_t)local_rows_ * rs_y_ * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
         return j;
     }
     // The Lagrange-basis twin of the grid [0, xs) x [0, ys) of this table: N [L_i(tau_x) L_j(tau_y)] G = the inverse NTT over G1 points of
     // the monomial sub-grid (tkmk_g1_ntt, unscaled), with the same commit table treatment.  commit(P) = (1/N) MSM(evaluations of P, this).
     DeviceVec<G1Affine> lagrange_points(size_t xs, size_t ys) const {   // plain affine records, row-major xs x ys
+        if (shard_.world != 1) throw Error("Lagrange table: needs the whole grid (build it before the rows are sharded)");
         if (xs > rs_x_ || ys > rs_y_ || !is_pow2(xs) || !is_pow2(ys)) throw Error("Lagrange table: the grid must be a power-of-two corner of xy_powers");
         DeviceVec<G1Affine> lam(xs * ys);
         host_trace("lagrange_points %zu x %zu", xs, ys);
@@ -774,11 +818,14 @@ class Sigma1 {
     // The table over which a PIECEWISE-CONSTANT evaluation vector (constant along the column-by-column walk of the xs x ys grid except at
     // a few jumps) commits as an MSM of its jumps: S_j = sum_{j' <= j} Lambda_{walk(j')}, and sum_j r_j Lambda_walk(j) = sum_j (r_j - r_{j+1}) S_j.
     // `lagrange` = lagrange_points(xs, ys).  The returned table has xs * ys rows in walk order.
-    Sigma1 lagrange_prefix_of(const DeviceVec<G1Affine> &lagrange, size_t xs, size_t ys) const {
+    static DeviceVec<G1Affine> lagrange_prefix_points(const DeviceVec<G1Affine> &lagrange, size_t xs, size_t ys) {   // plain affine, xs * ys rows in walk order
         DeviceVec<G1Affine> pre(xs * ys);
         host_trace("lagrange_prefix_of %zu x %zu", xs, ys);
         check(tkmk_g1_prefix_sums(lagrange.ptr(), TKMK_BASES_PLAIN, (uint32_t)xs, (uint32_t)ys, 1, pre.ptr(), nullptr), "tkmk_g1_prefix_sums");
-        return Sigma1(std::move(pre), xs * ys, 1, table_c_);
+        return pre;
+    }
+    Sigma1 lagrange_prefix_of(const DeviceVec<G1Affine> &lagrange, size_t xs, size_t ys) const {
+        return Sigma1(lagrange_prefix_points(lagrange, xs, ys), xs * ys, 1, table_c_);
     }
     // commitments of independent polynomials in one pipelined call
     std::vector<G1Affine> encode_polys(const std::vector<DensePolynomialExt *> &polys, const std::vector<const char *> &names = {}) const {

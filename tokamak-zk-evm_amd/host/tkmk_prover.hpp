@@ -131,7 +131,12 @@ struct ProverSigma {
         if (it == xy_edge.end()) throw Error("xy_powers entry not kept on the host");
         return it->second;
     }
-    static ProverSigma from_payload(const CrsPayload &crs, const SetupParams &sp, uint32_t table_c = 0) {
+    // shard.world > 1 (one proof over several GPUs): sigma1 keeps this rank's grid rows only; *whole_grid (when asked for) receives the
+    // whole xy_powers grid in the MSM's resident form without a table — what the Lagrange-basis tables are derived from before they
+    // are sharded the same way; the caller drops it afterwards.  The binding tables are replicated (their index-list commits are split
+    // by list position instead).
+    static ProverSigma from_payload(const CrsPayload &crs, const SetupParams &sp, uint32_t table_c = 0, Shard shard = Shard{},
+                                    std::unique_ptr<Sigma1> *whole_grid = nullptr) {
         size_t m_i = sp.l_D - sp.l, rs_x = std::max(2 * sp.n, 2 * m_i), rs_y = 2 * sp.s_max;
         auto want = [&](CrsPayload::Section s, size_t pts, const char *name) {
             if (crs.points(s) != pts) throw Error(std::string("CRS section ") + name + " does not match setupParams.json");
@@ -155,7 +160,10 @@ struct ProverSigma {
                 for (size_t k = 0; k < 4; k++)
                     if (base + k < rs_y) edge[{0, base + k}] = xy[base + k];
         }
-        ProverSigma out{Sigma1(crs.upload(CrsPayload::XyPowers), rs_x, rs_y, table_c),
+        DeviceVec<G1Affine> grid = crs.upload(CrsPayload::XyPowers);
+        DeviceVec<G1Affine> mine = shard.world > 1 ? Sigma1::rows_of_grid(grid, rs_x, rs_y, shard) : DeviceVec<G1Affine>();
+        if (shard.world > 1 && whole_grid) whole_grid->reset(new Sigma1(std::move(grid), rs_x, rs_y, 0));
+        ProverSigma out{Sigma1(shard.world > 1 ? std::move(mine) : std::move(grid), rs_x, rs_y, table_c, shard),
                            crs.upload(CrsPayload::GammaInvOInst),
                            crs.upload(CrsPayload::EtaInvLiOInterAlpha4Kj),
                            crs.upload(CrsPayload::DeltaInvLiOPrv),

@@ -22,6 +22,35 @@
 
 namespace tkmk {
 
+// One proof over the G GPUs of a node (include/tkmk_prover.h tkmk_prover_open_sharded; no reference
+// counterpart: the reference is single-device).  Every rank runs the whole prover — inputs, polynomial arithmetic and transcript are
+// replicated, so the Fiat-Shamir chain stays in lock step without a message — but holds only its 1/G of every commit table and
+// commits only its share of every polynomial; the shares meet in ONE all-gather of 144 bytes per commitment of a round.  The
+// entries of libtkmk_dist.so arrive as function pointers (the prover library does not link RCCL).
+struct ShardLink {
+    void *comm = nullptr;
+    Shard shard;
+    tkmk_error (*multi_ex_sharded)(void *, const tkmk_msm_job_ex *, int, const tkmk_msm_config *, int, tkmk_g1_projective *) = nullptr;
+    tkmk_error (*broadcast_host)(void *, void *, size_t, int) = nullptr;
+    tkmk_error (*device_turn)(void *, int) = nullptr;
+    explicit operator bool() const { return comm != nullptr; }
+};
+// for the span of one call on a sharded context: the commit batches of this thread go through the communicator, and (loopback
+// transport only) this virtual rank holds the device turn except while it waits for its peers
+struct ShardSpan {
+    const ShardLink &link;
+    explicit ShardSpan(const ShardLink &l) : link(l) {
+        if (!link) return;
+        check(link.device_turn(link.comm, 1), "tkmk_comm_device_turn");
+        commit_comm() = CommitComm{link.comm, link.multi_ex_sharded};
+    }
+    ~ShardSpan() {
+        if (!link) return;
+        commit_comm() = CommitComm{};
+        (void)link.device_turn(link.comm, 0);
+    }
+};
+
 struct ProveTiming {   // seconds
     double parse = 0, upload = 0, build = 0, binding = 0, init = 0;
     double prove[5] = {0, 0, 0, 0, 0};
@@ -38,6 +67,7 @@ class ProverContext {
     unsigned threads = 1;
     std::unique_ptr<ProverSigma> sigma;   // tables in the MSM's resident form (see open)
     std::string crs_source;               // which container the CRS came from
+    ShardLink link;                       // set: this context is rank link.shard.rank of a sharded prover
 
   private:
     tkmk_r1cs_library *lib_ = nullptr;
@@ -99,9 +129,14 @@ class ProverContext {
 
     // circuit-static state: subcircuit library from <lib_dir>, reference string from <crs_dir> (combined_sigma.rkyv, or the flat
     // combined_sigma.tkcrs payload when only that is present)
+    // link set: load_sigma returns this rank's rows of xy_powers and hands the whole grid over through *whole_grid (dropped here once
+    // the Lagrange-basis tables are cut from it)
     static std::unique_ptr<ProverContext> open(const std::string &lib_dir, const std::string &crs_dir,
-                                               const std::function<std::unique_ptr<ProverSigma>(const SetupParams &, std::string &)> &load_sigma) {
+                                               const std::function<std::unique_ptr<ProverSigma>(const SetupParams &, std::string &)> &load_sigma,
+                                               const ShardLink &link = ShardLink{}, std::unique_ptr<Sigma1> *whole_grid = nullptr) {
         std::unique_ptr<ProverContext> c(new ProverContext());
+        c->link = link;
+        ShardSpan span(c->link);
         c->lib_dir = lib_dir;
         c->threads = host_threads();
         c->sp = read_setup_params(lib_dir);
@@ -194,17 +229,42 @@ class ProverContext {
             const size_t n = c->sp.n, m_i = c->m_i, s_max = c->sp.s_max;
             if (c->sigma->sigma1.table_c() && !(e && atoi(e) == 0) && is_pow2(n) && is_pow2(m_i) && is_pow2(s_max)) {
                 const Sigma1 &s1 = c->sigma->sigma1;
-                DeviceVec<G1Affine> lam_mi = s1.lagrange_points(m_i, s_max);
-                c->lagrange_mi_prefix_.reset(new Sigma1(s1.lagrange_prefix_of(lam_mi, m_i, s_max)));
-                if (m_i == n) {
-                    c->lagrange_n_.reset(new Sigma1(std::move(lam_mi), m_i, s_max, s1.table_c()));
-                    c->lagrange_mi_ = c->lagrange_n_.get();
+                if (!c->link) {
+                    DeviceVec<G1Affine> lam_mi = s1.lagrange_points(m_i, s_max);
+                    c->lagrange_mi_prefix_.reset(new Sigma1(s1.lagrange_prefix_of(lam_mi, m_i, s_max)));
+                    if (m_i == n) {
+                        c->lagrange_n_.reset(new Sigma1(std::move(lam_mi), m_i, s_max, s1.table_c()));
+                        c->lagrange_mi_ = c->lagrange_n_.get();
+                    } else {
+                        c->lagrange_mi_own_.reset(new Sigma1(std::move(lam_mi), m_i, s_max, s1.table_c()));
+                        c->lagrange_mi_ = c->lagrange_mi_own_.get();
+                        c->lagrange_n_.reset(new Sigma1(s1.lagrange_of(n, s_max)));
+                    }
                 } else {
-                    c->lagrange_mi_own_.reset(new Sigma1(std::move(lam_mi), m_i, s_max, s1.table_c()));
-                    c->lagrange_mi_ = c->lagrange_mi_own_.get();
-                    c->lagrange_n_.reset(new Sigma1(s1.lagrange_of(n, s_max)));
+                    // sharded: the group transforms run over the WHOLE grid on every rank (the inverse NTT over G1 points and the prefix
+                    // sums are not sharded: one-time work, seconds), each rank keeps its rows and expands only those into a commit table
+                    if (!whole_grid || !*whole_grid) throw Error("sharded open: the whole xy_powers grid was not handed over");
+                    const Sigma1 &whole = **whole_grid;
+                    const Shard sh = c->link.shard;
+                    DeviceVec<G1Affine> lam_mi = whole.lagrange_points(m_i, s_max);
+                    {
+                        DeviceVec<G1Affine> pre = Sigma1::lagrange_prefix_points(lam_mi, m_i, s_max);
+                        c->lagrange_mi_prefix_.reset(new Sigma1(Sigma1::rows_of_grid(pre, m_i * s_max, 1, sh), m_i * s_max, 1, s1.table_c(), sh));
+                    }
+                    std::unique_ptr<Sigma1> local_mi(new Sigma1(Sigma1::rows_of_grid(lam_mi, m_i, s_max, sh), m_i, s_max, s1.table_c(), sh));
+                    lam_mi = DeviceVec<G1Affine>();
+                    if (m_i == n) {
+                        c->lagrange_n_ = std::move(local_mi);
+                        c->lagrange_mi_ = c->lagrange_n_.get();
+                    } else {
+                        c->lagrange_mi_own_ = std::move(local_mi);
+                        c->lagrange_mi_ = c->lagrange_mi_own_.get();
+                        DeviceVec<G1Affine> lam_n = whole.lagrange_points(n, s_max);
+                        c->lagrange_n_.reset(new Sigma1(Sigma1::rows_of_grid(lam_n, n, s_max, sh), n, s_max, s1.table_c(), sh));
+                    }
                 }
             }
+            if (whole_grid) whole_grid->reset();   // the whole grid has served its purpose: 1/G of it stays resident
         }
         host_trace("open: Lagrange polynomials");
         c->lagrange_ = Prover::LagrangePolys::make(c->m_i, c->sp.s_max);
@@ -351,9 +411,12 @@ class ProverContext {
         const double t3 = Prover::now();
         const Mixer &mx = mixer;
         Binding b;
-        auto indexed = [](const DeviceVec<ScalarField> &sc, const DeviceVec<uint32_t> &ix, uint64_t cnt, const DeviceVec<G1Affine> &table) {
+        // sharded: the binding tables are replicated and a rank commits its slice [cnt r / G, cnt (r + 1) / G) of the (scalar, row) list
+        const Shard sh = link ? link.shard : Shard{};
+        auto indexed = [sh](const DeviceVec<ScalarField> &sc, const DeviceVec<uint32_t> &ix, uint64_t cnt, const DeviceVec<G1Affine> &table) {
+            const uint64_t lo = cnt * sh.rank / sh.world, hi = cnt * (sh.rank + 1) / sh.world;
             tkmk_msm_job_ex j{};
-            j.scalars = sc.ptr(), j.bases = table.ptr(), j.msm_size = (int)cnt, j.base_index = ix.ptr(), j.base_table_len = table.len();
+            j.scalars = sc.ptr() + lo, j.bases = table.ptr(), j.msm_size = (int)(hi - lo), j.base_index = ix.ptr() + lo, j.base_table_len = table.len();
             return j;
         };
         std::vector<G1Affine> cm = Sigma1::run_jobs({sigma->sigma1.job(p->a_free_X, "A_free"), indexed(pub_sc, pub_ix, n_pub, sigma->gamma_inv_o_inst),
@@ -384,9 +447,14 @@ class ProverContext {
     // flags (include/tkmk_prover.h): TKMK_PROVE_TEST_PARTS = the reference's commit list in prove4 (Pi_AX, Pi_CX, Pi_B, M_X, N_X one by
     // one), TKMK_PROVE_COEFFICIENT_BASIS = U, V, W, B, R committed from coefficients although the Lagrange tables are resident.  Neither
     // changes a byte of the proof.
-    Proof prove(const std::string &synth_dir, const std::string &out_dir, const Mixer &mixer, ProveTiming *timing = nullptr, int flags = 0) {
+    Proof prove(const std::string &synth_dir, const std::string &out_dir, const Mixer &mixer_in, ProveTiming *timing = nullptr, int flags = 0) {
         ProveTiming tm;
         const double t0 = Prover::now();
+        ShardSpan span(link);
+        Mixer mixer = mixer_in;
+        // the ranks of a sharded prover commit shares of ONE polynomial: they must blind it with the same scalars — rank 0's
+        static_assert(std::is_trivially_copyable<Mixer>::value, "Mixer travels as bytes");
+        if (link) check(link.broadcast_host(link.comm, &mixer, sizeof mixer, 0), "tkmk_comm_broadcast_host");
         auto pb = init(synth_dir, mixer, tm);
         if (flags & 2) pb.first->lagrange_n = pb.first->lagrange_mi = pb.first->lagrange_mi_prefix = nullptr;
         std::map<std::string, double> times;

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 _lib = None
 
 # every symbol include/tkmk_dist.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ["tkmk_comm_unique_id", "tkmk_comm_init", "tkmk_comm_init_loopback", "tkmk_comm_is_loopback", "tkmk_comm_destroy", "tkmk_comm_rank",
+SYMBOLS = ["tkmk_comm_unique_id", "tkmk_comm_init", "tkmk_comm_init_loopback", "tkmk_comm_is_loopback", "tkmk_comm_device_turn",
+           "tkmk_comm_broadcast_host", "tkmk_comm_destroy", "tkmk_comm_rank",
            "tkmk_comm_size", "tkmk_dist_last_error", "tkmk_msm_sharded", "tkmk_msm_multi_ex_sharded", "tkmk_bintt_sharded"]
 
 

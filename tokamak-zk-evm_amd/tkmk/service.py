@@ -17,7 +17,7 @@ _libs = {}
 TEST_PARTS, COEFFICIENT_BASIS = 1, 2        # TKMK_PROVE_* of include/tkmk_prover.h
 
 # every symbol include/tkmk_prover.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ["tkmk_prover_open", "tkmk_prover_prove", "tkmk_prover_prove_ex", "tkmk_prover_close", "tkmk_prover_free_string", "tkmk_prover_last_error",
+SYMBOLS = ["tkmk_prover_open", "tkmk_prover_open_sharded", "tkmk_prover_world_size", "tkmk_prover_prove", "tkmk_prover_prove_ex", "tkmk_prover_close", "tkmk_prover_free_string", "tkmk_prover_last_error",
            "tkmk_prover_crs_source"]
 
 
@@ -58,14 +58,20 @@ class Prover:
     """with Prover(lib_dir, crs_dir) as p: proof, timing = p.prove(synth_dir, out_dir)
     testing=True binds libtkmk_prover_testing.so, the only build that takes `testing_mixer_json`."""
 
-    def __init__(self, subcircuit_library_dir, crs_dir, testing=False):
+    def __init__(self, subcircuit_library_dir, crs_dir, testing=False, comm=None):
+        """comm: a tkmk.dist.Comm — this process (or, over the loopback transport, this thread) is one rank of a sharded prover:
+        tkmk_prover_open_sharded; every rank constructs and then proves with the same arguments"""
         h = ctypes.c_void_p()
         self._h = None
         self._lib = lib(testing)
         self.testing = testing
-        code = self._lib.tkmk_prover_open(os.fsencode(subcircuit_library_dir), os.fsencode(crs_dir), ctypes.byref(h))
+        self.comm = comm
+        if comm is None:
+            code = self._lib.tkmk_prover_open(os.fsencode(subcircuit_library_dir), os.fsencode(crs_dir), ctypes.byref(h))
+        else:
+            code = self._lib.tkmk_prover_open_sharded(comm.handle, os.fsencode(subcircuit_library_dir), os.fsencode(crs_dir), ctypes.byref(h))
         if code != 0:
-            raise ProverError(code, "tkmk_prover_open", testing)
+            raise ProverError(code, "tkmk_prover_open" if comm is None else "tkmk_prover_open_sharded", testing)
         self._h = h
 
     @property
