@@ -68,6 +68,21 @@ SEED = 0x746F6B616D616B00
 SECTIONS = ("convert_bases", "digits", "hist", "scan", "scatter", "prepare", "accumulate", "combine", "reduce_segments", "reduce_windows")
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on stdout when a communicator comes up; stdout carries the ONE JSON line and nothing else, so file
+    descriptor 1 points at stderr while communicators are made"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def _read_sections(tkmk, proofs):
     """per-proof section times of the event profiler since the last reset -> ({name: {ms_per_proof, launches_per_proof}}, ntt ms per proof,
     (accumulate ms, launches))"""
@@ -119,10 +134,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        with _stdout_to_stderr():
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+            else:
+                dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            dist.barrier()                                  # the communicator comes up here (and says so on stdout)
     comm_device = "cuda" if args.dist_backend == "nccl" else "cpu"
 
     def barrier():
@@ -143,13 +160,14 @@ def main():
     slots = files["constraint_slots"]
     try:
         t = time.perf_counter()
-        one_proof = args.one_proof and world > 1
+        one_proof = args.one_proof          # N = 1: a one-rank RCCL communicator — the same code path, for rehearsing it on a one-GPU box
         if one_proof and comm_device != "cuda":
             raise SystemExit("--one-proof runs over libtkmk_dist.so (RCCL): needs --dist-backend nccl")
         shard_comm = None
         if one_proof:
             from tkmk import dist as tkdist
-            shard_comm = tkdist.comm_from_torch(dist)
+            with _stdout_to_stderr():
+                shard_comm = tkdist.comm_from_torch(dist) if dist is not None else tkdist.Comm(tkdist.unique_id(), 1, 0)
         prover = service.Prover(files["qap"], files["crs"], comm=shard_comm)      # circuit-static state -> HBM, once (sharded: 1/N of the tables)
         open_s = time.perf_counter() - t
         jobs_in_flight = 1 if one_proof else world                                # proofs a step completes
@@ -575,7 +593,8 @@ def _msm_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch)
     h.free()
     # the C-ABI entry (libtkmk_dist.so: RCCL all_gather on device buffers) when the ranks talk over RCCL; the torch helper for the
     # gloo rehearsal of the same partitioning
-    comm = tkdist.comm_from_torch(dist) if comm_device == "cuda" else None
+    with _stdout_to_stderr():
+        comm = tkdist.comm_from_torch(dist) if comm_device == "cuda" else None
     run = (lambda: comm.msm_sharded(scalars, bases)) if comm is not None else (lambda: sharding.msm_sharded(tkmk, dist, scalars, bases, device=comm_device))
     run()
     barrier()

@@ -229,7 +229,7 @@ class ProverContext {
             const size_t n = c->sp.n, m_i = c->m_i, s_max = c->sp.s_max;
             if (c->sigma->sigma1.table_c() && !(e && atoi(e) == 0) && is_pow2(n) && is_pow2(m_i) && is_pow2(s_max)) {
                 const Sigma1 &s1 = c->sigma->sigma1;
-                if (!c->link) {
+                if (!c->link || c->link.shard.world == 1) {   // (a one-rank communicator holds whole tables: nothing to cut)
                     DeviceVec<G1Affine> lam_mi = s1.lagrange_points(m_i, s_max);
                     c->lagrange_mi_prefix_.reset(new Sigma1(s1.lagrange_prefix_of(lam_mi, m_i, s_max)));
                     if (m_i == n) {
