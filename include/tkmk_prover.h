@@ -38,7 +38,13 @@ typedef struct {          /* seconds */
 /* Loads the circuit-static state.  Because the context is meant to stay, xy_powers is expanded once into a precomputed commit
  * table (ICICLE's msm_precompute_bases; 20-bit windows, 13 x the table in HBM: 21 GB for the 2^24-point CRS of BASELINE.json
  * configs[3]) so that every large commit costs 13 instead of 16 bucket additions per point; commitments are bit-identical either
- * way.  Environment: TKMK_PROVER_TABLE_C=0 disables the table, 13..20 picks another window width. */
+ * way.  Environment: TKMK_PROVER_TABLE_C=0 disables the table, 13..20 picks another window width.
+ * Resident cost per circuit, in full (BASELINE.json configs[3], n = m_I = 4096, s_max = 1024; the production shape s_max = 256 is a
+ * quarter of each): the commit table 21 GB; the Lagrange-basis twin of the n x s_max grid in the same 13-level form 5.2 GB; its prefix
+ * sums in prove1's walk order 5.2 GB; the binding tables 4.2 GB; the subcircuit library and the NTT domain < 1 GB — 36 GB of the 288 —
+ * and 7.6 s at open (2.7 s table expansion, 3.3 s group NTT behind the Lagrange table, 1.3 s prefix sums and their expansion; production
+ * shape 1.9 s).  TKMK_PROVER_LAGRANGE=0 drops the second and third items (U, V, W, B, R are then committed from coefficients).  A
+ * sharded context (tkmk_prover_open_sharded) keeps 1 / G of the first three per GPU. */
 tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const char *crs_dir, tkmk_prover **out);
 /* ONE proof over the G GPUs of a node (the reference is single-device, so nothing is replaced): rank
  * r of the communicator `comm` (a tkmk_comm of include/tkmk_dist.h, made by the host: one process per GPU over RCCL) keeps the grid rows
