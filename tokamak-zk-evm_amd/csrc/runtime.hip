@@ -62,6 +62,17 @@ tkmk_error tk_require_device() {
         g_dev_status = ok ? TKMK_SUCCESS : TKMK_ERR_INVALID_DEVICE;
         if (ok) g_bound_device.store(dev);
     });
+    // HIP's current device is per host thread and starts at 0: a thread the host started after binding (a rank's helper thread, the
+    // virtual ranks of the loopback transport) must work on the library's device, not on device 0 of a multi-GPU node
+    if (g_dev_status == TKMK_SUCCESS) {
+        static thread_local bool checked = false;
+        if (!checked) {
+            const int bound = g_bound_device.load();
+            int cur = -1;
+            if (bound >= 0 && hipGetDevice(&cur) == hipSuccess && cur != bound) (void)hipSetDevice(bound);
+            checked = true;
+        }
+    }
     return g_dev_status;
 }
 

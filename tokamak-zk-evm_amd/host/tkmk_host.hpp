@@ -773,8 +773,11 @@ class Sigma1 {
         return cfg;
     }
     // independent MSM jobs over converted tables in one pipelined call -> affine results; (0,0) = G1serde::zero()
-    static std::vector<G1Affine> run_jobs(const std::vector<tkmk_msm_job_ex> &jobs) {
+    // stream: the caller's stream for the batch's scratch frame (a helper thread names its own, so that its frame does not share the
+    // default stream's arena with the main thread: tkmk.h "re-entrant per stream")
+    static std::vector<G1Affine> run_jobs(const std::vector<tkmk_msm_job_ex> &jobs, tkmk_stream stream = nullptr) {
         tkmk_msm_config cfg = device_cfg();
+        cfg.stream_handle = stream;
         std::vector<tkmk_g1_projective> res(jobs.size());
         if (host_trace_on()) {
             std::string d;

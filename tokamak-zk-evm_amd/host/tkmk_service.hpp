@@ -15,6 +15,7 @@
 #include <sys/stat.h>
 
 #include <fstream>
+#include <future>
 
 #include "tkmk_fastparse.hpp"
 #include "tkmk_inputs.hpp"
@@ -51,6 +52,17 @@ struct ShardSpan {
     }
 };
 
+// The four binding commitments of Prover::init (A_free, O_pub_free, O_mid, O_prv: lib.rs:1086-1160) enter the proof document but not the
+// transcript: no round waits for them.  On a single-GPU context their MSM batch is issued from a helper thread on its own stream as
+// soon as the routed witness lists exist, and collected after prove4: its sort and tail kernels (latency-bound, a few ms) then run under
+// prove0's transforms and streaming passes instead of in front of them.  Members are destroyed in reverse order: the future first
+// (it waits for the batch), the operand buffers after it.
+struct PendingBinding {
+    DeviceVec<ScalarField> mid_sc, prv_sc, pub_sc;
+    DeviceVec<uint32_t> mid_ix, prv_ix, pub_ix;
+    std::future<std::vector<G1Affine>> cores;   // A_free, O_pub_free, O_mid_core, O_prv_core
+};
+
 struct ProveTiming {   // seconds
     double parse = 0, upload = 0, build = 0, binding = 0, init = 0;
     double prove[5] = {0, 0, 0, 0, 0};
@@ -84,6 +96,7 @@ class ProverContext {
     std::unique_ptr<Sigma1> lagrange_mi_prefix_;                      // prefix sums of the m_I x s_max one in prove1's walk order
     const Sigma1 *lagrange_mi_ = nullptr;                             // (= lagrange_n_ when n == m_I)
 
+    tkmk_stream binding_stream_ = nullptr;                          // the helper thread's stream (PendingBinding)
     ScalarField *pinned_ = nullptr;                                 // witness staging
     uint64_t pinned_cap_ = 0;
     std::vector<uint32_t> n_wires_;
@@ -118,6 +131,7 @@ class ProverContext {
     ~ProverContext() {
         if (lib_) tkmk_r1cs_library_destroy(lib_);
         if (pinned_) tkmk_host_free(pinned_);
+        if (binding_stream_) tkmk_stream_destroy(binding_stream_);
     }
 
     static SetupParams read_setup_params(const std::string &dir) {
@@ -276,7 +290,9 @@ class ProverContext {
     }
 
     // Prover::init (prove/src/lib.rs:675-1206) from the synthesizer's directory
-    std::pair<std::unique_ptr<Prover>, Binding> init(const std::string &synth_dir, const Mixer &mixer, ProveTiming &tm) {
+    // pending (optional): when given and this context is not sharded, the binding batch is left running and *pending holds it;
+    // finish_binding() completes the returned Binding later.  Otherwise the Binding is complete on return.
+    std::pair<std::unique_ptr<Prover>, Binding> init(const std::string &synth_dir, const Mixer &mixer, ProveTiming &tm, std::unique_ptr<PendingBinding> *pending = nullptr) {
         using namespace prover_detail;
         const double t0 = Prover::now();
         const size_t n = sp.n, s_max = sp.s_max, K = infos.size();
@@ -419,9 +435,39 @@ class ProverContext {
             j.scalars = sc.ptr() + lo, j.bases = table.ptr(), j.msm_size = (int)(hi - lo), j.base_index = ix.ptr() + lo, j.base_table_len = table.len();
             return j;
         };
-        std::vector<G1Affine> cm = Sigma1::run_jobs({sigma->sigma1.job(p->a_free_X, "A_free"), indexed(pub_sc, pub_ix, n_pub, sigma->gamma_inv_o_inst),
+        std::vector<tkmk_msm_job_ex> binding_jobs = {sigma->sigma1.job(p->a_free_X, "A_free"), indexed(pub_sc, pub_ix, n_pub, sigma->gamma_inv_o_inst),
                                                      indexed(mid_sc, mid_ix, n_mid, sigma->eta_inv_li_o_inter_alpha4_kj),
-                                                     indexed(prv_sc, prv_ix, n_prv, sigma->delta_inv_li_o_prv)});
+                                                     indexed(prv_sc, prv_ix, n_prv, sigma->delta_inv_li_o_prv)};
+        static const bool async_binding = [] {
+            const char *e = getenv("TKMK_PROVER_ASYNC_BINDING");
+            return !(e && atoi(e) == 0);
+        }();
+        if (pending && !link && async_binding) {
+            if (!binding_stream_) check(tkmk_stream_create(&binding_stream_), "stream_create");
+            pending->reset(new PendingBinding());
+            PendingBinding &pb = **pending;
+            pb.mid_sc = std::move(mid_sc), pb.prv_sc = std::move(prv_sc), pb.pub_sc = std::move(pub_sc);   // the jobs point into these blocks
+            pb.mid_ix = std::move(mid_ix), pb.prv_ix = std::move(prv_ix), pb.pub_ix = std::move(pub_ix);
+            tkmk_stream bs = binding_stream_;
+            pb.cores = std::async(std::launch::async, [binding_jobs, bs] { return Sigma1::run_jobs(binding_jobs, bs); });
+            tm.binding = Prover::now() - t3;
+            tm.init = Prover::now() - t0;
+            p->timing["init.parse"] = tm.parse, p->timing["init.upload"] = tm.upload, p->timing["init.build"] = tm.build;
+            p->timing["init.binding"] = tm.binding, p->timing["init.total"] = tm.init;
+            return {std::move(p), b};
+        }
+        b = finish_binding(Sigma1::run_jobs(binding_jobs), mx);
+        tm.binding = Prover::now() - t3;
+        tm.init = Prover::now() - t0;
+        p->timing["init.parse"] = tm.parse, p->timing["init.upload"] = tm.upload, p->timing["init.build"] = tm.build;
+        p->timing["init.binding"] = tm.binding, p->timing["init.total"] = tm.init;
+        return {std::move(p), b};
+    }
+
+    // the blinding terms on top of the four core commitments (lib.rs:1100-1160)
+    Binding finish_binding(const std::vector<G1Affine> &cm, const Mixer &mx) const {
+        using namespace prover_detail;
+        Binding b;
         b.A_free = cm[0], b.O_pub_free = cm[1];
         const G1Affine &O_mid_core = cm[2], &O_prv_core = cm[3];
         const auto &xh = sigma->delta_inv_alphak_xh_tx, &xj = sigma->delta_inv_alpha4_xj_tx, &yi = sigma->delta_inv_alphak_yi_ty;
@@ -436,11 +482,7 @@ class ProverContext {
             {mx.rB_Y[0], yi[9]}, {mx.rB_Y[1], yi[10]}};
         auto both = g1_lincombs({mid, prv});
         b.O_mid = both[0], b.O_prv = both[1];
-        tm.binding = Prover::now() - t3;
-        tm.init = Prover::now() - t0;
-        p->timing["init.parse"] = tm.parse, p->timing["init.upload"] = tm.upload, p->timing["init.build"] = tm.build;
-        p->timing["init.binding"] = tm.binding, p->timing["init.total"] = tm.init;
-        return {std::move(p), b};
+        return b;
     }
 
     // main() of prove/src/main.rs:27-97 after check_device: init, five rounds, <out_dir>/proof.json
@@ -455,10 +497,24 @@ class ProverContext {
         // the ranks of a sharded prover commit shares of ONE polynomial: they must blind it with the same scalars — rank 0's
         static_assert(std::is_trivially_copyable<Mixer>::value, "Mixer travels as bytes");
         if (link) check(link.broadcast_host(link.comm, &mixer, sizeof mixer, 0), "tkmk_comm_broadcast_host");
-        auto pb = init(synth_dir, mixer, tm);
+        std::pair<std::unique_ptr<Prover>, Binding> pb;
+        std::unique_ptr<PendingBinding> pending;   // declared after pb: destroyed (and thereby waited for) BEFORE the prover whose a_free_X it reads
+        pb = init(synth_dir, mixer, tm, &pending);
         if (flags & 2) pb.first->lagrange_n = pb.first->lagrange_mi = pb.first->lagrange_mi_prefix = nullptr;
         std::map<std::string, double> times;
-        Proof proof = run_rounds(*pb.first, pb.second, &times, (flags & 1) != 0);
+        Proof proof;
+        try {
+            proof = run_rounds(*pb.first, pb.second, &times, (flags & 1) != 0);
+        } catch (...) {
+            if (pending && pending->cores.valid()) pending->cores.wait();   // the batch reads a_free_X of the prover about to go
+            throw;
+        }
+        if (pending) {   // collect the binding commitments issued during init
+            const double tb = Prover::now();
+            proof.binding = finish_binding(pending->cores.get(), mixer);
+            pending.reset();
+            tm.binding += Prover::now() - tb;
+        }
         int k = 0;
         for (const char *name : {"prove0", "prove1", "prove2", "prove3", "prove4"}) tm.prove[k++] = times[name];
         const double tw = Prover::now();
