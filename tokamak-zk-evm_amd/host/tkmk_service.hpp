@@ -442,7 +442,8 @@ class ProverContext {
             const char *e = getenv("TKMK_PROVER_ASYNC_BINDING");
             return !(e && atoi(e) == 0);
         }();
-        if (pending && !link && async_binding) {
+        // (at one pipeline stream — bench.py's serialised profiling pass: every kernel alone on the device — the batch runs in line)
+        if (pending && !link && async_binding && tkmk_msm_get_pipeline_streams() > 1) {
             if (!binding_stream_) check(tkmk_stream_create(&binding_stream_), "stream_create");
             pending->reset(new PendingBinding());
             PendingBinding &pb = **pending;
