@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""NTT shapes of the configs[3] prover (2^10 / 2^11-point rows, 2^14-point columns, the bivariate domains) timed through the C ABI;
+run once per TKMK_NTT_MAX_LOGR value to compare pass plans (profiles/r03_ntt_max_radix_9_vs_10.txt)."""
 import json, os, sys, time
 sys.path.insert(0, "tokamak-zk-evm_amd")
 import tkmk
