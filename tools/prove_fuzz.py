@@ -1,7 +1,10 @@
 """Randomized differential run of the GPU prover against the big-int restatement (tests/prove_ref.py) over random circuit shapes:
 every proof point, evaluation and challenge must match, and the combined verifier equation must hold on the discrete logarithms.
-usage: python tools/prove_fuzz.py [CASES] [FIRST_SEED] [native] [mid]      (test infrastructure: uses the oracle)
-With `native` the proof comes from tokamak-zk-evm_amd/bin/prove over files (CRS written by Sigma.write, blinding through --testing-mixer)."""
+usage: python tools/prove_fuzz.py [CASES] [FIRST_SEED] [native] [mid] [sharded]      (test infrastructure: uses the oracle)
+With `native` the proof comes from tokamak-zk-evm_amd/bin/prove-testing over files (CRS written by Sigma.write, blinding through
+--testing-mixer); with `sharded` (implies native) the same files also go through the sharded resident prover over the loopback
+transport with 2, 3 or 4 virtual ranks (tkmk_prover_open_sharded), with and without the commit / Lagrange tables, and every rank's
+document must be the binary's byte for byte."""
 import json
 import os
 import random
@@ -23,7 +26,8 @@ from tkmk.setup import Sigma  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-native = "native" in sys.argv[3:]
+sharded = "sharded" in sys.argv[3:]
+native = "native" in sys.argv[3:] or sharded
 mid = "mid" in sys.argv[3:]            # m_I = 64 .. 128 instead of 16 .. 64 (the restatement then needs 1 .. 15 s per case)
 pins = json.load(open(os.path.join(ROOT, "tests", "golden", "pins.json")))
 tau = {k: int(pins["tau_" + k], 16) for k in ("x", "y", "alpha", "gamma", "delta", "eta")}
@@ -57,8 +61,22 @@ for seed in range(first, first + cases):
                             "--output", os.path.join(d, "out"), "--subcircuit-library", inst["qap"], "--testing-mixer", os.path.join(d, "mixer.json")],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (seed, shape, r.stderr)
-        points, scalars = proofio.recover_proof(json.load(open(os.path.join(d, "out", "proof.json"))))
+        native_doc = json.load(open(os.path.join(d, "out", "proof.json")))
+        points, scalars = proofio.recover_proof(native_doc)
         assert scalars == ref_scalars, (seed, shape)
+        if sharded:
+            from tkmk import dist, service
+            world = rnd.choice([2, 3, 4])
+            os.environ["TKMK_PROVER_TABLE_C"] = rnd.choice(["12", "0"])
+            comms = dist.loopback_comms(world)
+            provers = dist.run_ranks(comms, lambda c: service.Prover(inst["qap"], os.path.join(d, "crs"), testing=True, comm=c))
+            by_rank = {p.comm.rank: p for p in provers}
+            docs = dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(inst["synth"], None, testing_mixer_json=os.path.join(d, "mixer.json"))[0])
+            for p in provers:
+                p.close()
+            for c in comms:
+                c.close()
+            assert all(doc == native_doc for doc in docs), (seed, shape, world)
     else:
         prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, testing_mode=True, sigma=sigma.prover_view())
         points, scalars, challenges, p4t, _ = run_rounds(prover, binding)
