@@ -20,7 +20,7 @@ R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 @pytest.fixture(scope="module")
 def san(tkmk):
     out = {}
-    for name in ("inputs_driver", "rkyv_driver"):
+    for name in ("inputs_driver", "rkyv_driver", "args_driver"):
         src = os.path.join(HERE, "host_cpp", name + ".cpp")
         exe = os.path.join(HERE, "host_cpp", name + "_san")
         deps = [src] + [os.path.join(PKG, "host", f) for f in os.listdir(os.path.join(PKG, "host")) if f.endswith(".hpp")]
@@ -99,3 +99,40 @@ def test_rkyv_reader_and_writer_under_asan_ubsan(san, oracle, tmp_path):
     for cut in (0, 8, 16, len(pre) - 3, len(pre)):
         (tmp_path / "pre.rkyv").write_bytes(pre[:cut])
         assert _run(san["rkyv_driver"], "pre-decode", tmp_path / "pre.rkyv", tmp_path / "x").returncode == (0 if cut == len(pre) else 1)
+
+
+def test_argument_parser_and_library_resolution_under_asan_ubsan(san, tmp_path):
+    """host/tkmk_args.hpp (the argv tokamak-cli sends, clap's flag forms, the library search) on ordinary, odd and hostile argument
+    vectors: a result or an error, never a bad access"""
+    lib = tmp_path / "lib"
+    lib.mkdir()
+    (lib / "setupParams.json").write_text("{}")
+    exe = san["args_driver"]
+    env = dict(ENV, HOME=str(tmp_path / "home"))
+    env.pop("TKMK_SUBCIRCUIT_LIBRARY", None)
+    env.pop("XDG_CACHE_HOME", None)
+
+    def run(argv, extra=None):
+        r = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=60, env=dict(env, **(extra or {})))
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        return r
+    r = run(["--crs", "a", "--synthesizer-stat=b", "--output", "c", "--subcircuit-library", str(lib)])
+    assert r.returncode == 0 and r.stdout.strip() == "ok a|b|c|%s|0" % os.path.realpath(lib)
+    r = run(["--crs=a=b", "--fixed-tau"], {"TKMK_SUBCIRCUIT_LIBRARY": str(lib)})
+    assert r.returncode == 0 and r.stdout.startswith("ok a=b|||") and r.stdout.strip().endswith("|1")
+    assert run(["--crs", "a"]).returncode == 1                                      # nothing to resolve from
+    assert run(["--crs"]).returncode == 2 and run(["--fixed-tau=1"]).returncode == 2 and run(["--crs", "a", "--crs", "b"]).returncode == 2
+    rnd = random.Random(3)
+    atoms = ["--crs", "--crs=", "--output", "--subcircuit-library", "--subcircuit-library=" + str(lib), "--fixed-tau", "--", "-", "", "=", "--=x", "x" * 5000,
+             "--synthesizer-stat=" + "y" * 3000, str(lib), "--help", "-h", "\xff\xfe", "--crs=\n"]
+    for _ in range(150):
+        argv = [rnd.choice(atoms) for _ in range(rnd.randrange(0, 9))]
+        assert run(argv, rnd.choice([None, {"TKMK_SUBCIRCUIT_LIBRARY": str(lib)}, {"XDG_CACHE_HOME": str(tmp_path)}, {"HOME": ""}])).returncode in (0, 1, 2)
+    # a cache directory full of odd entries
+    snaps = tmp_path / "tokamak-zk-evm" / "subcircuit-library"
+    for name in ("staging-1-2", "a", "b" * 200, ".hidden"):
+        (snaps / name / "library").mkdir(parents=True)
+    (snaps / "a" / "library" / "setupParams.json").write_text("{}")
+    (snaps / "plainfile").write_text("x")
+    r = run(["--crs", "a"], {"XDG_CACHE_HOME": str(tmp_path)})
+    assert r.returncode == 0 and r.stdout.strip().endswith("/a/library|0")
