@@ -71,3 +71,13 @@ for i in (1, 2, 12):
 info = [e for e in json.load(open(lib + "subcircuitInfo.json")) if e["id"] in (1, 2, 12)]
 json.dump(info, open(dst + "/subcircuitInfo.json", "w"))
 json.dump(json.load(open(lib + "setupParams.json")), open(dst + "/setupParams.json", "w"))
+
+# A second, larger set for the direct parity tests of the device-side constraint library (tests/test_gpu_witness.py,
+# tests/test_r1cs_reader.py): four mid-size subcircuits of the same library (17 .. 154 KB each), same treatment — binary data files and
+# their subcircuitInfo entries, nothing executed.
+dst2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "qap_more")
+os.makedirs(dst2 + "/r1cs", exist_ok=True)
+MORE = (0, 3, 7, 9)
+for i in MORE:
+    shutil.copy(lib + "r1cs/subcircuit%d.r1cs" % i, dst2 + "/r1cs/")
+json.dump([e for e in json.load(open(lib + "subcircuitInfo.json")) if e["id"] in MORE], open(dst2 + "/subcircuitInfo.json", "w"))

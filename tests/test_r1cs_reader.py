@@ -1,6 +1,7 @@
-"""not-gpu tier: the `.r1cs` reader (tkmk/r1cs.py, mirror of libs/src/iotools/mod.rs:505-760) on three compiled
-subcircuits taken as DATA from the reference's committed library (tests/golden/qap, copied by tests/golden/make_pins.py),
-plus the oracle's eval_sparse_rows restatement against Python big ints."""
+"""not-gpu tier: the `.r1cs` reader (tkmk/r1cs.py, mirror of libs/src/iotools/mod.rs:505-760) on seven compiled
+subcircuits taken as DATA from the reference's committed library (tests/golden/qap: three small ones; tests/golden/qap_more: four
+mid-size ones, up to 1201 wires; copied by tests/golden/make_pins.py), plus the oracle's eval_sparse_rows restatement against
+Python big ints."""
 import json
 import os
 import random
@@ -26,6 +27,30 @@ def qap():
     infos = json.load(open(os.path.join(QAP, "subcircuitInfo.json")))
     params = json.load(open(os.path.join(QAP, "setupParams.json")))
     return infos, params
+
+
+QAP_MORE = os.path.join(HERE, "golden", "qap_more")
+
+
+def test_reader_and_oracle_rows_on_the_mid_size_subcircuits(r1cs_mod, qap, oracle):
+    """bufferPubOut, bufferEVMIn (1201 wires), DecToBit, Accumulator of the production library: header fields equal subcircuitInfo.json,
+    the CSR form is consistent, and the oracle's sparse-row evaluation equals big-int arithmetic on the raw file walk
+    (scan_constraints: the reader's slow path, independent of the numpy fast path csr() takes)"""
+    _, params = qap
+    rnd = random.Random(14)
+    for e in json.load(open(os.path.join(QAP_MORE, "subcircuitInfo.json"))):
+        path = os.path.join(QAP_MORE, "r1cs", "subcircuit%d.r1cs" % e["id"])
+        b = r1cs_mod.R1csBinary.read(path)
+        assert (b.n_wires, b.n_constraints, b.field_size) == (e["Nwires"], e["Nconsts"], 32) and b.prime() == oracle.R_MOD
+        var = [rnd.choice((0, 1, rnd.randrange(oracle.R_MOD))) for _ in range(e["Nwires"])]
+        want = [[0] * e["Nconsts"] for _ in range(3)]
+        for m, wire, coeff, row in b.scan_constraints():
+            want[m][row] = (want[m][row] + int.from_bytes(coeff, "little") * var[wire]) % oracle.R_MOD
+        V = oracle.to_bytes(var, 32)
+        for m, (ptr, wires, coeffs) in enumerate(b.csr()):
+            assert len(ptr) == e["Nconsts"] + 1 and ptr[-1] == wires.size == coeffs.size // 32
+            got = oracle.to_ints(oracle.r1cs_eval_rows(ptr, wires, coeffs if coeffs.size else np.zeros(32, np.uint8), V, e["Nconsts"]), 32)
+            assert got == want[m], (e["id"], m)
 
 
 def test_reader_matches_subcircuit_info(r1cs_mod, qap, oracle):
