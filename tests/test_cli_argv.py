@@ -105,9 +105,15 @@ def test_flag_forms_clap_accepts(tkmk, tmp_path):
     assert r.returncode == 2 and "unexpected value" in r.stderr
     r = _run("prove", ["--subcircuit-library", str(tmp_path / "nowhere"), "--crs", "a", "--synthesizer-stat", "b", "--output", "c"])
     assert r.returncode == 1 and "cannot resolve subcircuit library path" in r.stderr      # subcircuit_library.rs:42-45
+    import re
     for name in CLI_ARGV:
         r = _run(name, ["--help"])
         assert r.returncode == 0 and r.stdout.startswith("Usage: " + name)
+        # `tokamak-cli doctor` (packages/cli/src/cli.ts:390-404, 655-664): `<binary> --version`, first x.y.z of a line that starts with the name
+        for flag in ("--version", "-V"):
+            r = _run(name, [flag])
+            assert r.returncode == 0 and r.stdout.startswith(name + " ")
+            assert re.search(r"\b\d+\.\d+\.\d+(?:[-+][0-9A-Za-z.-]+)?\b", r.stdout).group(0).startswith("2.1.3")
 
 
 def test_production_prove_refuses_the_fixed_blinding_hook(tkmk, tmp_path):

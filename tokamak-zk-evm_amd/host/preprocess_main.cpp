@@ -29,6 +29,10 @@ int main(int argc, char **argv) {
         fputs(USAGE, stdout);
         return 0;
     }
+    if (a.version) {
+        printf("preprocess %s\n", TKMK_BACKEND_INTERFACE_VERSION);
+        return 0;
+    }
     for (const char *need : {"--crs", "--synthesizer-stat", "--output"})
         if (a.error.empty() && !a.has(need)) a.error = std::string("the following required arguments were not provided: ") + need + " <PATH>";
     if (!a.error.empty()) {

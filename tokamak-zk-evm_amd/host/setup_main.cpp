@@ -62,6 +62,10 @@ int main(int argc, char **argv) {
         fputs(USAGE, stdout);
         return 0;
     }
+    if (a.version) {
+        printf("trusted-setup %s\n", TKMK_BACKEND_INTERFACE_VERSION);
+        return 0;
+    }
     if (a.error.empty() && !a.has("--output")) a.error = "the following required arguments were not provided: --output <PATH>";
     const std::string format = a.get("--format", "both"), out_dir = a.get("--output");
     if (a.error.empty() && format != "both" && format != "rkyv" && format != "tkcrs") a.error = "invalid value '" + format + "' for '--format'";

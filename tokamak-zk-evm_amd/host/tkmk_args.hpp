@@ -31,10 +31,15 @@ struct Spec {
     std::set<std::string> switches; // "--fixed-tau", ...
 };
 
+// `--version` / `-V` (clap's `#[command(version)]`): "<binary> <version>".  `tokamak-cli doctor` runs every backend binary with it and
+// reads the first x.y.z it finds (packages/cli/src/cli.ts:390-404, 655-664).  The number is the version of the reference's backend
+// workspace whose command-line surface and file formats these binaries mirror (packages/backend/Cargo.toml:13), with a build tag.
+#define TKMK_BACKEND_INTERFACE_VERSION "2.1.3+mi355x"
+
 struct Parsed {
     std::map<std::string, std::string> values;
     std::set<std::string> switches;
-    bool help = false;
+    bool help = false, version = false;
     std::string error;   // non-empty: print it + usage, exit 2 (clap's exit code for usage errors)
     bool has(const std::string &k) const { return values.count(k) != 0; }
     std::string get(const std::string &k, const std::string &dflt = "") const {
@@ -50,6 +55,10 @@ inline Parsed parse(int argc, char **argv, const Spec &spec) {
         std::string a = argv[i];
         if (a == "--help" || a == "-h") {
             p.help = true;
+            continue;
+        }
+        if (a == "--version" || a == "-V") {
+            p.version = true;
             continue;
         }
         std::string key = a, val;
