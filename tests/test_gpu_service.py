@@ -227,8 +227,8 @@ def test_prove_and_preprocess_from_the_reference_archives(gpu, oracle, tmp_path,
 
 
 def test_native_setup_writes_archives_the_prover_reads(gpu, tmp_path):
-    """bin/trusted-setup --fixed-tau writes combined_sigma.rkyv, sigma_preprocess.rkyv and combined_sigma.tkcrs; the three hold the
-    same sections, and the service proves from either container"""
+    """bin/trusted-setup --fixed-tau writes combined_sigma.rkyv, sigma_preprocess.rkyv, sigma_verify.json and combined_sigma.tkcrs; they hold
+    the same sections, and the service proves from either container"""
     import synth_circuit
     from tkmk import crs as crsmod
     from tkmk import rkyv
@@ -246,6 +246,23 @@ def test_native_setup_writes_archives_the_prover_reads(gpu, tmp_path):
         assert bytes(arch[name]) == bytes(flat[name]), name
     pre = rkyv.decode_sigma_preprocess(open(os.path.join(out, "sigma_preprocess.rkyv"), "rb").read())
     assert bytes(pre["xy_powers"]) == bytes(flat["xy_powers"]) and bytes(pre["gamma_inv_o_inst"]) == bytes(flat["gamma_inv_o_inst"])
+    # sigma_verify.json, the verifier's part (SigmaVerify: libs/src/group_structures/mod.rs:849-860; points as {"x": hex, "y": hex} read
+    # back with from_hex: iotools/mod.rs:999-1059): the same points as the payload's singles and G2 section, the fixed generators of the
+    # reference's recipe among them (tests/golden/pins.json)
+    from tkmk import g2
+    sv = json.load(open(os.path.join(out, "sigma_verify.json")))
+    assert list(sv) == ["G", "H", "sigma_1", "sigma_2", "lagrange_KL"] and list(sv["sigma_2"]) == list(crsmod.G2_POINTS[1:])
+    g1_of = lambda name: bytes(crsmod.single_g1(flat, name))                                                        # noqa: E731
+    g1_json = lambda pt: int(pt["x"], 16).to_bytes(48, "little") + int(pt["y"], 16).to_bytes(48, "little")          # noqa: E731
+    assert g1_json(sv["G"]) == g1_of("G") and g1_json(sv["sigma_1"]["x"]) == g1_of("x") and g1_json(sv["sigma_1"]["y"]) == g1_of("y")
+    assert g1_json(sv["lagrange_KL"]) == g1_of("lagrange_KL")
+    recs = np.asarray(flat["g2"]).reshape(10, 192)
+    for i, name in enumerate(crsmod.G2_POINTS):
+        pt = sv["H"] if name == "H" else sv["sigma_2"][name]
+        assert len(pt["x"]) == 2 + 192 and g2.from_hex_pair(pt["x"], pt["y"]) == g2.decode(recs[i]), name
+    pins = json.load(open(os.path.join(ROOT, "tests", "golden", "pins.json")))
+    assert int(sv["G"]["x"], 16) == int(pins["fixed_tau_g1_x"], 16) and int(sv["H"]["x"], 16) == int(pins["fixed_tau_g2_x"], 16)
+    assert int(sv["H"]["y"], 16) == int(pins["fixed_tau_g2_y"], 16)
 
 
 @pytest.mark.parametrize("c", [12, 16, 18, 20])

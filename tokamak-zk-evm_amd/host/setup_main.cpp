@@ -4,6 +4,7 @@
 // library is resolved the way host/tkmk_args.hpp describes.
 // reads <lib>/setupParams.json, <lib>/subcircuitInfo.json, <lib>/r1cs/subcircuit{id}.r1cs; writes the reference's containers
 // <out>/combined_sigma.rkyv and <out>/sigma_preprocess.rkyv (write_final_crs_artifacts, libs/src/iotools/mod.rs:271-300; host/tkmk_rkyv.hpp)
+// <out>/sigma_verify.json (the verifier's part of the reference string, libs/src/iotools/mod.rs:186-218, 295-297)
 // and <out>/combined_sigma.tkcrs (the flat TKCRS001 payload the reference derives from its archive: tkmk/crs.py — the fast path of
 // `prove`).  --format picks one; a reference string past 2 GiB does not fit an rkyv archive (32-bit relative pointers) and is written
 // as .tkcrs only.  --fixed-tau uses the hardcoded testing generators and tau of the
@@ -145,6 +146,7 @@ int main(int argc, char **argv) {
             std::string path = sigma.write(out_dir);
             printf("combined_sigma.tkcrs written to %s\n", path.c_str());
         }
+        if (sigma.has_sigma2()) printf("sigma_verify.json written to %s\n", sigma.write_sigma_verify(out_dir).c_str());
         printf("Total: %.3f s\n", Prover_now() - t0);
     } catch (const std::exception &ex) {
         fprintf(stderr, "trusted-setup: %s\n", ex.what());

@@ -221,6 +221,46 @@ struct Sigma {
     uint64_t archive_bytes() const {
         return 96ull * (xy_powers.len() + gamma_inv_o_inst.len() + eta_inv_li_o_inter_alpha4_kj.len() + delta_inv_li_o_prv.len() + 29) + 10 * 192 + 65536;
     }
+    // <out_dir>/sigma_verify.json: what the reference's `verify` reads (verify-rust/src/lib.rs:68-71) — SigmaVerify { G, H, sigma_1 { x, y },
+    // sigma_2 { alpha, alpha2, alpha3, alpha4, gamma, delta, eta, x, y }, lagrange_KL } (libs/src/group_structures/mod.rs:849-860) through
+    // serde_json's pretty writer (libs/src/iotools/mod.rs:210-218); a point is {"x": hex, "y": hex} with the coordinate as ONE big-endian
+    // hex number over all its limbs (G1serde / G2serde: iotools/mod.rs:986-1059 — for G2 the 96-byte Fp2 element, imaginary part in the
+    // high half, as the fixed generator of setup/trusted-setup/src/main.rs:75-78 is written).  The reader parses with from_hex, so any
+    // "0x" + even-length hex is accepted; the digit count here (96 / 192) is ICICLE's own as far as known — parity of the exact text unpinned.
+    std::string sigma_verify_json() const {
+        auto hex_be = [](const uint8_t *le, size_t n) {
+            static const char *d = "0123456789abcdef";
+            std::string s = "0x";
+            for (size_t i = n; i-- > 0;) s += d[le[i] >> 4], s += d[le[i] & 15];
+            return s;
+        };
+        auto point = [&](const uint8_t *rec, size_t coord_bytes, const std::string &pad) {
+            return "{\n" + pad + "  \"x\": \"" + hex_be(rec, coord_bytes) + "\",\n" + pad + "  \"y\": \"" + hex_be(rec + coord_bytes, coord_bytes) + "\"\n" + pad + "}";
+        };
+        auto g1 = [&](size_t i, const std::string &pad) { return point(reinterpret_cast<const uint8_t *>(&singles.at(i)), 48, pad); };
+        auto g2p = [&](size_t i, const std::string &pad) { return point(g2.at(i).data(), 96, pad); };
+        static const char *names[9] = {"alpha", "alpha2", "alpha3", "alpha4", "gamma", "delta", "eta", "x", "y"};
+        std::string doc = "{\n  \"G\": " + g1(0, "  ") + ",\n  \"H\": " + g2p(0, "  ") + ",\n  \"sigma_1\": {\n    \"x\": " + g1(1, "    ") + ",\n    \"y\": " +
+                          g1(2, "    ") + "\n  },\n  \"sigma_2\": {\n";
+        for (int k = 0; k < 9; k++) doc += std::string("    \"") + names[k] + "\": " + g2p(1 + k, "    ") + (k < 8 ? ",\n" : "\n");
+        doc += "  },\n  \"lagrange_KL\": " + g1(5, "  ") + "\n}";
+        return doc;
+    }
+    bool has_sigma2() const {
+        for (const auto &p : g2)
+            for (uint8_t b : p)
+                if (b) return true;
+        return false;
+    }
+    std::string write_sigma_verify(const std::string &out_dir) const {
+        std::string path = out_dir + "/sigma_verify.json";
+        std::ofstream f(path);
+        if (!f) throw Error("cannot write " + path);
+        f << sigma_verify_json();
+        f.close();
+        if (!f) throw Error("short write on " + path);
+        return path;
+    }
     // <out_dir>/combined_sigma.rkyv and <out_dir>/sigma_preprocess.rkyv, the containers the reference's `prove` / `preprocess` open
     void write_rkyv(const std::string &out_dir, const SetupParams &sp) const {
         if (archive_bytes() >= (1ull << 31)) throw Error("this reference string does not fit an rkyv archive (32-bit relative pointers); use the .tkcrs payload");
