@@ -397,7 +397,10 @@ def test_binaries_under_the_cli_argv(gpu, tmp_path):
                 [str(rt / "bin" / "prove")] + backend_output_args(dirs["prove"])):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, (cmd, r.stdout, r.stderr)
-    assert os.path.exists(dirs["setup"] / "combined_sigma.rkyv") and os.path.exists(dirs["setup"] / "sigma_preprocess.rkyv")
+    # the files tokamak-cli checks for before it spawns the next stage (PREPROCESS_ / PROVE_ / VERIFY_REQUIRED_FILES, cli.ts:91-109)
+    for required in ("sigma_preprocess.rkyv", "combined_sigma.rkyv", "sigma_verify.json"):
+        assert os.path.exists(dirs["setup"] / required), required
+    assert os.path.exists(dirs["preprocess"] / "preprocess.json") and os.path.exists(dirs["prove"] / "proof.json")
     # the same preprocess.json as with the library named explicitly (the round-2 invocation)
     explicit = tmp_path / "explicit"
     explicit.mkdir()
