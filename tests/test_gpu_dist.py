@@ -131,3 +131,29 @@ def test_loopback_msm_multi_ex_sharded_row_interleaved_tables(gpu, oracle, world
             assert (aff[96 * k:96 * (k + 1)] == w).all(), (r, k)
     for c in comms:
         c.close()
+
+
+def test_loopback_rendezvous_times_out_instead_of_hanging(gpu, oracle, monkeypatch):
+    """a rank that never reaches the collective (it failed earlier) must not hang its peers: the loopback rendezvous gives up after
+    TKMK_LOOPBACK_TIMEOUT_S and the waiting rank gets an error; the group is then unusable and says so at once"""
+    import time
+    from tkmk import dist
+    monkeypatch.setenv("TKMK_LOOPBACK_TIMEOUT_S", "2")
+    comms = dist.loopback_comms(2)
+    s, p = oracle.fr_random(91, 8), oracle.g1_random_bases(92, 8)
+
+    def body(c):
+        if c.rank == 1:
+            return "absent"                                  # never calls the collective entry
+        t0 = time.time()
+        with pytest.raises(dist.DistError) as e:
+            c.msm_sharded(s, p)
+        assert "did not reach the collective" in str(e.value) and 1.5 < time.time() - t0 < 30
+        t0 = time.time()
+        with pytest.raises(dist.DistError):
+            c.msm_sharded(s, p)                              # broken group: no second wait
+        assert time.time() - t0 < 1.5
+        return "timed out"
+    assert dist.run_ranks(comms, body) == ["timed out", "absent"]
+    for c in comms:
+        c.close()

@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -32,16 +34,30 @@ struct loop_group {
     // the virtual ranks — one host thread each — take turns on the device and give the turn up while they wait in a collective
     std::mutex device_turn;
     explicit loop_group(int w) : world(w), send(w, nullptr), recv(w, nullptr) {}
-    void barrier() {
+    bool broken = false;   // a rendezvous timed out: every later one fails at once instead of waiting again
+    // false: a peer did not arrive within the limit (it failed before its collective, or never made the call) — the test transport
+    // turns what would be a hang into an error on the ranks that did arrive
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
         const uint64_t gen = generation;
         if (++arrived == world) {
             arrived = 0;
             generation++;
             cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return generation != gen; });
+            return true;
         }
+        if (!cv.wait_for(lk, std::chrono::seconds(rendezvous_timeout_s()), [&] { return generation != gen || broken; }) || broken) {
+            broken = true;
+            cv.notify_all();
+            return false;
+        }
+        return true;
+    }
+    static int rendezvous_timeout_s() {   // TKMK_LOOPBACK_TIMEOUT_S (default 180), read at every rendezvous
+        const char *e = getenv("TKMK_LOOPBACK_TIMEOUT_S");
+        int x = e ? atoi(e) : 180;
+        return x < 1 ? 1 : x;
     }
 };
 
@@ -102,12 +118,13 @@ static tkmk_error transport_all_gather(tkmk_comm *c, device_turn &turn, const vo
         TKD_HIP(hipDeviceSynchronize());   // this rank's send buffer is complete before a peer reads it
         turn.give();
         g.send[c->rank] = send;
-        g.barrier();                        // every rank has published
+        bool met = g.barrier();             // every rank has published
         hipError_t e = hipSuccess;
-        for (int q = 0; q < g.world && e == hipSuccess; q++)
+        for (int q = 0; met && q < g.world && e == hipSuccess; q++)
             e = hipMemcpy((uint8_t *)recv + (size_t)q * bytes, g.send[q], bytes, hipMemcpyDeviceToDevice);
-        g.barrier();                        // every rank has read: the send buffers may be reused
+        met = met && g.barrier();           // every rank has read: the send buffers may be reused
         turn.take();
+        if (!met) return fail(TKMK_ERR_UNKNOWN, "loopback all_gather: a peer rank did not reach the collective");
         TKD_HIP(e);
         return TKMK_SUCCESS;
     }
@@ -122,12 +139,13 @@ static tkmk_error transport_all_to_all(tkmk_comm *c, device_turn &turn, const vo
         TKD_HIP(hipDeviceSynchronize());
         turn.give();
         g.send[c->rank] = send;
-        g.barrier();
+        bool met = g.barrier();
         hipError_t e = hipSuccess;
-        for (int q = 0; q < g.world && e == hipSuccess; q++)
+        for (int q = 0; met && q < g.world && e == hipSuccess; q++)
             e = hipMemcpy((uint8_t *)recv + (size_t)q * bytes, (const uint8_t *)g.send[q] + (size_t)c->rank * bytes, bytes, hipMemcpyDeviceToDevice);
-        g.barrier();
+        met = met && g.barrier();
         turn.take();
+        if (!met) return fail(TKMK_ERR_UNKNOWN, "loopback all_to_all: a peer rank did not reach the collective");
         TKD_HIP(e);
         return TKMK_SUCCESS;
     }
