@@ -42,6 +42,32 @@ def test_find_degree_and_optimize_size(P, gpu, oracle, xs, ys, xd, yd):
     assert (z.x_size, z.y_size) == (4, 4)
 
 
+@pytest.mark.parametrize("xs,ys,cells", [
+    (4096, 512, "dense"),                                    # 2^21 elements
+    (8192, 512, [(4100, 300)]),                              # half the rows and 40 % of the columns empty
+    (2048, 2048, [(0, 0)]),                                  # one coefficient in the far corner: everything else is scanned and found empty
+    (2048, 2048, [(2047, 0), (0, 2047)]),                    # the extremes sit in different cells
+    (16384, 256, [(9, 255), (16000, 3)]),
+    (2048, 1024, [(5, 1000), (1200, 1001), (2000, 31), (7, 32)]),   # the y maximum inside a 32-column slab, reached in a late row
+    (1, 1 << 21, [(0, 77)]), ((1 << 21), 1, [(123456, 0)]),  # degenerate shapes
+    (4096, 512, [])])                                        # the zero polynomial
+def test_find_degree_on_large_matrices(P, gpu, oracle, xs, ys, cells):
+    """find_degree on matrices of 2^21 .. 2^22 elements (the grid-stride loop of k_find_degree, several elements per lane): the oracle's
+    answer whatever the support looks like.  (An early-exit variant that reads such matrices from the top was measured in round 3 and
+    dropped: 231.7-234.1 ms per configs[3] proof against 230.8 with the full scan — at 3 TB/s the scan is already cheap.)"""
+    if cells == "dense":
+        m = np.asarray(oracle.fr_random(7, xs * ys)).copy()
+    else:
+        m = np.zeros(32 * xs * ys, np.uint8)
+        for k, (i, j) in enumerate(cells):
+            m[32 * (i * ys + j)] = 1 + k
+    p = P.from_coeffs(m, xs, ys)
+    want = oracle.poly_find_degree(m, xs, ys)
+    assert p.find_degree() == want
+    if cells and cells != "dense":
+        assert want == (max(i for i, _ in cells), max(j for _, j in cells))
+
+
 def test_resize_and_mul_monomial(P, gpu, oracle):
     xs, ys = 32, 64
     m = _sparse_box(oracle, 7, xs, ys, 20, 40)
