@@ -81,3 +81,14 @@ MORE = (0, 3, 7, 9)
 for i in MORE:
     shutil.copy(lib + "r1cs/subcircuit%d.r1cs" % i, dst2 + "/r1cs/")
 json.dump([e for e in json.load(open(lib + "subcircuitInfo.json")) if e["id"] in MORE], open(dst2 + "/subcircuitInfo.json", "w"))
+
+# The rest of the production library (the seven largest subcircuits, 270-540 KB each) with the library's own subcircuitInfo.json and
+# setupParams.json, so that the three directories together are the whole library the reference ships (tests/real_library.py
+# assembles them into one directory for the reader / row-evaluation / setup -> preprocess -> prove tests).  Binary data, nothing executed.
+dst3 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "qap_rest")
+os.makedirs(dst3 + "/r1cs", exist_ok=True)
+REST = tuple(i for i in range(14) if i not in (1, 2, 12) + MORE)
+for i in REST:
+    shutil.copy(lib + "r1cs/subcircuit%d.r1cs" % i, dst3 + "/r1cs/")
+shutil.copy(lib + "subcircuitInfo.json", dst3 + "/subcircuitInfo.json")
+shutil.copy(lib + "setupParams.json", dst3 + "/setupParams.json")

@@ -85,6 +85,26 @@ def test_cli_argv_finds_the_library_of_the_installation(tkmk, tmp_path, name):
     assert r.returncode == 1 and NO_DEVICE in r.stderr, r.stderr
 
 
+@pytest.mark.parametrize("name", sorted(CLI_ARGV))
+def test_two_cached_snapshots_are_refused_and_tmp_is_never_searched(tkmk, tmp_path, name):
+    """the reference opens the snapshot its embedded integrity hash names; this resolver has no hash, so two candidates are an error that
+    lists both (no newest-mtime guess), and without HOME / XDG_CACHE_HOME nothing under $TMPDIR or /tmp is ever taken"""
+    root = tmp_path / "xdg" / "tokamak-zk-evm" / "subcircuit-library"
+    a, b = _library(root / "2.0.6-aaaaaaaaaaaa"), _library(root / "2.0.7-bbbbbbbbbbbb")
+    r = _run(name, CLI_ARGV[name](tmp_path), {"XDG_CACHE_HOME": str(tmp_path / "xdg")}, home=tmp_path / "home")
+    assert r.returncode == 1 and "more than one subcircuit-library snapshot" in r.stderr and str(a) in r.stderr and str(b) in r.stderr
+    # the explicit choices still work with both present
+    if not _has_gpu():
+        r = _run(name, CLI_ARGV[name](tmp_path), {"XDG_CACHE_HOME": str(tmp_path / "xdg"), "TKMK_SUBCIRCUIT_LIBRARY": str(b)}, home=tmp_path / "home")
+        assert r.returncode == 1 and NO_DEVICE in r.stderr and ("Subcircuit library: " + str(b)) in r.stdout
+    # a snapshot under $TMPDIR is not a candidate when there is no per-user cache directory
+    _library(tmp_path / "tmpdir" / "tokamak-zk-evm" / "subcircuit-library" / "planted")
+    env = {k: v for k, v in os.environ.items() if k not in ("TKMK_SUBCIRCUIT_LIBRARY", "XDG_CACHE_HOME", "HOME")}
+    env["TMPDIR"] = str(tmp_path / "tmpdir")
+    r = subprocess.run([os.path.join(BIN, name)] + CLI_ARGV[name](tmp_path), capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 1 and "--subcircuit-library is required" in r.stderr and "planted" not in r.stdout
+
+
 def test_flag_forms_clap_accepts(tkmk, tmp_path):
     """`--flag value` and `--flag=value`, any order; usage errors exit 2 like clap's"""
     lib = _library(tmp_path)

@@ -51,13 +51,14 @@ def _assert_boxes_equal_the_reference_table(boxes, sp, who):
     but the source the table ships with builds B = bXY + rB_X(X) t_{m_I}(X) + rB_Y(Y) t_{s_max}(Y) with
     low_degree_x_times_vanishing(&rB_X, l_D - l) (prove/src/lib.rs:1746-1754, :48-57) and bXY of X-degree < m_I
     (libs/src/polynomial_structures/mod.rs:154-160), i.e. x_degree = m_I + 1 = 4097 -> 4098 rows, and the verifier divides by
-    t_{m_I} too (verify-rust/src/lib.rs) — the report was written by an earlier revision (its setup_params also carry that
-    revision's s_D = 14 / m_D = 26591 against 17 / 43824 in the library the tree ships) whose blinding term had another exponent.  The y side of the same row (258 = s_max + 2) does agree and is asserted.  All other 18 rows match exactly."""
+    t_{m_I} too (verify-rust/src/lib.rs) — the report was written by an earlier revision of `prove` whose blinding term had another
+    exponent (its setup_params block is the library the tree still ships: s_D = 14, m_D = 26591, compared whole below).  The y side of the
+    same row (258 = s_max + 2) does agree and is asserted.  All other 18 rows match exactly."""
     golden = json.load(open(os.path.join(HERE, "golden", "encode_dims.json")))
-    # the parameters every box depends on; s_D / m_D (count of subcircuit kinds, private wires) moved since the report was written
-    # (14 / 26591 there, 17 / 43824 in the committed library) and enter no commitment's degree
-    for k in ("n", "s_max", "l", "l_D", "l_free", "l_user", "l_user_out"):
-        assert golden["setup_params"][k] == sp[k], "the fixture circuit is not the production shape: " + k
+    pins = json.load(open(os.path.join(HERE, "golden", "pins.json")))
+    # the report's setup_params, the library the tree ships (tests/golden/pins.json, = tests/golden/qap_rest/setupParams.json) and the
+    # synthetic production-shape fixture (tools/prove_bench.py PRODUCTION_*) are ONE set of nine values
+    assert golden["setup_params"] == pins["setup_params"] == sp, "the fixture circuit is not the production shape"
     want = {k: (v["x"], v["y"]) for k, v in golden["boxes"].items()}
     assert sorted(want) == sorted(COMMIT_ORDER) and sorted(boxes) == sorted(COMMIT_ORDER), (who, sorted(boxes))
     m_i = sp["l_D"] - sp["l"]

@@ -18,16 +18,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-# committed reference data (tests/golden/make_pins.py): three small subcircuits and four mid-size ones of the production library
-# (bufferPubOut, bufferEVMIn with 1201 wires, DecToBit, Accumulator) — seven of its fourteen kinds
-FIXTURES = [("qap", 1), ("qap", 2), ("qap", 12), ("qap_more", 0), ("qap_more", 3), ("qap_more", 7), ("qap_more", 9)]
+# committed reference data (tests/golden/make_pins.py): ALL fourteen kinds of the production library — three small subcircuits, four
+# mid-size ones (bufferPubOut, bufferEVMIn, DecToBit, Accumulator) and the seven largest (bufferPrvIn, ALU1, ALU2, SubExpBatch with 5093
+# wires, Poseidon, JubjubExpBatch, VerifyMerkleProof: 270-540 KB each)
+FIXTURES = [("qap", 1), ("qap", 2), ("qap", 12), ("qap_more", 0), ("qap_more", 3), ("qap_more", 7), ("qap_more", 9)] + [
+    ("qap_rest", i) for i in (4, 5, 6, 8, 10, 11, 13)]
 
 
 def _library(oracle):
     from tkmk import r1cs
     bins = []
     for d, sid in FIXTURES:
-        infos = {e["id"]: e for e in json.load(open(os.path.join(GOLDEN, d, "subcircuitInfo.json")))}
+        infos = {e["id"]: e for e in json.load(open(os.path.join(GOLDEN, d, "subcircuitInfo.json")))}      # qap_rest holds the library's whole file
         b = r1cs.R1csBinary.read(os.path.join(GOLDEN, d, "r1cs", "subcircuit%d.r1cs" % sid))
         assert b.n_wires == infos[sid]["Nwires"]
         bins.append(b)
@@ -39,7 +41,7 @@ def _fr(oracle, vals):
 
 
 def test_r1cs_library_eval_vs_oracle_sparse_rows(gpu, oracle):
-    """seven kinds of the reference's production library (up to 1201 wires), every kind placed 3 times in mixed order, random witnesses with zeros / ones / r-1 mixed in, placements fewer than s_max:
+    """all fourteen kinds of the reference's production library (up to 5093 wires, 3936 rows), every kind placed 3 times in mixed order, random witnesses with zeros / ones / r-1 mixed in, placements fewer than s_max:
     u / v / w (n x s_max, element (row, placement)) must equal the oracle's row evaluation of each placement, zeros elsewhere"""
     from tkmk import witness
     tk = gpu
@@ -47,9 +49,11 @@ def test_r1cs_library_eval_vs_oracle_sparse_rows(gpu, oracle):
     n_rows = [b.n_constraints for b in bins]
     n_wires = [b.n_wires for b in bins]
     n = 1 << max(6, (max(n_rows) - 1).bit_length())
-    s_max = 32
+    s_max = 64
     rnd = random.Random(2026)
-    order = [0, 1, 2, 3, 4, 5, 6, 6, 2, 0, 5, 1, 3, 4, 4, 6, 0, 3, 1, 5, 2]   # 21 placements <= s_max, every one of the 7 kinds 3 times
+    order = list(range(len(bins))) * 3                                 # 42 placements <= s_max, every one of the 14 kinds 3 times
+    rnd.shuffle(order)
+    assert n == 4096                                                   # the production library's n (setupParams.json)
     lib = witness.R1csLibrary(csrs, n_rows, n_wires)
     offsets, chunks, pos = [], [], 5                                   # variables do not start at element 0 and are not back to back
     for k, kind in enumerate(order):

@@ -42,6 +42,8 @@ int main(int argc, char **argv) {
     const std::string crs_dir = a.get("--crs"), synth_dir = a.get("--synthesizer-stat"), out_dir = a.get("--output");
     try {
         const std::string lib_dir = args::resolve_subcircuit_library(a);
+        printf("Subcircuit library: %s\n", lib_dir.c_str());   // which circuit this run is for (the reference names it by an embedded hash)
+        fflush(stdout);
         int ndev = 0;
         if (tkmk_device_count(&ndev) != TKMK_SUCCESS || ndev < 1) throw Error("no HIP device: the MI355X backend has no CPU fallback");
         check(tkmk_set_device(0), "set_device");   // check_device(): device id 0 (libs/src/utils/mod.rs:88-110)

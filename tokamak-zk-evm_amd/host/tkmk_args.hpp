@@ -10,6 +10,7 @@
 // and, when it is absent, look for the library where a tokamak-cli installation has it (resolve_subcircuit_library below).
 // Flags are parsed the way clap does for `#[arg(long)]` options: `--flag value` and `--flag=value`, any order, each at most once.
 #pragma once
+#include <algorithm>
 #include <dirent.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -107,12 +108,13 @@ inline std::string exe_dir() {
     return s == std::string::npos ? "" : p.substr(0, s);
 }
 
-// cache_root_dir() of the reference (libs/src/subcircuit_library.rs:112-128), Linux branch
+// cache_root_dir() of the reference (libs/src/subcircuit_library.rs:112-128), Linux branch — WITHOUT its last two fallbacks ($TMPDIR, /tmp):
+// the reference opens exactly the snapshot named by the integrity hash it embeds, so a world-writable directory is harmless there; this
+// resolver has no such hash and must not pick up a directory anybody on the machine may have written.  "" = no per-user cache directory.
 inline std::string cache_root_dir() {
     if (const char *x = std::getenv("XDG_CACHE_HOME"); x && *x) return x;
     if (const char *h = std::getenv("HOME"); h && *h) return std::string(h) + "/.cache";
-    if (const char *t = std::getenv("TMPDIR"); t && *t) return t;
-    return "/tmp";
+    return "";
 }
 
 /* --subcircuit-library given: that directory (canonicalised; the reference panics "cannot resolve subcircuit library path {path}",
@@ -121,7 +123,9 @@ inline std::string cache_root_dir() {
  *   2. next to the installation: <exe>/../resource/qap-compiler/library, <exe>/../subcircuit-library, <exe>/../library
  *      (tokamak-cli keeps binaries under <runtime>/bin and resources under <runtime>/resource, runtime.ts:465-485)
  *   3. the directory a reference release binary of the same installation has materialised:
- *      <cache>/tokamak-zk-evm/subcircuit-library/<snapshot>/library (newest snapshot that holds setupParams.json)
+ *      <cache>/tokamak-zk-evm/subcircuit-library/<snapshot>/library, <cache> = $XDG_CACHE_HOME or $HOME/.cache only — if exactly ONE
+ *      snapshot holds a setupParams.json; several snapshots are an error that lists them (no guessing by modification time)
+ * The binaries print the directory they resolved ("Subcircuit library: ...") before they read it.
  * Nothing found: the reference's message for a binary without an embedded library, plus where this one looked. */
 inline std::string resolve_subcircuit_library(const Parsed &p) {
     if (p.has("--subcircuit-library")) {
@@ -143,23 +147,35 @@ inline std::string resolve_subcircuit_library(const Parsed &p) {
     std::string exe = exe_dir();
     if (!exe.empty())
         for (const char *rel : {"/../resource/qap-compiler/library", "/../subcircuit-library", "/../library"})
-            if (ok(exe + rel)) return exe + rel;
-    std::string snapshots = cache_root_dir() + "/tokamak-zk-evm/subcircuit-library";
-    tried.push_back(snapshots + "/*/library");
-    std::string best;
-    time_t best_time = 0;
-    if (DIR *d = ::opendir(snapshots.c_str())) {
-        while (dirent *e = ::readdir(d)) {
-            std::string name = e->d_name;
-            if (name == "." || name == ".." || name.rfind("staging-", 0) == 0) continue;
-            std::string lib = snapshots + "/" + name + "/library";
-            struct stat st;
-            if (is_library_dir(lib) && ::stat((lib + "/setupParams.json").c_str(), &st) == 0 && (best.empty() || st.st_mtime > best_time))
-                best = lib, best_time = st.st_mtime;
+            if (ok(exe + rel)) {   // canonical, so that the "Subcircuit library:" line names the directory without a /bin/.. detour
+                char real[PATH_MAX];
+                return ::realpath((exe + rel).c_str(), real) ? std::string(real) : exe + rel;
+            }
+    const std::string cache = cache_root_dir();
+    if (!cache.empty()) {
+        std::string snapshots = cache + "/tokamak-zk-evm/subcircuit-library";
+        tried.push_back(snapshots + "/*/library");
+        std::vector<std::string> found;
+        if (DIR *d = ::opendir(snapshots.c_str())) {
+            while (dirent *e = ::readdir(d)) {
+                std::string name = e->d_name;
+                if (name == "." || name == ".." || name.rfind("staging-", 0) == 0) continue;
+                std::string lib = snapshots + "/" + name + "/library";
+                if (is_library_dir(lib)) found.push_back(lib);
+            }
+            ::closedir(d);
         }
-        ::closedir(d);
+        if (found.size() == 1) return found[0];
+        if (found.size() > 1) {
+            // the reference would open the one whose name is its embedded integrity hash; without that hash any choice is a guess, and a
+            // wrong guess is a CRS or a proof for another circuit
+            std::sort(found.begin(), found.end());
+            std::string msg = "more than one subcircuit-library snapshot found, refusing to pick one:";
+            for (const std::string &f : found) msg += " " + f + ";";
+            msg += " set TKMK_SUBCIRCUIT_LIBRARY or pass --subcircuit-library";
+            throw Error(msg);
+        }
     }
-    if (!best.empty()) return best;
     std::string msg = "--subcircuit-library is required: no subcircuit library found (looked in";
     for (const std::string &t : tried) msg += " " + t + ";";
     msg += " set TKMK_SUBCIRCUIT_LIBRARY or pass the flag)";

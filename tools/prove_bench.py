@@ -37,7 +37,14 @@ def stage_crs(tkmk, inst):
     return Sigma.gen(inst["setup_params"], tau, inst["qap"], inst["infos"], g, h2), g
 
 
-def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, seed=0x746F6B616D616B04, profile_host=False,
+# The production library's parameters that the synthetic full-size circuits share with it (packages/frontend/qap-compiler/subcircuits/library/
+# setupParams.json = tests/golden/pins.json "setup_params"): s_D = 14 subcircuit kinds (4 public buffers + 10 gate kinds here), m_D = 26591
+# global wires, i.e. 21767 private ones, spread over the gate kinds; l = 728, l_D = 4824, n = 4096 as before.
+PRODUCTION_GATE_KINDS = 10
+PRODUCTION_N_PRV = [2177] * 9 + [2174]
+
+
+def run(s_max=256, placements=None, pool=24, n_prv=None, repeat=3, check=False, seed=0x746F6B616D616B04, profile_host=False,
         dist=None, comm_device="cuda"):
     """dist = torch.distributed with an initialised group: every rank calls run() with the same arguments, replicates the
     polynomial work and runs only the commitments it owns (Sigma1.dist, sharding.commits_balanced)"""
@@ -45,7 +52,7 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
     import tkmk
     from tkmk.prove import Prover, fr, random_mixer, run_rounds
     t = time.perf_counter()
-    inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=13, n_out=80, n_in=170, n_prv=n_prv, k_out=65, k_pub=20,
+    inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=PRODUCTION_GATE_KINDS, n_out=80, n_in=170, n_prv=PRODUCTION_N_PRV if n_prv is None else n_prv, k_out=65, k_pub=20,
                                   l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements, bit_fraction=0.6)
     tmp = tempfile.mkdtemp(prefix="tkmk_prove_bench_")
     synth_circuit.write(inst, tmp, synth_files=False)
@@ -116,7 +123,7 @@ def run(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, check=False, 
         "generate_s": round(gen_s, 2), "stage_crs_s": round(crs_s, 2), "checked": bool(check)}
 
 
-def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0x746F6B616D616B04, compare=False):
+def run_native(s_max=256, placements=None, pool=24, n_prv=None, repeat=3, seed=0x746F6B616D616B04, compare=False):
     """the same workload through tokamak-zk-evm_amd/bin/prove (C++ host side): every input as a file in the reference's formats,
     the CRS as the TKCRS001 payload; times are the binary's own printout (inputs + CRS loading included in its total)"""
     import re
@@ -124,7 +131,7 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
     import subprocess
     import synth_circuit
     import tkmk
-    inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=13, n_out=80, n_in=170, n_prv=n_prv, k_out=65, k_pub=20,
+    inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=PRODUCTION_GATE_KINDS, n_out=80, n_in=170, n_prv=PRODUCTION_N_PRV if n_prv is None else n_prv, k_out=65, k_pub=20,
                                   l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements, bit_fraction=0.6)
     tmp = tempfile.mkdtemp(prefix="tkmk_prove_native_")
     try:
@@ -186,14 +193,15 @@ def run_native(s_max=256, placements=None, pool=24, n_prv=3000, repeat=3, seed=0
         "equals_python_prover": same}
 
 
-def stage_files(s_max=256, placements=None, pool=24, n_prv=3000, seed=0x746F6B616D616B04, tmp=None):
+def stage_files(s_max=256, placements=None, pool=24, n_prv=None, seed=0x746F6B616D616B04, tmp=None):
     """everything `prove` reads, as files in the reference's formats: <tmp>/qap (subcircuit library), <tmp>/synth (the synthesizer's
     three documents), <tmp>/crs/combined_sigma.tkcrs (the fixed-tau trusted setup of that circuit, generated on the device by
     tkmk/setup.py).  -> dict(dirs, setup params, counts); the caller removes `tmp`"""
     import synth_circuit
     import tkmk
     t = time.perf_counter()
-    inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=13, n_out=80, n_in=170, n_prv=n_prv, k_out=65, k_pub=20,
+    inst = synth_circuit.generate(random.Random(seed), s_max=s_max, n_gate_kinds=PRODUCTION_GATE_KINDS, n_out=80, n_in=170,
+                                  n_prv=PRODUCTION_N_PRV if n_prv is None else n_prv, k_out=65, k_pub=20,
                                   l_free=128, l_extra=600, n=4096, m_i=4096, pool=pool, used_placements=placements, bit_fraction=0.6)
     tmp = tempfile.mkdtemp(prefix="tkmk_prove_files_") if tmp is None else tmp
     synth_circuit.write(inst, tmp)
@@ -217,7 +225,7 @@ def stage_files(s_max=256, placements=None, pool=24, n_prv=3000, seed=0x746F6B61
                 sp["n"], sp["l_D"] - sp["l"], sp["s_max"], len(inst["placement_variables"]), inst["r1cs_rows"])}
 
 
-def run_service(s_max=256, placements=None, pool=24, n_prv=3000, repeat=5, warmup=1, seed=0x746F6B616D616B04, check=False):
+def run_service(s_max=256, placements=None, pool=24, n_prv=None, repeat=5, warmup=1, seed=0x746F6B616D616B04, check=False):
     """the same workload through the resident prover (libtkmk_prover.so: host/tkmk_service.hpp): context opened once, then `repeat`
     proofs from the synthesizer's files to proof.json; per-stage seconds are the library's own (median over the repeats)"""
     import shutil
@@ -269,7 +277,7 @@ def main():
     ap.add_argument("--s-max", type=int, default=256)
     ap.add_argument("--placements", type=int, default=None, help="used placements (default: all s_max; the reference's run has 166)")
     ap.add_argument("--pool", type=int, default=24, help="distinct gate witnesses")
-    ap.add_argument("--n-prv", type=int, default=3000)
+    ap.add_argument("--n-prv", type=int, default=None, help="private wires per gate kind (default: the production library's 21767 over 10 kinds)")
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--profile-host", action="store_true", help="cProfile of one more init + rounds, printed to stderr")

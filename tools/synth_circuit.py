@@ -110,7 +110,11 @@ def generate(rnd, s_max=8, n_gate_kinds=2, n_out=2, n_in=3, n_prv=6, k_pub=2, us
     assert k_block >= 0 and l_free & (l_free - 1) == 0
     l = l_free + k_fn
     subs = [buffer(i, name, k) for i, (name, k) in enumerate(zip(BUFFER_NAMES, (k_out, k_pub, k_block, k_fn)))]
-    subs += [random_gates(4 + g, rnd, n_out, n_in, n_prv, bit_fraction=bit_fraction) for g in range(n_gate_kinds)]
+    # n_prv: one count for every gate kind, or a list with one count per kind (the production shape: private wires summing to the
+    # real library's m_D - l_D = 21767)
+    prv_counts = list(n_prv) if isinstance(n_prv, (list, tuple)) else [n_prv] * n_gate_kinds
+    assert len(prv_counts) == n_gate_kinds
+    subs += [random_gates(4 + g, rnd, n_out, n_in, prv_counts[g], bit_fraction=bit_fraction) for g in range(n_gate_kinds)]
     pub_base = (0, l_user_out, l_user, l_free)        # first public wire of each buffer
     # interface wires: constant + the non-public side of the buffers, constant + outputs + inputs of the gates
     need_iface = sum(1 + s.n_out for s in subs[:4]) + sum(1 + s.n_out + s.n_in for s in subs[4:])
