@@ -83,6 +83,20 @@ class _stdout_to_stderr:
         os.close(self.saved)
 
 
+def dist_size(comm):
+    from tkmk import dist as tkdist
+    return int(tkdist.lib().tkmk_comm_size(comm.handle))
+
+
+def _per_rank(dist, comm_device, torch, values):
+    """values: dict of numbers of THIS rank -> list of every rank's dict (rank order); one rank: [values]"""
+    if dist is None:
+        return [values]
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, values)
+    return box
+
+
 def _read_sections(tkmk, proofs):
     """per-proof section times of the event profiler since the last reset -> ({name: {ms_per_proof, launches_per_proof}}, ntt ms per proof,
     (accumulate ms, launches))"""
@@ -108,6 +122,10 @@ def main():
                     "commitments sharded by grid row, one all-gather per round) instead of N independent proofs; value = 2^22 / time per proof, scaling strong")
     ap.add_argument("--msm-sharded", action="store_true", help="N > 1: also time the point-sharded MSM of BASELINE.json configs[4] (2^25 points per rank)")
     ap.add_argument("--msm-sharded-logn", type=int, default=25)
+    ap.add_argument("--ntt-sharded", action="store_true", help="also time BASELINE.json configs[2] over the N GPUs: 256 x 2^20 NTTs split by batch index "
+                    "(no collective), and ONE 2^25-point bivariate transform through the sharded prover's transform (one all-to-all); N = 1 runs over a "
+                    "one-rank RCCL communicator")
+    ap.add_argument("--ntt-sharded-logn", type=int, default=20, help="length of one NTT of the batch leg (2^20 = configs[2])")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the serialised profiling pass (for a rocprofv3 run whose kernel "
@@ -164,11 +182,19 @@ def main():
         if one_proof and comm_device != "cuda":
             raise SystemExit("--one-proof runs over libtkmk_dist.so (RCCL): needs --dist-backend nccl")
         shard_comm = None
-        if one_proof:
+        comm_report = None
+        if (one_proof or args.msm_sharded or args.ntt_sharded) and comm_device == "cuda":
+            # the communicator of libtkmk_dist.so (RCCL) for every sharded leg of this run, and ITS OWN account of who takes part: each
+            # rank's line (size / rank as the communicator holds them, ncclCommCount, RCCL version, device PCI bus id and UUID) gathered
+            # over the communicator itself — N ranks on N distinct devices, or the line says otherwise
             from tkmk import dist as tkdist
             with _stdout_to_stderr():
                 shard_comm = tkdist.comm_from_torch(dist) if dist is not None else tkdist.Comm(tkdist.unique_id(), 1, 0)
-        prover = service.Prover(files["qap"], files["crs"], comm=shard_comm)      # circuit-static state -> HBM, once (sharded: 1/N of the tables)
+            lines = shard_comm.describe_all()
+            comm_report = {"size_reported_by_communicator": dist_size(shard_comm), "ranks": lines,
+                           "distinct_devices": len({(l["pci_bus_id"], l["uuid"]) for l in lines}),
+                           "gathered_with": "tkmk_comm_all_gather_host over this communicator"}
+        prover = service.Prover(files["qap"], files["crs"], comm=shard_comm if one_proof else None)      # circuit-static state -> HBM, once (sharded: 1/N of the tables)
         open_s = time.perf_counter() - t
         jobs_in_flight = 1 if one_proof else world                                # proofs a step completes
         out_dir = os.path.join(files["tmp"], "out_rank%d" % rank)
@@ -220,12 +246,19 @@ def main():
                        "timed region, 1 internal stream: launch duration of the kernel running alone" if streams_default == 1 else
                        "timed region, %d internal streams: QUEUE-INCLUSIVE event times, not kernel durations" % streams_default)
         prover.close()
+        # what each rank did in the timed region, by its own counters (one process per GPU: the library's counters are the rank's)
+        rank_work = _per_rank(dist, comm_device, torch, {"rank": rank, "msm_points": stats["msm.points"] / args.steps, "msm_calls": stats["msm.calls"] / args.steps,
+                                                         "msm_bucket_additions": stats.get("msm.bucket_additions", 0) / args.steps,
+                                                         "ntt_elements": stats["ntt.elements"] / args.steps, "ntt_calls": stats["ntt.calls"] / args.steps,
+                                                         "per_proof_s": {k: round(statistics.median(t_[k] for t_ in timings), 5) for k in timings[0]}})
+
+        msm_sharded = ntt_sharded = None
+        if args.msm_sharded and (world > 1 or shard_comm is not None):         # every rank takes part
+            msm_sharded = _msm_sharded_leg(tkmk, dist, comm_device, rank, world, args.msm_sharded_logn, barrier, torch, shard_comm)
+        if args.ntt_sharded:
+            ntt_sharded = _ntt_sharded_leg(tkmk, dist, comm_device, rank, world, args.ntt_sharded_logn, barrier, torch, shard_comm)
         if shard_comm is not None:
             shard_comm.close()
-
-        msm_sharded = None
-        if dist is not None and world > 1 and args.msm_sharded:         # every rank takes part
-            msm_sharded = _msm_sharded_leg(tkmk, dist, comm_device, rank, world, args.msm_sharded_logn, barrier, torch)
 
         if rank == 0:
             med = {k: statistics.median(t_[k] for t_ in timings) for k in timings[0]}
@@ -294,6 +327,11 @@ def main():
             out["hbm_roofline_whole_step"] = {"achieved_GBps": out["work_per_proof"]["algorithmic_bytes"] / (elapsed / args.steps) / 1e9, "peak_GBps": HBM_PEAK_GBS}
             if msm_sharded is not None:
                 out["msm_sharded"] = msm_sharded
+            if ntt_sharded is not None:
+                out["ntt_sharded"] = ntt_sharded
+            out["comm"] = comm_report if comm_report is not None else {"note": "no libtkmk_dist.so communicator in this run (independent proofs per GPU: "
+                                                                                "torch.distributed carries the timing barrier only)"}
+            out["per_rank"] = rank_work
 
             def leg(key, fn):
                 """a secondary figure must never cost the headline line: its failure is recorded under its key instead"""
@@ -580,7 +618,76 @@ def _ntt_secondary(tkmk):
     return res
 
 
-def _msm_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch):
+def _ntt_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch, comm):
+    """BASELINE.json configs[2] over the N GPUs of the job.
+    batch: 256 independent length-2^logn forward NTTs, natural order, device resident, split by BATCH INDEX — rank r transforms the vectors
+           b = r mod N (independent units, no collective); value = elements of the whole batch / max-over-ranks time.
+    bivariate: ONE 2^25-point transform (16384 x 2048: the domain of prove2's p_comb) through the sharded prover's transform
+           (tkmk_dist_fwd_cols_to_rows: X pass on the rank's columns, ONE all-to-all, Y pass on its rows) and back (tkmk_dist_inv_rows_to_cols);
+           needs the libtkmk_dist.so communicator (RCCL), N = 1: a one-rank communicator."""
+    out = {}
+    n, batch = 1 << logn, 256
+    mine = len(range(rank, batch, world))
+    tkmk.init_ntt_domain_for_size(max(n, 1 << 25))
+    data = tkmk.fr_random_device(SEED + 7 + 16 * rank, n * mine)
+    res = tkmk.DeviceBuffer(32 * n * mine)
+    tkmk.ntt(data, n, batch=mine, out=res)
+    tkmk.native_stats_reset()
+    barrier()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tkmk.ntt(data, n, batch=mine, out=res)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    dt /= steps
+    st = tkmk.native_stats()
+    data.free()
+    res.free()
+    out["batch"] = {"workload": "256 x 2^%d forward NTTs split by batch index over %d rank(s), no collective" % (logn, world),
+                    "ms": dt * 1e3, "elements_per_s": batch * n / dt, "vectors_on_this_rank": mine,
+                    "hbm": {"algorithmic_bytes": ALG_BYTES_PER_NTT_ELEMENT * batch * n, "achieved_GBps_whole_job": ALG_BYTES_PER_NTT_ELEMENT * batch * n / dt / 1e9,
+                            "peak_GBps_per_gpu": HBM_PEAK_GBS, "frac_of_job_peak": ALG_BYTES_PER_NTT_ELEMENT * batch * n / dt / 1e9 / (HBM_PEAK_GBS * world)},
+                    "per_rank_ntt_elements": [w["ntt_elements"] for w in _per_rank(dist, comm_device, torch, {"ntt_elements": st["ntt.elements"] / steps})]}
+    if comm is None:
+        out["bivariate"] = {"skipped": "needs the libtkmk_dist.so communicator (--dist-backend nccl)"}
+        return out
+    xs, ys = 16384, 2048
+    lc, h = ys // world, xs // world
+    coeff = tkmk.fr_random_device(SEED + 9 + 16 * rank, xs * lc)
+    ev = comm.fwd_cols_to_rows(coeff, xs, ys, xs, ys)
+    back = comm.inv_rows_to_cols(ev, xs, ys)
+    same = bool((np.asarray(back.to_host()[:32 * 64]) == np.asarray(coeff.to_host()[:32 * 64])).all())     # round trip, first elements
+    ev.free()
+    back.free()
+    tkmk.native_stats_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev = comm.fwd_cols_to_rows(coeff, xs, ys, xs, ys)
+        tkmk.synchronize()
+        ev.free()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    dt /= steps
+    st = tkmk.native_stats()
+    coeff.free()
+    out["bivariate"] = {"workload": "one %d x %d forward bivariate NTT over %d rank(s): columns r mod N -> X pass -> one all-to-all -> Y pass -> row slabs" % (xs, ys, world),
+                        "entry": "tkmk_dist_fwd_cols_to_rows (C ABI, RCCL on device buffers)", "ms": dt * 1e3, "elements_per_s": xs * ys / dt,
+                        "all_to_all_bytes_sent_per_rank": 32 * h * lc * (world - 1), "round_trip_equal": same,
+                        "per_rank_ntt_elements": [w["ntt_elements"] for w in _per_rank(dist, comm_device, torch, {"ntt_elements": st["ntt.elements"] / steps})]}
+    return out
+
+
+def _msm_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch, comm=None):
     """BASELINE.json configs[4]'s shape: every rank holds 2^logn points of one MSM (generated in HBM from the seed), runs the full
     single-GPU pipeline on its shard, the 144-byte partial results meet in ONE all_gather (RCCL over xGMI) and every rank adds them"""
     from tkmk import dist as tkdist
@@ -593,10 +700,9 @@ def _msm_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch)
     h.free()
     # the C-ABI entry (libtkmk_dist.so: RCCL all_gather on device buffers) when the ranks talk over RCCL; the torch helper for the
     # gloo rehearsal of the same partitioning
-    with _stdout_to_stderr():
-        comm = tkdist.comm_from_torch(dist) if comm_device == "cuda" else None
     run = (lambda: comm.msm_sharded(scalars, bases)) if comm is not None else (lambda: sharding.msm_sharded(tkmk, dist, scalars, bases, device=comm_device))
     run()
+    tkmk.native_stats_reset()
     barrier()
     steps = 3
     t0 = time.perf_counter()
@@ -604,14 +710,15 @@ def _msm_sharded_leg(tkmk, dist, comm_device, rank, world, logn, barrier, torch)
         res = run()
     barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=comm_device)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item()) / steps
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    dt /= steps
+    st = tkmk.native_stats()
     scalars.free()
     bases.free()
-    if comm is not None:
-        comm.close()
-    return {"workload": "2^%d-point BLS12-381 G1 MSM, 2^%d points per rank, one all_gather of 144-byte partial results" % (logn + (world - 1).bit_length(), logn),
+    return {"per_rank": _per_rank(dist, comm_device, torch, {"rank": rank, "msm_points": st["msm.points"] / steps, "msm_bucket_additions": st.get("msm.bucket_additions", 0) / steps}),"workload": "2^%d-point BLS12-381 G1 MSM, 2^%d points per rank, one all_gather of 144-byte partial results" % (logn + (world - 1).bit_length(), logn),
             "entry": "tkmk_msm_sharded (C ABI, RCCL on device buffers)" if comm_device == "cuda" else "tkmk/sharding.py over torch.distributed (%s)" % comm_device,
             "ms_per_msm": dt * 1e3, "points_per_s": n * world / dt, "result_x_lo": int.from_bytes(bytes(res[:8]), "little")}
 

@@ -452,6 +452,12 @@ typedef struct {
 tkmk_error tkmk_poly_expr_eval_views(const tkmk_expr_instr *prog, uint32_t n_instr, const tkmk_expr_leaf *leaves, uint32_t n_leaves,
                                      const tkmk_fr *consts, uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev,
                                      tkmk_stream stream);
+/* The same on ONE ROW SLAB of a larger domain (a rank of the sharded prover, include/tkmk_dist.h ROWS layout): rows [x_first, x_first +
+ * x_rows) of a domain with x_global rows; leaves are x_rows x y_size slabs or broadcast vectors (x_len in {x_rows, 1}); rot_x must be 0 (a
+ * rotation along X crosses slabs: tkmk_dist_rows_rotate makes it beforehand).  Only MUL_X_MINUS_ONE depends on the global row index. */
+tkmk_error tkmk_poly_expr_eval_views_slab(const tkmk_expr_instr *prog, uint32_t n_instr, const tkmk_expr_leaf *leaves, uint32_t n_leaves,
+                                          const tkmk_fr *consts, uint32_t n_consts, uint32_t x_global, uint32_t x_first, uint32_t x_rows,
+                                          uint32_t y_size, tkmk_fr *out_dev, tkmk_stream stream);
 /* eval_x / eval_y / eval (mod.rs:1719-1750): out_dev has y_size / x_size elements; out_host one */
 tkmk_error tkmk_poly_eval_x(const tkmk_fr *coeffs_dev, uint32_t x_size, uint32_t y_size, const tkmk_fr *x, tkmk_fr *out_dev,
                             tkmk_stream stream);

@@ -47,6 +47,46 @@ tkmk_error tkmk_comm_destroy(tkmk_comm *comm);
 int tkmk_comm_rank(const tkmk_comm *comm);
 int tkmk_comm_size(const tkmk_comm *comm);
 const char *tkmk_dist_last_error(void);
+/* One line of JSON text about THIS rank's side of the communicator (at most cap - 1 bytes, 512 is enough): transport, size / rank as held
+ * by the communicator, ncclCommCount / ncclCommUserRank of the RCCL communicator underneath (-1 over the loopback), the RCCL version,
+ * and the rank's device (HIP index, PCI bus id, UUID).  Gathered over the communicator itself (tkmk_comm_all_gather_host) the lines
+ * show N ranks on N distinct devices. */
+tkmk_error tkmk_comm_describe(const tkmk_comm *comm, char *out, size_t cap);
+
+/* ---- host values and agreement ---- */
+/* recv (host, world_size x bytes) <- send (host, bytes) of every rank, rank order: the few values a sharded computation reduces on the
+ * host (degrees, evaluation partials, column totals).  One all-gather through a device staging pair kept with the communicator. */
+tkmk_error tkmk_comm_all_gather_host(tkmk_comm *comm, const void *send, size_t bytes, void *recv);
+tkmk_error tkmk_comm_all_gather_dev(tkmk_comm *comm, const void *send_dev, size_t bytes, void *recv_dev);
+/* recv_dev (bytes) of rank r <- send_dev (bytes) of rank (r - distance) mod world_size, device to device: one place-shift along the ring
+ * (grouped ncclSend / ncclRecv).  The sharded prover's Y shifts: Y^s p moves every rank's columns to the rank s places on. */
+tkmk_error tkmk_comm_ring_shift(tkmk_comm *comm, const void *send_dev, size_t bytes, int distance, void *recv_dev);
+/* every rank passes the status of a local step; ALL ranks return success only if every rank passed success (otherwise an error naming
+ * the failed rank).  The sharded entries below use it between their local step and their exchange, and tkmk_msm_sharded /
+ * tkmk_msm_multi_ex_sharded carry the same status inside the gathered record (16 bytes behind the partial results): a share that
+ * failed on one rank is an error on every rank, never a sum that silently lacks it. */
+tkmk_error tkmk_comm_agree(tkmk_comm *comm, tkmk_error local_status);
+/* A rank that leaves a sharded computation early calls this so that its peers fail instead of waiting: the loopback group's pending and
+ * later rendezvous fail at once; an RCCL communicator is aborted (ncclCommAbort).  The communicator only accepts tkmk_comm_destroy afterwards. */
+tkmk_error tkmk_comm_abort(tkmk_comm *comm);
+
+/* ---- the sharded prover's two matrix layouts and the transforms between them (world_size a power of two) ----
+ * COLS: rank r holds all rows of the columns iy = r mod G (row-major x_size x (y_size / G); local column k = global column r + G k) —
+ *       coefficient matrices and witness-native evaluations;  ROWS: rank r holds rows [r h, (r + 1) h), h = x_size / G, of all columns —
+ *       evaluations on the large domains.  One bivariate transform = a pass on the local axis, ONE all-to-all, a pass on the other axis. */
+#define TKMK_DIST_SKIP_X_PASS 1
+#define TKMK_DIST_SKIP_Y_PASS 2
+/* forward transform of the zero-padded extension of an in_x x in_y COLS coefficient matrix to the x_size x y_size domain -> ROWS
+ * evaluations (h x y_size), natural order (= tkmk_bintt_padded on the whole matrix, bit for bit).  flags: skip either pass; both = a
+ * change of layout only.  in_y >= world_size. */
+tkmk_error tkmk_dist_fwd_cols_to_rows(tkmk_comm *comm, const tkmk_fr *in_cols_dev, size_t in_x, size_t in_y, size_t x_size, size_t y_size, int flags,
+                                      tkmk_fr *out_rows_dev);
+/* inverse transform of x_size x y_size ROWS evaluations -> COLS coefficients (x_size x (y_size / G)); in_rows_dev is overwritten.
+ * (= tkmk_bintt inverse on the whole matrix).  flags as above. */
+tkmk_error tkmk_dist_inv_rows_to_cols(tkmk_comm *comm, tkmk_fr *in_rows_dev, size_t x_size, size_t y_size, int flags, tkmk_fr *out_cols_dev);
+/* out (h x y_size) = this rank's ROWS slab of the matrix rotated down by rot <= h rows, cyclically over all G h rows: the evaluations of
+ * p(w^-rot X, Y) from those of p.  One all-gather of rot rows per rank. */
+tkmk_error tkmk_dist_rows_rotate(tkmk_comm *comm, const tkmk_fr *slab_dev, size_t h, size_t y_size, size_t rot, tkmk_fr *out_dev);
 
 /* One MSM whose points are sharded over the ranks: this rank holds msm_size points (scalars / bases as in bls12_381_msm, host or
  * device per cfg; msm_size may be 0 on some ranks).  Every rank gets the full result (canonical projective, host).  Exchange: ONE

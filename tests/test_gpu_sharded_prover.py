@@ -35,7 +35,7 @@ def _open_ranks(dist, service, comms, qap, crs_dir):
     return dist.run_ranks(comms, lambda c: service.Prover(qap, crs_dir, testing=True, comm=c))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("seed,shape", SHAPES)
 @pytest.mark.parametrize("table_c", ["12", "0"])
 def test_sharded_proof_equals_the_single_gpu_proof(gpu, oracle, tmp_path, monkeypatch, world, seed, shape, table_c):
@@ -43,6 +43,9 @@ def test_sharded_proof_equals_the_single_gpu_proof(gpu, oracle, tmp_path, monkey
     from test_gpu_prove import _stage_crs_file, seeded_mixer
     from tkmk import dist, service
     inst = synth_circuit.build(str(tmp_path), random.Random(seed), **shape)
+    sp = inst["setup_params"]
+    if world > min(sp["n"], sp["l_D"] - sp["l"], sp["s_max"]):
+        pytest.skip("more ranks than the circuit has rows / columns")
     crs_dir = str(tmp_path / "crs")
     _stage_crs_file(gpu, oracle, inst, crs_dir)
     mixer_path = _mixer_file(tmp_path, seeded_mixer(seed))
@@ -78,7 +81,7 @@ def test_sharded_proof_with_fresh_blinding_verifies_and_failures_reach_every_ran
     import verify_files
     from test_gpu_prove import _stage_crs_file
     from tkmk import dist, service
-    world = 3                                                   # not a power of two: ragged row shares everywhere
+    world = 4
     inst = synth_circuit.build(str(tmp_path), random.Random(67), s_max=8, n_gate_kinds=2, used_placements=7, bit_fraction=0.4)
     crs_dir = str(tmp_path / "crs")
     _stage_crs_file(gpu, oracle, inst, crs_dir)
@@ -88,8 +91,8 @@ def test_sharded_proof_with_fresh_blinding_verifies_and_failures_reach_every_ran
     by_rank = {p.comm.rank: p for p in provers}
     try:
         out = str(tmp_path / "out")
-        docs = dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(inst["synth"], out if c.rank == 0 else None)[0])
-        assert docs[1] == docs[0] and docs[2] == docs[0]        # rank 0's blinding scalars reached every rank
+        docs = dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(inst["synth"], out)[0])          # every rank names the directory: rank 0 writes
+        assert docs[1] == docs[0] and docs[2] == docs[0] and docs[3] == docs[0]        # rank 0's blinding scalars reached every rank
         again = dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(inst["synth"], None)[0])
         assert again[0] != docs[0]                              # and they are fresh per proof
         assert verify_files.verify(inst["qap"], inst["synth"], crs_dir, out)
@@ -115,8 +118,8 @@ def test_sharded_proof_with_fresh_blinding_verifies_and_failures_reach_every_ran
             c.close()
 
 
-def test_shard_row_arithmetic():
-    """Shard::rows_of (host/tkmk_host.hpp) restated: |{ix < total : ix = r mod G}|; the shares of any box add up to the box"""
+def test_shard_column_arithmetic():
+    """Shard::cols_of (host/tkmk_host.hpp) restated: |{iy < total : iy = r mod G}|; the shares of any box add up to the box"""
     for world in (1, 2, 3, 4, 8):
         for total in (0, 1, 2, 5, 8, 4097, 8191):
             shares = [len(range(r, total, world)) for r in range(world)]

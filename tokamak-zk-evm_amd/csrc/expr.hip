@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256) void k_expr_eval(expr_args_t a, const fr_t *__
 
 // xm1[i] = w^i - 1 (Montgomery), w = root of unity of order x_size (the evaluation-domain form of "multiply by X - 1":
 // mod.rs:372-378, x_minus_one_evals :504-518)
-__global__ __launch_bounds__(256) void k_xm1_table(fr_t *__restrict__ out, fr_t w, uint32_t n) {
+__global__ __launch_bounds__(256) void k_xm1_table(fr_t *__restrict__ out, fr_t w, uint32_t n, uint32_t first) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) tk_store(out + i, Fr::sub(Fr::pow_u64(w, i), Fr::one()));
+    if (i < n) tk_store(out + i, Fr::sub(Fr::pow_u64(w, (uint64_t)first + i), Fr::one()));
 }
 
 // Host-side "compilation": validates the postfix program and inserts the form conversions.
@@ -116,8 +116,11 @@ struct emitter {
 };
 }  // namespace
 
+// x_global / x_first: the rows [x_first, x_first + x_size) of a domain with x_global rows are evaluated (a row slab of a sharded prover;
+// x_global = x_size, x_first = 0 for a whole domain): only the (w_x^ix - 1) factors depend on the global row index
 static tkmk_error expr_eval_impl(const tkmk_expr_instr *prog, uint32_t n_instr, expr_args_t &a, uint32_t n_leaves, const tkmk_fr *consts,
-                                 uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev, tkmk_stream stream);
+                                 uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev, tkmk_stream stream, uint32_t x_global = 0,
+                                 uint32_t x_first = 0);
 
 TK_API tkmk_error tkmk_poly_expr_eval(const tkmk_expr_instr *prog, uint32_t n_instr, const tkmk_fr *const *leaves_dev, uint32_t n_leaves,
                                       const tkmk_fr *consts, uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev,
@@ -157,9 +160,36 @@ TK_API tkmk_error tkmk_poly_expr_eval_views(const tkmk_expr_instr *prog, uint32_
     return expr_eval_impl(prog, n_instr, a, n_leaves, consts, n_consts, x_size, y_size, out_dev, stream);
 }
 
+// The evaluator on ONE ROW SLAB of a larger domain (a rank of a sharded prover, include/tkmk_dist.h ROWS layout): the domain has x_global
+// rows of which this call evaluates [x_first, x_first + x_rows); leaves are x_rows x y_size slabs (or vectors broadcast along an axis:
+// x_len = 1 / y_len = 1, the x_len = x_rows vector being the slab's piece of an X-only polynomial's evaluations).  rot_x must be 0 — a
+// rotation along X crosses slabs and is made beforehand (tkmk_dist_rows_rotate); rot_y is local.  x_rows, y_size, x_global powers of two.
+TK_API tkmk_error tkmk_poly_expr_eval_views_slab(const tkmk_expr_instr *prog, uint32_t n_instr, const tkmk_expr_leaf *leaves, uint32_t n_leaves,
+                                                 const tkmk_fr *consts, uint32_t n_consts, uint32_t x_global, uint32_t x_first, uint32_t x_rows,
+                                                 uint32_t y_size, tkmk_fr *out_dev, tkmk_stream stream) {
+    if (!prog || !out_dev || (n_leaves && !leaves) || (n_consts && !consts)) return TKMK_ERR_INVALID_POINTER;
+    if (!n_instr || !x_rows || !y_size || n_leaves > EXPR_MAX_LEAVES || n_consts > EXPR_MAX_CONSTS) return TKMK_ERR_INVALID_ARGUMENT;
+    if ((x_rows & (x_rows - 1)) || (y_size & (y_size - 1)) || (x_global & (x_global - 1)) || x_first % x_rows || (uint64_t)x_first + x_rows > x_global)
+        return TKMK_ERR_INVALID_ARGUMENT;
+    expr_args_t a;
+    memset(&a, 0, sizeof a);
+    for (uint32_t k = 0; k < n_leaves; k++) {
+        const tkmk_expr_leaf &l = leaves[k];
+        if (!l.data) return TKMK_ERR_INVALID_POINTER;
+        if ((l.x_len != x_rows && l.x_len != 1) || (l.y_len != y_size && l.y_len != 1) || l.rot_x || l.rot_y >= l.y_len) return TKMK_ERR_INVALID_ARGUMENT;
+        a.leaf[k].data = (const fr_t *)l.data;
+        a.leaf[k].xmask = l.x_len - 1, a.leaf[k].ymask = l.y_len - 1, a.leaf[k].y_len = l.y_len;
+        a.leaf[k].rot_x = 0, a.leaf[k].rot_y = l.rot_y;
+        a.leaf[k].plain = (l.x_len == x_rows && l.y_len == y_size && !l.rot_y) ? 1u : 0u;
+    }
+    return expr_eval_impl(prog, n_instr, a, n_leaves, consts, n_consts, x_rows, y_size, out_dev, stream, x_global, x_first);
+}
+
 static tkmk_error expr_eval_impl(const tkmk_expr_instr *prog, uint32_t n_instr, expr_args_t &a, uint32_t n_leaves, const tkmk_fr *consts,
-                                 uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev, tkmk_stream stream) {
+                                 uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev, tkmk_stream stream, uint32_t x_global,
+                                 uint32_t x_first) {
     TK_TRY(tk_require_device());
+    if (!x_global) x_global = x_size, x_first = 0;
     for (uint32_t k = 0; k < n_consts; k++) {
         fr_t c;
         for (int i = 0; i < 8; i++) c.l[i] = consts[k].limbs[i];
@@ -207,7 +237,7 @@ static tkmk_error expr_eval_impl(const tkmk_expr_instr *prog, uint32_t n_instr, 
                 E.emit(X_SCALE, (uint8_t)arg);  // form unchanged
                 break;
             case TKMK_EXPR_MUL_X_MINUS_ONE:
-                if (sp < 1 || (x_size & (x_size - 1))) return TKMK_ERR_INVALID_ARGUMENT;
+                if (sp < 1 || (x_global & (x_global - 1))) return TKMK_ERR_INVALID_ARGUMENT;
                 E.emit(X_XM1);
                 uses_xm1 = true;
                 break;
@@ -222,11 +252,11 @@ static tkmk_error expr_eval_impl(const tkmk_expr_instr *prog, uint32_t n_instr, 
     tk_scratch tx;
     if (uses_xm1) {
         tkmk_fr w;
-        TK_TRY(bls12_381_get_root_of_unity(x_size, &w));
+        TK_TRY(bls12_381_get_root_of_unity(x_global, &w));
         fr_t wf;
         for (int i = 0; i < 8; i++) wf.l[i] = w.limbs[i];
         TK_TRY(tx.alloc((size_t)x_size * sizeof(fr_t), s));
-        hipLaunchKernelGGL(k_xm1_table, tk_div_up(x_size, 256), 256, 0, s, tx.as<fr_t>(), Fr::to_mont(wf), x_size);
+        hipLaunchKernelGGL(k_xm1_table, tk_div_up(x_size, 256), 256, 0, s, tx.as<fr_t>(), Fr::to_mont(wf), x_size, x_first);
     }
     const uint64_t total = (uint64_t)x_size * y_size;
     uint64_t g = (total + 255) / 256;

@@ -78,6 +78,13 @@ static ShardLink link_for(void *comm) {
     l.multi_ex_sharded = (decltype(l.multi_ex_sharded))sym("tkmk_msm_multi_ex_sharded");
     l.broadcast_host = (decltype(l.broadcast_host))sym("tkmk_comm_broadcast_host");
     l.device_turn = (decltype(l.device_turn))sym("tkmk_comm_device_turn");
+    l.all_gather_host = (decltype(l.all_gather_host))sym("tkmk_comm_all_gather_host");
+    l.agree = (decltype(l.agree))sym("tkmk_comm_agree");
+    l.abort = (decltype(l.abort))sym("tkmk_comm_abort");
+    l.fwd_cols_to_rows = (decltype(l.fwd_cols_to_rows))sym("tkmk_dist_fwd_cols_to_rows");
+    l.inv_rows_to_cols = (decltype(l.inv_rows_to_cols))sym("tkmk_dist_inv_rows_to_cols");
+    l.rows_rotate = (decltype(l.rows_rotate))sym("tkmk_dist_rows_rotate");
+    l.ring_shift = (decltype(l.ring_shift))sym("tkmk_comm_ring_shift");
     int world = ((int (*)(const void *))sym("tkmk_comm_size"))(comm), rank = ((int (*)(const void *))sym("tkmk_comm_rank"))(comm);
     if (world < 1 || rank < 0 || rank >= world) throw Error("tkmk_prover_open_sharded: invalid communicator");
     l.shard = Shard{(uint32_t)world, (uint32_t)rank};

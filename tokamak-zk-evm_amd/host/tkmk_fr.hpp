@@ -8,7 +8,7 @@
 #include <cstring>
 #include <string>
 
-#include "tkmk_host.hpp"
+#include "tkmk_base.hpp"
 
 namespace tkmk {
 namespace frh {

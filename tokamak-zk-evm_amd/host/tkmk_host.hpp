@@ -11,66 +11,10 @@
 // Every method is a few calls into libtkmk_hip.so; the coefficient matrix stays in HBM (the reference copies it to the
 // host for find_degree / resize / mul_monomial / scaling / divisions).  Header-only; link with -ltkmk_hip.
 #pragma once
-#include <algorithm>
-#include <chrono>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <map>
-#include <memory>
-#include <stdexcept>
-#include <string>
-#include <tuple>
-#include <utility>
-#include <vector>
-
-#include "../../include/tkmk.h"
+#include "tkmk_base.hpp"
+#include "tkmk_fr.hpp"
 
 namespace tkmk {
-
-struct Error : std::runtime_error {
-    tkmk_error code;
-    Error(tkmk_error c, const std::string &where) : std::runtime_error(where + ": " + tkmk_error_string(c)), code(c) {}
-    explicit Error(const std::string &msg) : std::runtime_error(msg), code(TKMK_ERR_INVALID_ARGUMENT) {}
-};
-inline void check(tkmk_error e, const char *where) {
-    if (e != TKMK_SUCCESS) throw Error(e, where);
-}
-// TKMK_HOST_TRACE=1: one stderr line per transform / commit batch / division issued by the host side (sizes and a host clock),
-// to read a proof's operation sequence next to a kernel trace
-inline bool host_trace_on() {
-    static const bool on = getenv("TKMK_HOST_TRACE") != nullptr;
-    return on;
-}
-inline void host_trace(const char *fmt, ...) {
-    if (!host_trace_on()) return;
-    static const auto t0 = std::chrono::steady_clock::now();
-    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    fprintf(stderr, "[tkmk host %9.3f ms] ", ms);
-    va_list ap;
-    va_start(ap, fmt);
-    vfprintf(stderr, fmt, ap);
-    va_end(ap);
-    fputc('\n', stderr);
-}
-
-using ScalarField = tkmk_fr;
-using G1Affine = tkmk_g1_affine;
-
-inline ScalarField fr_from_u32(uint32_t v) {
-    ScalarField f{};
-    f.limbs[0] = v;
-    return f;
-}
-inline bool fr_is_zero(const ScalarField &a) {
-    uint32_t x = 0;
-    for (uint32_t l : a.limbs) x |= l;
-    return x == 0;
-}
-inline bool fr_eq(const ScalarField &a, const ScalarField &b) { return std::memcmp(&a, &b, sizeof a) == 0; }
 
 template <class T>
 class DeviceVec {
@@ -148,48 +92,163 @@ inline tkmk_vecops_config dev_cfg() {
     return c;
 }
 
+// ---- One proof over G GPUs: the calling thread's place in a sharded prover (no reference counterpart) ----
+// world == 1 (the default): everything below is the single-GPU code path, unchanged.  world > 1 (installed for the span of a call by
+// the sharded ProverContext, host/tkmk_service.hpp ShardSpan): matrices are DISTRIBUTED in the two layouts of include/tkmk_dist.h —
+//   COLS  coefficient matrices: rank r holds all rows of the columns iy = r mod G; local column k = global column r + G k
+//   ROWS  evaluations on a domain: rank r holds the rows [r h, (r + 1) h), h = x_size / G
+// and every method of DensePolynomialExt / PolyExpr / Sigma1 works on the local part, with the few collectives the operation needs
+// (a transform: one all-to-all; find_degree, eval, div_by_ruffini's remainder row: an all-gather of a few values).  G is a power of two.
+struct Shard {
+    uint32_t world = 1, rank = 0;
+    size_t cols_of(size_t total) const { return total > rank ? (total - rank + world - 1) / world : 0; }   // |{iy < total : iy = rank mod world}|
+    size_t rows_of(size_t total) const { return cols_of(total); }                                         // the same count for an interleaved row set
+};
+struct DistCtx {
+    void *comm = nullptr;
+    Shard shard;
+    tkmk_error (*all_gather_host)(void *, const void *, size_t, void *) = nullptr;
+    tkmk_error (*fwd_cols_to_rows)(void *, const tkmk_fr *, size_t, size_t, size_t, size_t, int, tkmk_fr *) = nullptr;
+    tkmk_error (*inv_rows_to_cols)(void *, tkmk_fr *, size_t, size_t, int, tkmk_fr *) = nullptr;
+    tkmk_error (*rows_rotate)(void *, const tkmk_fr *, size_t, size_t, size_t, tkmk_fr *) = nullptr;
+    tkmk_error (*ring_shift)(void *, const void *, size_t, int, void *) = nullptr;
+    bool on() const { return shard.world > 1; }
+    uint32_t G() const { return shard.world; }
+    uint32_t r() const { return shard.rank; }
+    // host values of every rank, rank order
+    template <class T>
+    std::vector<T> gather(const T &mine) const {
+        std::vector<T> all(shard.world);
+        check(all_gather_host(comm, &mine, sizeof(T), all.data()), "tkmk_comm_all_gather_host");
+        return all;
+    }
+};
+inline DistCtx &dist_ctx() {
+    static thread_local DistCtx c;
+    return c;
+}
+
 class DensePolynomialExt {
   public:
-    DeviceVec<ScalarField> poly;  // x_size * y_size coefficients, element (ix, iy) at ix*y_size + iy
+    // x_size * ly() coefficients, element (ix, local column k) at ix * ly() + k.  Single GPU: ly() = y_size, k = iy.
+    // Sharded prover: a DISTRIBUTED matrix holds the columns iy = rank mod G (ly() = |those|); a REPLICATED one (rep: small polynomials
+    // built from host values — vanishing polynomials, blinding terms, the Lagrange polynomials K, L, a_free) holds all columns on every rank.
+    DeviceVec<ScalarField> poly;
     int64_t x_degree = -1, y_degree = -1;
     size_t x_size = 1, y_size = 1;
+    bool rep = true;
+    DeviceVec<ScalarField> commit_slice_;   // sharded prover: this rank's columns of a REPLICATED polynomial while its commit is in flight (Sigma1::job)
 
     DensePolynomialExt() = default;
-    DensePolynomialExt(DeviceVec<ScalarField> &&c, size_t xs, size_t ys, int64_t xd, int64_t yd)
-        : poly(std::move(c)), x_degree(xd), y_degree(yd), x_size(xs), y_size(ys) {}
+    DensePolynomialExt(DeviceVec<ScalarField> &&c, size_t xs, size_t ys, int64_t xd, int64_t yd, bool replicated = !dist_ctx().on())
+        : poly(std::move(c)), x_degree(xd), y_degree(yd), x_size(xs), y_size(ys), rep(replicated || !dist_ctx().on()) {}
+
+    bool distributed() const { return !rep && dist_ctx().on(); }
+    static size_t local_cols(size_t ys, bool replicated) { return (replicated || !dist_ctx().on()) ? ys : dist_ctx().shard.cols_of(ys); }
+    size_t ly() const { return local_cols(y_size, rep); }
 
     static DensePolynomialExt zero() {
         ScalarField z{};
-        return DensePolynomialExt(DeviceVec<ScalarField>::from_host(&z, 1), 1, 1, -1, -1);
+        return DensePolynomialExt(DeviceVec<ScalarField>::from_host(&z, 1), 1, 1, -1, -1, true);
     }
-    // from_coeffs (mod.rs:1527-1551): takes ownership of a device vector
-    static DensePolynomialExt from_coeffs(DeviceVec<ScalarField> &&coeffs, size_t x_size, size_t y_size) {
-        if (x_size * y_size != coeffs.len()) throw Error("Mismatch between the coefficient vector and the polynomial size");
+    // from_coeffs (mod.rs:1527-1551): takes ownership of a device vector (sharded prover: the local columns of a distributed matrix
+    // unless `replicated`)
+    static DensePolynomialExt from_coeffs(DeviceVec<ScalarField> &&coeffs, size_t x_size, size_t y_size, bool replicated = !dist_ctx().on()) {
+        if (x_size * local_cols(y_size, replicated) != coeffs.len()) throw Error("Mismatch between the coefficient vector and the polynomial size");
         if (!is_pow2(x_size) || !is_pow2(y_size)) throw Error("The input sizes for from_coeffs must be powers of two.");
-        return DensePolynomialExt(std::move(coeffs), x_size, y_size, (int64_t)x_size - 1, (int64_t)y_size - 1);
+        return DensePolynomialExt(std::move(coeffs), x_size, y_size, (int64_t)x_size - 1, (int64_t)y_size - 1, replicated);
     }
+    // host values: the same on every rank, hence replicated
     static DensePolynomialExt from_coeffs(const std::vector<ScalarField> &coeffs, size_t x_size, size_t y_size) {
-        return from_coeffs(DeviceVec<ScalarField>::from_host(coeffs), x_size, y_size);
+        return from_coeffs(DeviceVec<ScalarField>::from_host(coeffs), x_size, y_size, true);
     }
-    // from_rou_evals (mod.rs:1615-1644): inverse _biNTT of device-resident evaluations
+    // from_rou_evals (mod.rs:1615-1644): inverse _biNTT of device-resident evaluations.  Sharded prover: `evals` is this rank's ROWS slab
+    // (h x y_size), the result a distributed COLS matrix (one all-to-all).
     static DensePolynomialExt from_rou_evals(const DeviceVec<ScalarField> &evals, size_t x_size, size_t y_size,
                                              const ScalarField *coset_x = nullptr, const ScalarField *coset_y = nullptr) {
         if (!is_pow2(x_size) || !is_pow2(y_size)) throw Error("The input sizes for from_rou_evals must be powers of two.");
+        const DistCtx &dc = dist_ctx();
+        if (dc.on()) {
+            if (coset_x || coset_y) throw Error("from_rou_evals: cosets are not used by the sharded prover");
+            if (x_size % dc.G() || y_size % dc.G()) throw Error("from_rou_evals: the domain is smaller than the number of ranks");
+            if (evals.len() < x_size / dc.G() * y_size) throw Error("Insufficient buffer length for from_rou_evals");
+            DeviceVec<ScalarField> slab = evals.clone();   // the exchange consumes its input
+            return from_rou_evals_consume(std::move(slab), x_size, y_size);
+        }
         if (evals.len() < x_size * y_size) throw Error("Insufficient buffer length for from_rou_evals");
         DeviceVec<ScalarField> coeffs(x_size * y_size);
         host_trace("from_rou_evals %zu x %zu%s", x_size, y_size, coset_x || coset_y ? " coset" : "");
         check(tkmk_bintt(evals.ptr(), x_size, y_size, TKMK_NTT_INVERSE, coset_x, coset_y, true, nullptr, coeffs.ptr()), "_biNTT");
         return from_coeffs(std::move(coeffs), x_size, y_size);
     }
-    // to_rou_evals (mod.rs:1646-1674) without the reference's D->H->D round trip
+    // the same for evaluations the caller no longer needs (sharded prover: saves the copy; single GPU: identical)
+    static DensePolynomialExt from_rou_evals_consume(DeviceVec<ScalarField> &&evals, size_t x_size, size_t y_size) {
+        const DistCtx &dc = dist_ctx();
+        if (!dc.on()) return from_rou_evals(evals, x_size, y_size);
+        DeviceVec<ScalarField> coeffs(x_size * (y_size / dc.G()));
+        host_trace("from_rou_evals %zu x %zu (rank %u of %u)", x_size, y_size, dc.r(), dc.G());
+        check(dc.inv_rows_to_cols(dc.comm, evals.ptr(), x_size, y_size, 0, coeffs.ptr()), "tkmk_dist_inv_rows_to_cols");
+        return from_coeffs(std::move(coeffs), x_size, y_size, false);
+    }
+    // evaluations in the COLS layout — what the witness side produces (one column per placement: u, v, w, b, s0, s1) and prove1's walk
+    // works on — to coefficients: a change of layout (one all-to-all) in front of the inverse transform.  Single GPU: from_rou_evals.
+    static DensePolynomialExt from_rou_evals_cols(const DeviceVec<ScalarField> &evals_cols, size_t x_size, size_t y_size) {
+        const DistCtx &dc = dist_ctx();
+        if (!dc.on()) return from_rou_evals(evals_cols, x_size, y_size);
+        if (x_size % dc.G() || y_size % dc.G()) throw Error("from_rou_evals: the domain is smaller than the number of ranks");
+        if (evals_cols.len() < x_size * (y_size / dc.G())) throw Error("Insufficient buffer length for from_rou_evals");
+        DeviceVec<ScalarField> slab(x_size / dc.G() * y_size);
+        check(dc.fwd_cols_to_rows(dc.comm, evals_cols.ptr(), x_size, y_size, x_size, y_size, 3, slab.ptr()), "tkmk_dist_fwd_cols_to_rows");
+        return from_rou_evals_consume(std::move(slab), x_size, y_size);
+    }
+    // small evaluation vectors made from host values (unit evaluations, the public inputs): the same on every rank -> replicated result
+    static DensePolynomialExt from_rou_evals_rep(const DeviceVec<ScalarField> &evals, size_t x_size, size_t y_size) {
+        if (!is_pow2(x_size) || !is_pow2(y_size)) throw Error("The input sizes for from_rou_evals must be powers of two.");
+        if (evals.len() < x_size * y_size) throw Error("Insufficient buffer length for from_rou_evals");
+        DeviceVec<ScalarField> coeffs(x_size * y_size);
+        check(tkmk_bintt(evals.ptr(), x_size, y_size, TKMK_NTT_INVERSE, nullptr, nullptr, true, nullptr, coeffs.ptr()), "_biNTT");
+        return from_coeffs(std::move(coeffs), x_size, y_size, true);
+    }
+    // to_rou_evals (mod.rs:1646-1674) without the reference's D->H->D round trip (single GPU)
     void to_rou_evals(const ScalarField *coset_x, const ScalarField *coset_y, DeviceVec<ScalarField> &evals) const {
+        if (dist_ctx().on()) throw Error("to_rou_evals: the sharded prover evaluates through evals_on (ROWS layout)");
         if (evals.len() < x_size * y_size) throw Error("Insufficient buffer length for to_rou_evals");
         host_trace("to_rou_evals %zu x %zu%s", x_size, y_size, coset_x || coset_y ? " coset" : "");
         check(tkmk_bintt(poly.ptr(), x_size, y_size, TKMK_NTT_FORWARD, coset_x, coset_y, true, nullptr, evals.ptr()), "_biNTT");
     }
+    // this polynomial as a distributed matrix (a replicated one gives up the other ranks' columns; y_size grows to G if smaller)
+    DensePolynomialExt to_distributed() const {
+        const DistCtx &dc = dist_ctx();
+        if (!dc.on() || !rep) return clone();
+        DensePolynomialExt wide = clone();
+        if (wide.y_size < dc.G()) wide.resize(wide.x_size, dc.G());
+        const size_t lc = wide.y_size / dc.G();
+        DeviceVec<ScalarField> loc(wide.x_size * lc);
+        // local element (i, k) = replicated element (i, r + G k) = flat index r + G (i lc + k): one strided copy
+        check(tkmk_memcpy_2d_d2d(loc.ptr(), sizeof(ScalarField), wide.poly.ptr() + dc.r(), (size_t)dc.G() * sizeof(ScalarField), sizeof(ScalarField), wide.x_size * lc),
+              "to_distributed");
+        DensePolynomialExt out(std::move(loc), wide.x_size, wide.y_size, x_degree, y_degree, false);
+        return out;
+    }
     // evaluations of this polynomial on the xs x ys domain: `resize` + forward _biNTT of the reference (mod.rs:1646-1674, 1920-1960),
-    // without materialising the zero padding when the matrix is smaller than the domain (tkmk_bintt_padded)
+    // without materialising the zero padding when the matrix is smaller than the domain (tkmk_bintt_padded).
+    // Sharded prover: -> this rank's ROWS slab (xs / G x ys); X pass on the local columns, one all-to-all, Y pass on the local rows.
     DeviceVec<ScalarField> evals_on(size_t xs, size_t ys) const {
+        const DistCtx &dc = dist_ctx();
+        if (dc.on()) {
+            if (rep) return to_distributed().evals_on(xs, ys);
+            if (xs % dc.G() || ys % dc.G()) throw Error("evals_on: the domain is smaller than the number of ranks");
+            if (x_size > xs || y_size > ys) {
+                DensePolynomialExt r = clone();
+                r.resize(std::min(x_size, xs), std::min(y_size, ys));
+                if (r.x_size > xs || r.y_size > ys) throw Error("evals_on: the polynomial does not fit the domain");
+                return r.evals_on(xs, ys);
+            }
+            DeviceVec<ScalarField> out(xs / dc.G() * ys);
+            host_trace("evals_on %zu x %zu -> %zu x %zu (rank %u of %u)", x_size, y_size, xs, ys, dc.r(), dc.G());
+            check(dc.fwd_cols_to_rows(dc.comm, poly.ptr(), x_size, y_size, xs, ys, 0, out.ptr()), "tkmk_dist_fwd_cols_to_rows");
+            return out;
+        }
         if (x_size <= xs && y_size <= ys) {
             DeviceVec<ScalarField> out(xs * ys);
             host_trace("evals_on %zu x %zu -> %zu x %zu (padded)", x_size, y_size, xs, ys);
@@ -202,28 +261,60 @@ class DensePolynomialExt {
         check(tkmk_bintt(r.poly.ptr(), xs, ys, TKMK_NTT_FORWARD, nullptr, nullptr, true, nullptr, r.poly.ptr()), "_biNTT");
         return std::move(r.poly);
     }
-    DensePolynomialExt clone() const { return DensePolynomialExt(poly.clone(), x_size, y_size, x_degree, y_degree); }
-    std::vector<ScalarField> copy_coeffs() const { return poly.to_host(); }
+    // a replicated polynomial's evaluations on a domain, computed whole on every rank (the X-only / Y-only leaves of the fused evaluator)
+    DeviceVec<ScalarField> evals_on_rep(size_t xs, size_t ys) const {
+        if (!rep) throw Error("evals_on_rep: the polynomial is distributed");
+        if (x_size > xs || y_size > ys) throw Error("evals_on_rep: the polynomial does not fit the domain");
+        DeviceVec<ScalarField> out(xs * ys);
+        check(tkmk_bintt_padded(poly.ptr(), x_size, y_size, xs, ys, nullptr, nullptr, nullptr, out.ptr()), "_biNTT");
+        return out;
+    }
+    DensePolynomialExt clone() const { return DensePolynomialExt(poly.clone(), x_size, y_size, x_degree, y_degree, rep); }
+    std::vector<ScalarField> copy_coeffs() const { return poly.to_host(); }   // the LOCAL coefficients
     ScalarField get_coeff(uint64_t ix, uint64_t iy) const {
         if (!(ix <= x_size && iy <= y_size)) throw Error("The index at which to get a coefficient exceeds the coefficient size.");
-        ScalarField v;
-        poly.copy_to_host(&v, 1, ix * y_size + iy);
-        return v;
+        ScalarField v{};
+        if (!distributed()) {
+            poly.copy_to_host(&v, 1, ix * y_size + iy);
+            return v;
+        }
+        const DistCtx &dc = dist_ctx();   // the owner's value reaches every rank
+        if (iy % dc.G() == dc.r()) poly.copy_to_host(&v, 1, ix * ly() + iy / dc.G());
+        return dc.gather(v)[iy % dc.G()];
+    }
+    // coefficient (0, 0) += s (`&poly + &scalar`, mod.rs:1042-1116): column 0 belongs to rank 0
+    void add_to_constant_term(const ScalarField &s) {
+        if (distributed() && dist_ctx().r() != 0) return;
+        if (poly.len() == 0) return;
+        ScalarField c0;
+        poly.copy_to_host(&c0, 1, 0);
+        c0 = fr_add(c0, s);
+        check(tkmk_memcpy_h2d(poly.ptr(), &c0, sizeof c0), "memcpy_h2d");
     }
     std::pair<int64_t, int64_t> degree() const { return {x_degree, y_degree}; }
 
     // find_degree (mod.rs:1480-1515)
     std::pair<int64_t, int64_t> find_degree() const {
-        int64_t xd, yd;
-        check(tkmk_poly_find_degree(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &xd, &yd, nullptr), "find_degree");
-        return {xd, yd};
+        int64_t xd = -1, yd = -1;
+        const size_t lc = ly();
+        if (lc) check(tkmk_poly_find_degree(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, &xd, &yd, nullptr), "find_degree");
+        if (!distributed()) return {xd, yd};
+        const DistCtx &dc = dist_ctx();
+        struct { int64_t x, y; } mine{xd, yd < 0 ? -1 : (int64_t)dc.r() + (int64_t)dc.G() * yd};   // local column k is global column r + G k
+        int64_t gx = -1, gy = -1;
+        for (auto &q : dc.gather(mine)) gx = std::max(gx, q.x), gy = std::max(gy, q.y);
+        return {gx, gy};
     }
     // resize (mod.rs:1784-1806)
     void resize(size_t target_x_size, size_t target_y_size) {
         auto [nx, ny] = find_size_as_twopower(target_x_size, target_y_size);
         if (x_size == nx && y_size == ny) return;
-        DeviceVec<ScalarField> dst(nx * ny);
-        check(tkmk_poly_place(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, dst.ptr(), (uint32_t)nx, (uint32_t)ny, 0, 0, nullptr), "resize");
+        const size_t sl = ly(), dl = local_cols(ny, rep);
+        DeviceVec<ScalarField> dst(nx * dl);
+        if (dl) {
+            if (sl) check(tkmk_poly_place(poly.ptr(), (uint32_t)x_size, (uint32_t)sl, dst.ptr(), (uint32_t)nx, (uint32_t)dl, 0, 0, nullptr), "resize");
+            else check(tkmk_memset(dst.ptr(), 0, nx * dl * sizeof(ScalarField)), "resize");
+        }
         poly = std::move(dst);
         x_size = nx, y_size = ny;
     }
@@ -237,37 +328,69 @@ class DensePolynomialExt {
     // mul_monomial (mod.rs:1820-1844)
     DensePolynomialExt mul_monomial(size_t x_exponent, size_t y_exponent) const {
         if (x_exponent == 0 && y_exponent == 0) return clone();
+        if (distributed() && y_exponent) return lincomb({Term(fr_from_u32(1), this, (uint32_t)x_exponent, (uint32_t)y_exponent)});
         auto [nx, ny] = find_size_as_twopower((size_t)(x_degree + 1) + x_exponent, (size_t)(y_degree + 1) + y_exponent);
         if (x_size + x_exponent > nx || y_size + y_exponent > ny) throw Error("mul_monomial: coefficient block does not fit the target");
-        DeviceVec<ScalarField> dst(nx * ny);
-        check(tkmk_poly_place(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, dst.ptr(), (uint32_t)nx, (uint32_t)ny, (uint32_t)x_exponent,
-                              (uint32_t)y_exponent, nullptr),
-              "mul_monomial");
-        return from_coeffs(std::move(dst), nx, ny);
+        const size_t sl = ly(), dl = local_cols(ny, rep);
+        DeviceVec<ScalarField> dst(nx * dl);
+        if (dl)
+            check(tkmk_poly_place(poly.ptr(), (uint32_t)x_size, (uint32_t)sl, dst.ptr(), (uint32_t)nx, (uint32_t)dl, (uint32_t)x_exponent,
+                                  (uint32_t)y_exponent, nullptr),
+                  "mul_monomial");
+        return from_coeffs(std::move(dst), nx, ny, rep);
     }
-    // scale_coeffs_x / scale_coeffs_y (mod.rs:1553-1613)
+    // scale_coeffs_x / scale_coeffs_y (mod.rs:1553-1613).  Distributed: local column k is global column r + G k, so the Y factor of
+    // element (i, k) is fy^r (fy^G)^k.
     DensePolynomialExt scale_coeffs(const ScalarField *fx, const ScalarField *fy) const {
-        DeviceVec<ScalarField> dst(x_size * y_size);
-        check(tkmk_poly_scale_coeffs(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, fx, fy, dst.ptr(), nullptr), "_scale_coeffs");
-        return from_coeffs(std::move(dst), x_size, y_size);
+        const size_t lc = ly();
+        DeviceVec<ScalarField> dst(x_size * lc);
+        if (!lc) return from_coeffs(std::move(dst), x_size, y_size, rep);
+        if (!distributed() || !fy) {
+            check(tkmk_poly_scale_coeffs(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, fx, fy, dst.ptr(), nullptr), "_scale_coeffs");
+            return from_coeffs(std::move(dst), x_size, y_size, rep);
+        }
+        const DistCtx &dc = dist_ctx();
+        const ScalarField fy_g = fr_pow(*fy, dc.G()), fy_r = fr_pow(*fy, dc.r());
+        check(tkmk_poly_scale_coeffs(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, fx, &fy_g, dst.ptr(), nullptr), "_scale_coeffs");
+        if (dc.r()) {
+            tkmk_vecops_config c = dev_cfg();
+            c.is_a_on_device = false;
+            check(bls12_381_scalar_mul_vec(&fy_r, dst.ptr(), dst.len(), &c, dst.ptr()), "_scale_coeffs");
+        }
+        return from_coeffs(std::move(dst), x_size, y_size, false);
     }
     DensePolynomialExt scale_coeffs_x(const ScalarField &f) const { return scale_coeffs(&f, nullptr); }
     DensePolynomialExt scale_coeffs_y(const ScalarField &f) const { return scale_coeffs(nullptr, &f); }
     // eval_x / eval_y / eval (mod.rs:1719-1750)
-    DensePolynomialExt eval_x(const ScalarField &x) const {
-        DeviceVec<ScalarField> out(y_size);
-        check(tkmk_poly_eval_x(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &x, out.ptr(), nullptr), "eval_x");
-        return from_coeffs(std::move(out), 1, y_size);
+    DensePolynomialExt eval_x(const ScalarField &x) const {   // -> a Y-only polynomial with this one's distribution
+        const size_t lc = ly();
+        DeviceVec<ScalarField> out(lc);
+        if (lc) check(tkmk_poly_eval_x(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, &x, out.ptr(), nullptr), "eval_x");
+        return from_coeffs(std::move(out), 1, y_size, rep);
     }
     DensePolynomialExt eval_y(const ScalarField &y) const {
+        if (distributed()) throw Error("eval_y: not used by the sharded prover");
         DeviceVec<ScalarField> out(x_size);
         check(tkmk_poly_eval_y(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &y, out.ptr(), nullptr), "eval_y");
-        return from_coeffs(std::move(out), x_size, 1);
+        return from_coeffs(std::move(out), x_size, 1, rep);
     }
     ScalarField eval(const ScalarField &x, const ScalarField &y) const {
-        ScalarField r;
-        check(tkmk_poly_eval(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &x, &y, &r, nullptr), "eval");
-        return r;
+        ScalarField r{};
+        if (!distributed()) {
+            check(tkmk_poly_eval(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &x, &y, &r, nullptr), "eval");
+            return r;
+        }
+        // sum_k sum_i c[i][k] x^i y^(r + G k) = y^r * (local matrix evaluated at (x, y^G)); the G partial values are added on the host
+        const DistCtx &dc = dist_ctx();
+        const size_t lc = ly();
+        if (lc) {
+            const ScalarField y_g = fr_pow(y, dc.G());
+            check(tkmk_poly_eval(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, &x, &y_g, &r, nullptr), "eval");
+            r = fr_mul(r, fr_pow(y, dc.r()));
+        }
+        ScalarField sum{};
+        for (const ScalarField &q : dc.gather(r)) sum = fr_add(sum, q);
+        return sum;
     }
 
     // ---- arithmetic (mod.rs:532-1281): operands are brought to the common (max) shape first ----
@@ -279,12 +402,19 @@ class DensePolynomialExt {
         return {std::move(l), std::move(r)};
     }
     friend DensePolynomialExt operator+(const DensePolynomialExt &a, const DensePolynomialExt &b) {
+        if (dist_ctx().on()) return lincomb({Term(fr_from_u32(1), &a), Term(fr_from_u32(1), &b)});
         auto [l, r] = same_shape(a, b);
         tkmk_vecops_config c = dev_cfg();
         check(bls12_381_vector_add(l.poly.ptr(), r.poly.ptr(), l.poly.len(), &c, l.poly.ptr()), "add");
         return from_coeffs(std::move(l.poly), l.x_size, l.y_size);
     }
     friend DensePolynomialExt operator-(const DensePolynomialExt &a, const DensePolynomialExt &b) {
+        if (dist_ctx().on()) {
+            ScalarField zero{}, one = fr_from_u32(1), minus_one;
+            tkmk_vecops_config hc = tkmk_vecops_default_config();   // host in, host out
+            check(bls12_381_vector_sub(&zero, &one, 1, &hc, &minus_one), "sub");
+            return lincomb({Term(one, &a), Term(minus_one, &b)});
+        }
         auto [l, r] = same_shape(a, b);
         tkmk_vecops_config c = dev_cfg();
         check(bls12_381_vector_sub(l.poly.ptr(), r.poly.ptr(), l.poly.len(), &c, l.poly.ptr()), "sub");
@@ -294,8 +424,8 @@ class DensePolynomialExt {
         DensePolynomialExt out = a.clone();
         tkmk_vecops_config c = dev_cfg();
         c.is_a_on_device = false;
-        check(bls12_381_scalar_mul_vec(&s, out.poly.ptr(), out.poly.len(), &c, out.poly.ptr()), "scalar_mul");
-        return from_coeffs(std::move(out.poly), out.x_size, out.y_size);
+        if (out.poly.len()) check(bls12_381_scalar_mul_vec(&s, out.poly.ptr(), out.poly.len(), &c, out.poly.ptr()), "scalar_mul");
+        return from_coeffs(std::move(out.poly), out.x_size, out.y_size, out.rep);
     }
     // sum_t c_t * X^ox_t Y^oy_t * p_t in ONE pass (tkmk_poly_lincomb): poly_comb! and the `&a * &s`, `&a + &b`, mul_monomial chains
     // around it (prove/src/lib.rs:30-124), which cost one pass and one temporary per operator when evaluated step by step
@@ -308,19 +438,65 @@ class DensePolynomialExt {
     static DensePolynomialExt lincomb(const std::vector<Term> &terms) {
         if (terms.empty()) return zero();
         size_t nx = 1, ny = 1;
+        bool all_rep = true;
+        for (const Term &t : terms) {
+            nx = std::max(nx, next_pow2(t.p->x_size + t.ox)), ny = std::max(ny, next_pow2(t.p->y_size + t.oy));
+            all_rep = all_rep && !t.p->distributed();
+        }
+        const DistCtx &dc = dist_ctx();
+        // sharded prover: operands that are all replicated and small give a replicated result (every rank computes the same few values);
+        // anything else is a distributed matrix, each rank combining its columns of every operand
+        const bool out_rep = !dc.on() || (all_rep && nx * ny <= (1u << 16));
+        if (!out_rep) ny = std::max<size_t>(ny, dc.G()), nx = std::max<size_t>(nx, 1);   // at least one column per rank
         std::vector<ScalarField> c;
         std::vector<const tkmk_fr *> ptr;
         std::vector<uint32_t> xs, ys, ox, oy;
+        std::vector<DeviceVec<ScalarField>> temps;   // local column sets of replicated operands, columns received from the neighbour for Y shifts
         for (const Term &t : terms) {
-            nx = std::max(nx, next_pow2(t.p->x_size + t.ox)), ny = std::max(ny, next_pow2(t.p->y_size + t.oy));
-            c.push_back(t.c), ptr.push_back(t.p->poly.ptr());
-            xs.push_back((uint32_t)t.p->x_size), ys.push_back((uint32_t)t.p->y_size), ox.push_back(t.ox), oy.push_back(t.oy);
+            const DensePolynomialExt &p = *t.p;
+            if (out_rep) {
+                c.push_back(t.c), ptr.push_back(p.poly.ptr()), xs.push_back((uint32_t)p.x_size), ys.push_back((uint32_t)p.y_size), ox.push_back(t.ox), oy.push_back(t.oy);
+                continue;
+            }
+            const uint32_t G = dc.G(), r = dc.r();
+            if (p.rep) {
+                // a replicated operand contributes its columns r, r + G, ...: a strided copy of that set (a Y shift that is not a multiple
+                // of G is applied to the whole small matrix first)
+                DensePolynomialExt d = (t.oy % G) ? p.mul_monomial(0, t.oy).to_distributed() : p.to_distributed();
+                const size_t lc = d.ly(), lx = d.x_size;
+                temps.push_back(std::move(d.poly));
+                if (!lc) continue;
+                c.push_back(t.c), ptr.push_back(temps.back().ptr()), xs.push_back((uint32_t)lx), ys.push_back((uint32_t)lc), ox.push_back(t.ox);
+                oy.push_back((t.oy % G) ? 0u : t.oy / G);
+                continue;
+            }
+            const size_t lc = p.ly();
+            if (t.oy % G == 0) {
+                if (!lc) continue;
+                c.push_back(t.c), ptr.push_back(p.poly.ptr()), xs.push_back((uint32_t)p.x_size), ys.push_back((uint32_t)lc), ox.push_back(t.ox), oy.push_back(t.oy / G);
+                continue;
+            }
+            // Y^oy p: global column j of p becomes column j + oy.  With s = oy mod G, my local column k (global r + G k) receives the
+            // column r + G k - oy of p = local column k - q' of rank (r - s) mod G, q' = oy / G + (r < s): the whole local matrix of that
+            // rank, fetched once (ring shift), then an ordinary local column offset
+            if (p.y_size % G) throw Error("lincomb: a Y shift needs at least one column per rank");
+            const uint32_t sft = t.oy % G;
+            temps.emplace_back(p.x_size * lc);
+            check(dc.ring_shift(dc.comm, p.poly.ptr(), p.x_size * lc * sizeof(ScalarField), (int)sft, temps.back().ptr()), "tkmk_comm_ring_shift");
+            c.push_back(t.c), ptr.push_back(temps.back().ptr()), xs.push_back((uint32_t)p.x_size), ys.push_back((uint32_t)lc), ox.push_back(t.ox);
+            oy.push_back(t.oy / G + (r < sft ? 1u : 0u));
         }
-        DeviceVec<ScalarField> out(nx * ny);
-        check(tkmk_poly_lincomb((uint32_t)terms.size(), c.data(), ptr.data(), xs.data(), ys.data(), ox.data(), oy.data(), out.ptr(), (uint32_t)nx, (uint32_t)ny,
-                                nullptr),
-              "tkmk_poly_lincomb");
-        return from_coeffs(std::move(out), nx, ny);
+        const size_t out_l = local_cols(ny, out_rep);
+        DeviceVec<ScalarField> out(nx * out_l);
+        if (out_l) {
+            if (ptr.empty()) check(tkmk_memset(out.ptr(), 0, nx * out_l * sizeof(ScalarField)), "lincomb");
+            else
+                check(tkmk_poly_lincomb((uint32_t)ptr.size(), c.data(), ptr.data(), xs.data(), ys.data(), ox.data(), oy.data(), out.ptr(), (uint32_t)nx, (uint32_t)out_l,
+                                        nullptr),
+                      "tkmk_poly_lincomb");
+            if (!temps.empty()) check(tkmk_device_synchronize(), "synchronize");   // the temporaries go out of scope here
+        }
+        return from_coeffs(std::move(out), nx, ny, out_rep);
     }
     // _mul (mod.rs:1846-1996)
     friend DensePolynomialExt operator*(const DensePolynomialExt &a, const DensePolynomialExt &b) {
@@ -335,10 +511,12 @@ class DensePolynomialExt {
         }
         size_t tx = (size_t)(lx + rx + 1), ty = (size_t)(ly + ry + 1);
         auto [xs, ys] = find_size_as_twopower(tx, ty);
+        const DistCtx &dc = dist_ctx();
+        if (dc.on()) xs = std::max<size_t>(xs, dc.G()), ys = std::max<size_t>(ys, dc.G());   // at least one row and one column per rank
         DeviceVec<ScalarField> le = a.evals_on(xs, ys), re = b.evals_on(xs, ys);
         tkmk_vecops_config c = dev_cfg();
         check(bls12_381_vector_mul(le.ptr(), re.ptr(), le.len(), &c, le.ptr()), "mul");
-        return from_rou_evals(le, xs, ys);
+        return from_rou_evals_consume(std::move(le), xs, ys);
     }
 
     // this * scale * (1 + X + ... + X^(m-1)); with scale = 1/m the factor is K_0 = unit evaluations at index 0 of the m-th roots
@@ -348,12 +526,14 @@ class DensePolynomialExt {
         (void)yd;
         if (xd < 0) return zero();
         size_t ox = next_pow2((size_t)xd + m);
-        DeviceVec<ScalarField> out(ox * y_size);
+        const size_t lc = ly();
+        DeviceVec<ScalarField> out(ox * lc);
         host_trace("mul_ones_x %zu x %zu by m = %zu", x_size, y_size, m);
-        check(tkmk_poly_mul_ones_x(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, (uint32_t)m, &scale, (uint32_t)ox, out.ptr(), nullptr), "mul_ones_x");
-        return from_coeffs(std::move(out), ox, y_size);
+        if (lc) check(tkmk_poly_mul_ones_x(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, (uint32_t)m, &scale, (uint32_t)ox, out.ptr(), nullptr), "mul_ones_x");
+        return from_coeffs(std::move(out), ox, y_size, rep);
     }
-    // div_by_vanishing_opt (mod.rs:2284-2410)
+    // div_by_vanishing_opt (mod.rs:2284-2410).  Distributed: every row is local, and the Y recurrence's stride d is a multiple of G, so a
+    // column's predecessor j - d lives on the same rank d / G local columns earlier: both passes are local.
     std::pair<DensePolynomialExt, DensePolynomialExt> div_by_vanishing_opt(int64_t denom_x_degree, int64_t denom_y_degree) {
         if (denom_x_degree <= 0 || denom_y_degree <= 0 || !is_pow2((size_t)denom_x_degree) || !is_pow2((size_t)denom_y_degree))
             throw Error("The denominators must have degress as powers of two.");
@@ -361,23 +541,47 @@ class DensePolynomialExt {
         if (x_degree < denom_x_degree || y_degree < denom_y_degree) throw Error("The numerator must have grater degrees than denominators.");
         size_t c = (size_t)denom_x_degree, d = (size_t)denom_y_degree;
         size_t xs = (x_size / c) * c, ys = (y_size / d) * d;
-        DeviceVec<ScalarField> qx(xs * ys), qy(c * ys);
+        size_t ysl = ys, dl = d;
+        if (distributed()) {
+            const size_t G = dist_ctx().G();
+            if (d % G || ys % G) throw Error("div_by_vanishing_opt: the Y divisor must be a multiple of the number of ranks");
+            ysl = ys / G, dl = d / G;
+        }
+        DeviceVec<ScalarField> qx(xs * ysl), qy(c * ysl);
         host_trace("div_by_vanishing_opt %zu x %zu by (%zu, %zu)", xs, ys, c, d);
-        check(tkmk_poly_div_by_vanishing_opt(poly.ptr(), (uint32_t)xs, (uint32_t)ys, (uint32_t)c, (uint32_t)d, qx.ptr(), qy.ptr(), nullptr),
+        check(tkmk_poly_div_by_vanishing_opt(poly.ptr(), (uint32_t)xs, (uint32_t)ysl, (uint32_t)c, (uint32_t)dl, qx.ptr(), qy.ptr(), nullptr),
               "div_by_vanishing_opt");
-        DensePolynomialExt quo_x = from_coeffs(std::move(qx), xs, ys), quo_y = from_coeffs(std::move(qy), c, ys);
+        DensePolynomialExt quo_x = from_coeffs(std::move(qx), xs, ys, rep), quo_y = from_coeffs(std::move(qy), c, ys, rep);
         if (xs > c) quo_x.x_degree = (int64_t)(xs - c) - 1, quo_x.y_degree = (int64_t)ys - 1;
         else quo_x.x_degree = quo_x.y_degree = -1;
         if (ys > d) quo_y.x_degree = (int64_t)c - 1, quo_y.y_degree = (int64_t)(ys - d) - 1;
         else quo_y.x_degree = quo_y.y_degree = -1;
         return {std::move(quo_x), std::move(quo_y)};
     }
-    // div_by_ruffini (mod.rs:2412-2458)
+    // div_by_ruffini (mod.rs:2412-2458).  Distributed: Q_X is a Horner scan along X, local in every column; the remainder row P(x, Y) —
+    // one value per column — is gathered (y_size values), and its division by (Y - y) is done whole on every rank (Q_Y: replicated).
     std::tuple<DensePolynomialExt, DensePolynomialExt, ScalarField> div_by_ruffini(const ScalarField &x, const ScalarField &y) const {
-        DeviceVec<ScalarField> qx(x_size * y_size), qy(y_size);
         ScalarField r;
-        check(tkmk_poly_div_by_ruffini(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &x, &y, qx.ptr(), qy.ptr(), &r, nullptr), "div_by_ruffini");
-        return {from_coeffs(std::move(qx), x_size, y_size), from_coeffs(std::move(qy), 1, y_size), r};
+        if (!distributed()) {
+            DeviceVec<ScalarField> qx(x_size * y_size), qy(y_size);
+            check(tkmk_poly_div_by_ruffini(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &x, &y, qx.ptr(), qy.ptr(), &r, nullptr), "div_by_ruffini");
+            return {from_coeffs(std::move(qx), x_size, y_size, rep), from_coeffs(std::move(qy), 1, y_size, rep), r};
+        }
+        const DistCtx &dc = dist_ctx();
+        const size_t lc = ly(), G = dc.G();
+        if (y_size % G) throw Error("div_by_ruffini: needs at least one column per rank");
+        DeviceVec<ScalarField> qx(x_size * lc), scratch_qy(lc), rem(lc);
+        ScalarField ignored;
+        check(tkmk_poly_div_by_ruffini(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, &x, &y, qx.ptr(), scratch_qy.ptr(), &ignored, nullptr), "div_by_ruffini");
+        check(tkmk_poly_eval_x(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, &x, rem.ptr(), nullptr), "div_by_ruffini: remainder row");
+        std::vector<ScalarField> mine = rem.to_host(), all(y_size), whole(y_size);
+        check(dc.all_gather_host(dc.comm, mine.data(), lc * sizeof(ScalarField), all.data()), "tkmk_comm_all_gather_host");
+        for (size_t q = 0; q < G; q++)
+            for (size_t k = 0; k < lc; k++) whole[q + G * k] = all[q * lc + k];
+        DeviceVec<ScalarField> row = DeviceVec<ScalarField>::from_host(whole), qrow(y_size), qy(y_size);
+        // P(x, Y) as a 1 x y_size matrix: its "X division" is trivial (one row), its Y division is the one wanted
+        check(tkmk_poly_div_by_ruffini(row.ptr(), 1, (uint32_t)y_size, &x, &y, qrow.ptr(), qy.ptr(), &r, nullptr), "div_by_ruffini");
+        return {from_coeffs(std::move(qx), x_size, y_size, false), from_coeffs(std::move(qy), 1, y_size, true), r};
     }
 };
 
@@ -489,7 +693,57 @@ class PolyExpr {
         // otherwise node by node
         Program pg;
         int need = compile(pg, 0);
-        if (need > 0 && need <= 6 && !pg.leaves.empty() && pg.leaves.size() <= 16 && pg.consts.size() <= 16 && pg.code.size() <= 100) {
+        const DistCtx &dc = dist_ctx();
+        const bool fits = need > 0 && need <= 6 && !pg.leaves.empty() && pg.leaves.size() <= 16 && pg.consts.size() <= 16 && pg.code.size() <= 100;
+        if (dc.on()) {
+            // sharded prover: every rank evaluates its ROWS slab [r h, (r + 1) h) of the domain.  Distributed leaves are transformed with one
+            // all-to-all each (evals_on); replicated X-only / Y-only leaves are transformed whole (1-D, small) and read through their
+            // slab piece / broadcast; a root shift along X is a rotation that crosses slabs and is made beforehand (rows_rotate).
+            if (!fits) throw Error("Fused polynomial expression: too large for the one-pass evaluator (sharded prover)");
+            const size_t G = dc.G(), h = target_x_size / G;
+            if (target_x_size % G || target_y_size % G) throw Error("Fused polynomial expression: the domain is smaller than the number of ranks");
+            std::vector<tkmk_expr_leaf> views;
+            std::vector<std::shared_ptr<DeviceVec<ScalarField>>> rotated;
+            for (const Program::Leaf &l : pg.leaves) {
+                if ((l.ord_x && target_x_size % l.ord_x) || (l.ord_y && target_y_size % l.ord_y))
+                    throw Error("Fused polynomial expression: a root shift's order does not divide the domain.");
+                tkmk_expr_leaf v{};
+                const bool x_only = l.p->rep && l.p->y_size == 1, y_only = l.p->rep && l.p->x_size == 1;
+                if (x_only || y_only) {
+                    const size_t lx = y_only ? 1 : target_x_size, ly = x_only ? 1 : target_y_size;
+                    auto key = std::make_tuple(l.p, lx, ly);
+                    auto it = cache.find(key);
+                    if (it == cache.end()) it = cache.emplace(key, std::make_shared<DeviceVec<ScalarField>>(l.p->evals_on_rep(lx, ly))).first;
+                    if (x_only && l.ord_x) throw Error("Fused polynomial expression: root shift of a replicated X-only leaf (sharded prover)");
+                    v.data = it->second->ptr() + (x_only && lx > 1 ? dc.r() * h : 0);
+                    v.x_len = (uint32_t)(lx > 1 ? h : 1), v.y_len = (uint32_t)ly;
+                    v.rot_y = (l.ord_y && ly > 1) ? (uint32_t)(target_y_size / l.ord_y) : 0;
+                    views.push_back(v);
+                    continue;
+                }
+                std::shared_ptr<DeviceVec<ScalarField>> slab = leaf_evals(l.p, target_x_size, target_y_size, cache);
+                const size_t rot_x = l.ord_x ? target_x_size / l.ord_x : 0;
+                if (rot_x % target_x_size) {
+                    if (rot_x > h) throw Error("Fused polynomial expression: the root shift spans more than one rank's rows");
+                    auto rt = std::make_shared<DeviceVec<ScalarField>>(h * target_y_size);
+                    check(dc.rows_rotate(dc.comm, slab->ptr(), h, target_y_size, rot_x, rt->ptr()), "tkmk_dist_rows_rotate");
+                    rotated.push_back(rt);
+                    slab = rt;
+                }
+                v.data = slab->ptr();
+                v.x_len = (uint32_t)h, v.y_len = (uint32_t)target_y_size;
+                v.rot_y = l.ord_y ? (uint32_t)((target_y_size / l.ord_y) % target_y_size) : 0;
+                views.push_back(v);
+            }
+            DeviceVec<ScalarField> out(h * target_y_size);
+            check(tkmk_poly_expr_eval_views_slab(pg.code.data(), (uint32_t)pg.code.size(), views.data(), (uint32_t)views.size(), pg.consts.data(),
+                                                 (uint32_t)pg.consts.size(), (uint32_t)target_x_size, (uint32_t)(dc.r() * h), (uint32_t)h, (uint32_t)target_y_size,
+                                                 out.ptr(), nullptr),
+                  "tkmk_poly_expr_eval_views_slab");
+            check(tkmk_device_synchronize(), "synchronize");   // the rotated copies go out of scope
+            return DensePolynomialExt::from_rou_evals_consume(std::move(out), target_x_size, target_y_size);
+        }
+        if (fits) {
             // leaves as VIEWS: an X-only (Y-only) polynomial is transformed in one dimension and broadcast; a root-shifted leaf
             // reads the unshifted polynomial's evaluations rotated by size / order
             std::vector<tkmk_expr_leaf> views;
@@ -669,13 +923,9 @@ inline std::vector<CommitBox> *&commit_box_sink() {
     return sink;
 }
 
-// One proof over G GPUs: every commit table is sharded by GRID ROW, interleaved — rank r of G holds
-// the rows ix = r mod G — so that any coefficient box [0, tx) x [0, ty) splits evenly whatever its height, and a rank's share of a
-// commit is again a strided view: rows r, r + G, ... of the (replicated) coefficient matrix against the rank's own rows.
-struct Shard {
-    uint32_t world = 1, rank = 0;
-    size_t rows_of(size_t total) const { return total > rank ? (total - rank + world - 1) / world : 0; }   // |{ix < total : ix = rank mod world}|
-};
+// One proof over G GPUs: the commit table xy_powers is sharded like the coefficient matrices it is
+// multiplied with — rank r of G holds the grid columns iy = r mod G (COLS layout, struct Shard above) — so that any coefficient box
+// [0, tx) x [0, ty) splits evenly whatever its width, and a rank's share of a commit is a view of its own columns on both sides.
 // The commit batches of a sharded prover go through its communicator (tkmk_msm_multi_ex_sharded of libtkmk_dist.so: every rank runs
 // its share, ONE all-gather of 144 bytes per commit, the partials summed on the device).  Installed per host thread by the sharded
 // context for the span of a call; absent, batches run on this GPU alone.
@@ -690,10 +940,10 @@ inline CommitComm &commit_comm() {
 
 class Sigma1 {
     DeviceVec<G1Affine> xy_powers_;   // level 0: the table in resident form; with table_c_: levels 1 .. table_factor_ - 1 behind it
-    size_t rs_x_, rs_y_;              // the GRID (all ranks' rows); this rank holds local_rows_ of its rs_x_ rows
+    size_t rs_x_, rs_y_;              // the GRID (all ranks' columns); this rank holds local_cols_ of its rs_y_ columns, all rs_x_ rows
     uint32_t table_c_ = 0, table_factor_ = 0;
     Shard shard_;
-    size_t local_rows_;
+    size_t local_cols_;
 
   public:
     // xy_powers[i*rs_y + j] = [tau_x^i tau_y^j]G (plain affine records);  rs_x = max(2n, 2(l_D - l)), rs_y = 2 s_max.
@@ -701,12 +951,12 @@ class Sigma1 {
     // multiples (ICICLE's msm_precompute_bases, MSMConfig::precompute_factor — left at 1 by the reference), so that every large
     // commit runs as ONE bucket set with table_c-bit windows: 13 instead of 16 bucket additions per point at table_c = 20.
     // HBM: windows x the table (2^24 points at table_c = 20: 21 GB of the 288).
-    // shard.world > 1: `xy_powers` holds THIS RANK'S rows only (rows_of_grid(...) below cuts them out of a whole grid), row-major
-    // local_rows x rs_y; rs_x_size stays the grid's height.
+    // shard.world > 1: `xy_powers` holds THIS RANK'S columns only (cols_of_grid(...) below cuts them out of a whole grid), row-major
+    // rs_x x local_cols; rs_y_size stays the grid's width.
     Sigma1(DeviceVec<G1Affine> &&xy_powers, size_t rs_x_size, size_t rs_y_size, uint32_t table_c = 0, Shard shard = Shard{})
-        : xy_powers_(std::move(xy_powers)), rs_x_(rs_x_size), rs_y_(rs_y_size), shard_(shard), local_rows_(shard.rows_of(rs_x_size)) {
+        : xy_powers_(std::move(xy_powers)), rs_x_(rs_x_size), rs_y_(rs_y_size), shard_(shard), local_cols_(shard.cols_of(rs_y_size)) {
         if (shard_.world < 1 || shard_.rank >= shard_.world) throw Error("Sigma1: invalid shard");
-        if (xy_powers_.len() != local_rows_ * rs_y_) throw Error("xy_powers has the wrong length");
+        if (xy_powers_.len() != rs_x_ * local_cols_) throw Error("xy_powers has the wrong length");
         tkmk_msm_config cfg = tkmk_msm_default_config();
         cfg.are_points_on_device = cfg.are_results_on_device = true;
         if (table_c >= 2 && xy_powers_.len() >= 2) {
@@ -724,9 +974,20 @@ class Sigma1 {
     }
     size_t rs_x() const { return rs_x_; }
     size_t rs_y() const { return rs_y_; }
-    size_t table_len() const { return local_rows_ * rs_y_; }   // rows of one table level on THIS rank
+    size_t table_len() const { return rs_x_ * local_cols_; }   // rows of one table level on THIS rank
     const Shard &shard() const { return shard_; }
-    // rows r, r + G, ... of a row-major rs_x x rs_y grid of points: what rank r of G keeps (one strided copy on the device)
+    // columns r, r + G, ... of a row-major rs_x x rs_y grid of points: what rank r of G keeps (one strided copy on the device: local
+    // element (i, k) = grid element (i, r + G k) = flat index r + G (i lc + k) when G divides rs_y)
+    static DeviceVec<G1Affine> cols_of_grid(const DeviceVec<G1Affine> &grid, size_t rs_x, size_t rs_y, Shard shard) {
+        if (grid.len() != rs_x * rs_y) throw Error("cols_of_grid: the grid has the wrong length");
+        if (rs_y % shard.world) throw Error("cols_of_grid: the grid's width is not a multiple of the number of ranks");
+        const size_t lc = rs_y / shard.world;
+        DeviceVec<G1Affine> out(rs_x * lc);
+        if (out.len())
+            check(tkmk_memcpy_2d_d2d(out.ptr(), sizeof(G1Affine), grid.ptr() + shard.rank, (size_t)shard.world * sizeof(G1Affine), sizeof(G1Affine), rs_x * lc), "cols_of_grid");
+        return out;
+    }
+    // rows r, r + G, ... of a row-major grid (the walk-ordered prefix table of prove1: one row per grid column)
     static DeviceVec<G1Affine> rows_of_grid(const DeviceVec<G1Affine> &grid, size_t rs_x, size_t rs_y, Shard shard) {
         if (grid.len() != rs_x * rs_y) throw Error("rows_of_grid: the grid has the wrong length");
         const size_t rows = shard.rows_of(rs_x);
@@ -744,20 +1005,29 @@ class Sigma1 {
         size_t tx = (size_t)(poly.x_degree + 1), ty = (size_t)(poly.y_degree + 1);
         if (tx > rs_x_ || ty > rs_y_) throw Error("Insufficient length of sigma.sigma_1.xy_powers");
         if (auto *sink = commit_box_sink()) sink->push_back({name ? name : "?", tx, ty, "coeff"});
-        // this rank's rows of the box: grid rows r, r + G, ... < tx = rows 0 .. mine - 1 of the local table; the same rows of the
-        // coefficient matrix through a stride of G rows (world = 1: the whole box, stride = the matrix's own)
-        const size_t mine = shard_.rows_of(tx);
+        // this rank's columns of the box: grid columns r, r + G, ... < ty = columns 0 .. mine - 1 of the local table, and the same columns
+        // of the coefficient matrix (distributed: its own local columns; replicated: that column set is cut out first).  world = 1: the
+        // whole box, strides = the matrices' own.
+        const size_t mine = shard_.cols_of(ty);
+        const ScalarField *scalars = poly.poly.ptr();
+        size_t scalar_stride = poly.ly();
+        if (shard_.world > 1 && poly.rep) {
+            DensePolynomialExt d = poly.to_distributed();
+            scalar_stride = d.ly();
+            poly.commit_slice_ = std::move(d.poly);
+            scalars = poly.commit_slice_.ptr();
+        }
         tkmk_msm_job_ex j{};
-        j.scalars = poly.poly.ptr() + (size_t)shard_.rank * poly.y_size;
+        j.scalars = scalars;
         j.bases = xy_powers_.ptr();
-        j.msm_size = (int)(mine * ty);
-        j.scalar_cols = (uint32_t)ty, j.scalar_stride = (uint32_t)(poly.y_size * shard_.world);
-        j.base_cols = (uint32_t)ty, j.base_stride = (uint32_t)rs_y_;
+        j.msm_size = (int)(tx * mine);
+        j.scalar_cols = (uint32_t)mine, j.scalar_stride = (uint32_t)scalar_stride;
+        j.base_cols = (uint32_t)mine, j.base_stride = (uint32_t)local_cols_;
         j.base_index = nullptr;
         j.base_table_len = table_len();
         // large commits through the expanded table; small ones (the wide windows' two-pass sort needs 2^18 entries, and a 2^19-bucket
         // reduction is not worth paying for a few thousand points) through level 0 with the ordinary multi-window path
-        if (table_c_ && (uint64_t)mine * ty * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
+        if (table_c_ && (uint64_t)tx * mine * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
         return j;
     }
     static G1Affine to_affine(const tkmk_g1_projective &res) {
@@ -793,18 +1063,20 @@ class Sigma1 {
     }
     // -> affine commitment
     G1Affine encode_poly(DensePolynomialExt &poly, const char *name = nullptr) const { return run_jobs({job(poly, name)})[0]; }
-    // the MSM job of a polynomial given by its rs_x x rs_y EVALUATIONS, over a table that holds the Lagrange-basis points of that grid
-    // (lagrange_of below): all rows, no view; zeros and small values cost the MSM next to nothing
-    tkmk_msm_job_ex job_evals(const DeviceVec<ScalarField> &evals, const char *name = nullptr) const {
+    // the MSM job of a polynomial given by its EVALUATIONS on the grid of this table, which holds the Lagrange-basis points of that grid
+    // (lagrange_of below): every row of the table against the evaluation vector, no view; zeros and small values cost the MSM next to
+    // nothing.  Sharded prover: the table object is built over THIS RANK'S part of the grid (its columns, or its stretch of the walk) and
+    // `evals` is the same part of the evaluations — COLS layout on both sides.
+    tkmk_msm_job_ex job_evals(const DeviceVec<ScalarField> &evals, const char *name = nullptr, size_t whole_x = 0, size_t whole_y = 0) const {
+        if (shard_.world != 1) throw Error("job_evals: a Lagrange-basis table is built over the rank's own part of the grid");
         if (evals.len() < rs_x_ * rs_y_) throw Error("evaluation vector shorter than the Lagrange table");
-        if (auto *sink = commit_box_sink()) sink->push_back({name ? name : "?", rs_x_, rs_y_, "evals"});
+        if (auto *sink = commit_box_sink()) sink->push_back({name ? name : "?", whole_x ? whole_x : rs_x_, whole_y ? whole_y : rs_y_, "evals"});
         tkmk_msm_job_ex j{};
-        j.scalars = evals.ptr() + (size_t)shard_.rank * rs_y_;
+        j.scalars = evals.ptr();
         j.bases = xy_powers_.ptr();
-        j.msm_size = (int)(local_rows_ * rs_y_);
-        if (shard_.world > 1) j.scalar_cols = (uint32_t)rs_y_, j.scalar_stride = (uint32_t)(rs_y_ * shard_.world);   // grid rows r, r + G, ...; the local table is contiguous
+        j.msm_size = (int)(rs_x_ * rs_y_);
         j.base_table_len = table_len();
-        if (table_c_ && (uint64_t)local_rows_ * rs_y_ * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
+        if (table_c_ && (uint64_t)rs_x_ * rs_y_ * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
         return j;
     }
     // The Lagrange-basis twin of the grid [0, xs) x [0, ys) of this table: N [L_i(tau_x) L_j(tau_y)] G = the inverse NTT over G1 points of

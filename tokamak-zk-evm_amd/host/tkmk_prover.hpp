@@ -131,10 +131,10 @@ struct ProverSigma {
         if (it == xy_edge.end()) throw Error("xy_powers entry not kept on the host");
         return it->second;
     }
-    // shard.world > 1 (one proof over several GPUs): sigma1 keeps this rank's grid rows only; *whole_grid (when asked for) receives the
+    // shard.world > 1 (one proof over several GPUs): sigma1 keeps this rank's grid columns only; *whole_grid (when asked for) receives the
     // whole xy_powers grid in the MSM's resident form without a table — what the Lagrange-basis tables are derived from before they
-    // are sharded the same way; the caller drops it afterwards.  The binding tables are replicated (their index-list commits are split
-    // by list position instead).
+    // are sharded the same way; the caller drops it afterwards.  The binding tables are replicated (every rank commits the index lists
+    // of its own placements).
     static ProverSigma from_payload(const CrsPayload &crs, const SetupParams &sp, uint32_t table_c = 0, Shard shard = Shard{},
                                     std::unique_ptr<Sigma1> *whole_grid = nullptr) {
         size_t m_i = sp.l_D - sp.l, rs_x = std::max(2 * sp.n, 2 * m_i), rs_y = 2 * sp.s_max;
@@ -161,7 +161,7 @@ struct ProverSigma {
                     if (base + k < rs_y) edge[{0, base + k}] = xy[base + k];
         }
         DeviceVec<G1Affine> grid = crs.upload(CrsPayload::XyPowers);
-        DeviceVec<G1Affine> mine = shard.world > 1 ? Sigma1::rows_of_grid(grid, rs_x, rs_y, shard) : DeviceVec<G1Affine>();
+        DeviceVec<G1Affine> mine = shard.world > 1 ? Sigma1::cols_of_grid(grid, rs_x, rs_y, shard) : DeviceVec<G1Affine>();
         if (shard.world > 1 && whole_grid) whole_grid->reset(new Sigma1(std::move(grid), rs_x, rs_y, 0));
         ProverSigma out{Sigma1(shard.world > 1 ? std::move(mine) : std::move(grid), rs_x, rs_y, table_c, shard),
                            crs.upload(CrsPayload::GammaInvOInst),
@@ -221,13 +221,10 @@ inline Poly unit_evals(size_t size, size_t index, bool x_axis) {   // the Lagran
     std::vector<ScalarField> e(size);
     e.at(index) = fr_one();
     DeviceVec<ScalarField> d = DeviceVec<ScalarField>::from_host(e);
-    return x_axis ? Poly::from_rou_evals(d, size, 1) : Poly::from_rou_evals(d, 1, size);
+    return x_axis ? Poly::from_rou_evals_rep(d, size, 1) : Poly::from_rou_evals_rep(d, 1, size);   // host values: the same on every rank
 }
 // &poly + &scalar / &poly - &scalar (bivariate_polynomial/mod.rs:1042-1116, 1189-1262): only coefficient (0,0) changes
-inline void add_const_in_place(Poly &p, const ScalarField &s) {
-    ScalarField c0 = fr_add(p.get_coeff(0, 0), s);
-    check(tkmk_memcpy_h2d(p.poly.ptr(), &c0, sizeof c0), "memcpy_h2d");
-}
+inline void add_const_in_place(Poly &p, const ScalarField &s) { p.add_to_constant_term(s); }
 inline Poly add_const(const Poly &p, const ScalarField &s) {
     Poly out = p.clone();
     add_const_in_place(out, s);
@@ -289,6 +286,11 @@ class Prover {
     // unity before they exist as coefficients (read_R1CS_gen_uvwXY, gen_bXY), and those are mostly zeros and small numbers.  With the
     // tables set, prove0 commits U, V, W, B as (1/N) MSM(evaluations, Lagrange table) + the blinding terms; the points are the same.
     DeviceVec<ScalarField> u_ev, v_ev, w_ev, b_ev;
+    // the permutation polynomials' evaluations on the m_I x s_max grid and their identity part (w_x^row, w_y^col) — kept by a resident
+    // context: prove1's f and g are then formed ON THE GRID (the forward transforms of lib.rs:1813-1830 are linear and exact, so the
+    // values are the same) instead of from coefficients through two transforms.  All in the COLS layout of a sharded prover.
+    DeviceVec<ScalarField> s0_ev, s1_ev;
+    const DeviceVec<ScalarField> *s0_identity = nullptr, *s1_identity = nullptr;
     const Sigma1 *lagrange_n = nullptr, *lagrange_mi = nullptr;   // grids n x s_max (u, v, w) and m_I x s_max (b)
     // prove1's r is a running product of g / f along the column-by-column walk of the m_I x s_max grid, and g / f = 1 wherever the copy
     // permutation is the identity: r is constant between the few cells the permutation touches.  Over the prefix sums of the Lagrange
@@ -414,8 +416,8 @@ class Prover {
         using namespace prover_detail;
         const Mixer &mx = mixer;
         const size_t n = sp.n, s_max = sp.s_max;
-        std::vector<G1Affine> c = Sigma1::run_jobs({lagrange_n->job_evals(u_ev, "U"), lagrange_n->job_evals(v_ev, "V"), lagrange_n->job_evals(w_ev, "W"),
-                                                    sigma->sigma1.job(Q_AX_XY, "Q_AX"), sigma->sigma1.job(Q_AY_XY, "Q_AY"), lagrange_mi->job_evals(b_ev, "B")});
+        std::vector<G1Affine> c = Sigma1::run_jobs({lagrange_n->job_evals(u_ev, "U", n, s_max), lagrange_n->job_evals(v_ev, "V", n, s_max), lagrange_n->job_evals(w_ev, "W", n, s_max),
+                                                    sigma->sigma1.job(Q_AX_XY, "Q_AX"), sigma->sigma1.job(Q_AY_XY, "Q_AY"), lagrange_mi->job_evals(b_ev, "B", m_i, s_max)});
         const ScalarField inv_n = fr_inv(fr_mul(fr_from_u32((uint32_t)n), fr_from_u32((uint32_t)s_max)));
         const ScalarField inv_mi = fr_inv(fr_mul(fr_from_u32((uint32_t)m_i), fr_from_u32((uint32_t)s_max)));
         using Row = std::vector<std::pair<ScalarField, G1Affine>>;
@@ -440,26 +442,98 @@ class Prover {
 
     // prove1 (lib.rs:1784-1956)
     Proof1 prove1(const std::vector<ScalarField> &thetas) {
-        size_t s_max = sp.s_max, cells = m_i * s_max;
-        auto f_g = fg(thetas);
-        f_g.first.resize(m_i, s_max);
-        f_g.second.resize(m_i, s_max);
-        DeviceVec<ScalarField> f_ev(cells), g_ev(cells), tr(cells), sfx(cells);
-        f_g.first.to_rou_evals(nullptr, nullptr, f_ev);
-        f_g.second.to_rou_evals(nullptr, nullptr, g_ev);
-        // r[last] = 1, r[idx] = r[idx + 1] * (g / f)[idx + 1] over the TRANSPOSED (s_max x m_i) order (lib.rs:1858-1866)
+        const size_t s_max = sp.s_max;
+        const DistCtx &dc = dist_ctx();
+        const size_t lc = Poly::local_cols(s_max, false);   // columns of the m_I x s_max grid on this rank (all of them on one GPU)
+        const size_t cells = m_i * lc;
         tkmk_vecops_config c = dev_cfg();
+        DeviceVec<ScalarField> f_ev(cells), g_ev(cells), tr(cells + 1), sfx(cells + 1);
+        const bool on_grid = b_ev.len() >= cells && s0_ev.len() >= cells && s1_ev.len() >= cells && s0_identity && s1_identity && m_i >= 2 && s_max >= 2;
+        if (on_grid) {
+            // f = b + th0 s0 + th1 s1 + th2 and g = b + th0 X + th1 Y + th2 evaluated where their operands already are evaluations
+            auto combine = [&](const DeviceVec<ScalarField> &a0, const DeviceVec<ScalarField> &a1, DeviceVec<ScalarField> &out) {
+                const ScalarField coef[3] = {fr_one(), thetas[0], thetas[1]};
+                const tkmk_fr *ptr[3] = {b_ev.ptr(), a0.ptr(), a1.ptr()};
+                const uint32_t xs[3] = {(uint32_t)m_i, (uint32_t)m_i, (uint32_t)m_i}, ys[3] = {(uint32_t)lc, (uint32_t)lc, (uint32_t)lc};
+                check(tkmk_poly_lincomb(3, coef, ptr, xs, ys, nullptr, nullptr, out.ptr(), (uint32_t)m_i, (uint32_t)lc, nullptr), "tkmk_poly_lincomb");
+                tkmk_vecops_config sc = dev_cfg();
+                sc.is_a_on_device = false;
+                check(bls12_381_scalar_add_vec(&thetas[2], out.ptr(), cells, &sc, out.ptr()), "scalar_add");
+            };
+            combine(s0_ev, s1_ev, f_ev);
+            combine(*s0_identity, *s1_identity, g_ev);
+        } else {
+            if (dc.on()) throw Error("prove1: a sharded prover needs the evaluation tables of a resident context");
+            auto f_g = fg(thetas);
+            f_g.first.resize(m_i, s_max);
+            f_g.second.resize(m_i, s_max);
+            f_g.first.to_rou_evals(nullptr, nullptr, f_ev);
+            f_g.second.to_rou_evals(nullptr, nullptr, g_ev);
+        }
+        // r[last] = 1, r[idx] = r[idx + 1] * (g / f)[idx + 1] over the TRANSPOSED (s_max x m_i) order (lib.rs:1858-1866): the walk goes down
+        // column 0, then column 1, ...
         check(bls12_381_vector_div(g_ev.ptr(), f_ev.ptr(), cells, &c, g_ev.ptr()), "vector_div");
-        check(bls12_381_matrix_transpose(g_ev.ptr(), (uint32_t)m_i, (uint32_t)s_max, &c, tr.ptr()), "transpose");
-        check(tkmk_vec_suffix_product(tr.ptr(), cells, sfx.ptr(), nullptr), "tkmk_vec_suffix_product");
-        check(bls12_381_matrix_transpose(sfx.ptr(), (uint32_t)s_max, (uint32_t)m_i, &c, tr.ptr()), "transpose");
-        rXY = Poly::from_rou_evals(tr, m_i, s_max);
-        if (lagrange_mi_prefix && cells >= 2) {
+        check(bls12_381_matrix_transpose(g_ev.ptr(), (uint32_t)m_i, (uint32_t)lc, &c, tr.ptr()), "transpose");
+        std::vector<ScalarField> next_top;   // sharded: r at the top of the column that FOLLOWS each local column in the walk
+        if (!dc.on()) {
+            check(tkmk_vec_suffix_product(tr.ptr(), cells, sfx.ptr(), nullptr), "tkmk_vec_suffix_product");
+        } else {
+            // My columns are c(k) = rank + G k.  The running product at (k, row) is the product of the rest of column k and of ALL later
+            // columns, mine and the other ranks'.  The column totals of every rank are gathered (s_max values); the other ranks' columns
+            // between c(k) and c(k + 1) enter as ONE factor O_k multiplied onto the first element of my next column, those after my last
+            // column as one element appended to the vector — and the ordinary scan over my columns gives the global running product.
+            const uint32_t G = dc.G(), r = dc.r();
+            DeviceVec<ScalarField> totals(lc);
+            tkmk_vecops_config pc = dev_cfg();
+            pc.batch_size = (int)lc;
+            check(bls12_381_vector_product(tr.ptr(), m_i, &pc, totals.ptr()), "vector_product");
+            std::vector<ScalarField> mine = totals.to_host(), all((size_t)G * lc);
+            check(dc.all_gather_host(dc.comm, mine.data(), lc * sizeof(ScalarField), all.data()), "tkmk_comm_all_gather_host");
+            auto total_of = [&](size_t col) { return all[(col % G) * lc + col / G]; };
+            std::vector<ScalarField> others(lc, fr_one());   // O_k
+            for (size_t k = 0; k < lc; k++)
+                for (size_t col = r + G * k + 1; col < std::min<size_t>(r + G * (k + 1), s_max); col++) others[k] = fr_mul(others[k], total_of(col));
+            if (lc > 1) {
+                std::vector<ScalarField> firsts(lc - 1);
+                DeviceVec<ScalarField> compact(lc - 1);
+                check(tkmk_memcpy_2d_d2d(compact.ptr(), sizeof(ScalarField), tr.ptr() + m_i, m_i * sizeof(ScalarField), sizeof(ScalarField), lc - 1), "gather column heads");
+                compact.copy_to_host(firsts.data(), lc - 1);
+                for (size_t k = 1; k < lc; k++) firsts[k - 1] = fr_mul(firsts[k - 1], others[k - 1]);
+                compact.copy_from_host(firsts.data(), lc - 1);
+                check(tkmk_memcpy_2d_d2d(tr.ptr() + m_i, m_i * sizeof(ScalarField), compact.ptr(), sizeof(ScalarField), sizeof(ScalarField), lc - 1), "scatter column heads");
+            }
+            check(tkmk_memcpy_h2d(tr.ptr() + cells, &others[lc - 1], sizeof(ScalarField)), "append");
+            check(tkmk_vec_suffix_product(tr.ptr(), cells + 1, sfx.ptr(), nullptr), "tkmk_vec_suffix_product");
+            // the value at the top of every column, for the jumps across column ends below
+            DeviceVec<ScalarField> tops(lc);
+            check(tkmk_memcpy_2d_d2d(tops.ptr(), sizeof(ScalarField), sfx.ptr(), m_i * sizeof(ScalarField), sizeof(ScalarField), lc), "gather column tops");
+            std::vector<ScalarField> my_tops = tops.to_host(), all_tops((size_t)G * lc);
+            check(dc.all_gather_host(dc.comm, my_tops.data(), lc * sizeof(ScalarField), all_tops.data()), "tkmk_comm_all_gather_host");
+            next_top.assign(lc, ScalarField{});
+            for (size_t k = 0; k < lc; k++) {
+                const size_t col = r + G * k + 1;
+                if (col < s_max) next_top[k] = all_tops[(col % G) * lc + col / G];
+            }
+        }
+        {
+            DeviceVec<ScalarField> r_ev(cells);
+            check(bls12_381_matrix_transpose(sfx.ptr(), (uint32_t)lc, (uint32_t)m_i, &c, r_ev.ptr()), "transpose");
+            rXY = Poly::from_rou_evals_cols(r_ev, m_i, s_max);
+        }
+        if (lagrange_mi_prefix && m_i * s_max >= 2) {
             // jumps of r along the walk: d_j = r_j - r_{j+1} (d_last = r_last), zero wherever g / f = 1
             DeviceVec<ScalarField> d(cells);
-            check(bls12_381_vector_sub(sfx.ptr(), sfx.ptr() + 1, cells - 1, &c, d.ptr()), "vector_sub");
+            if (cells > 1) check(bls12_381_vector_sub(sfx.ptr(), sfx.ptr() + 1, cells - 1, &c, d.ptr()), "vector_sub");
             check(tkmk_memcpy_d2d(d.ptr() + (cells - 1), sfx.ptr() + (cells - 1), sizeof(ScalarField)), "memcpy");
-            G1Affine core = Sigma1::run_jobs({lagrange_mi_prefix->job_evals(d, "R")})[0];
+            if (dc.on()) {   // the successor of a column's last cell is the top of the NEXT GLOBAL column, another rank's
+                DeviceVec<ScalarField> compact(lc);
+                check(tkmk_memcpy_2d_d2d(compact.ptr(), sizeof(ScalarField), sfx.ptr() + (m_i - 1), m_i * sizeof(ScalarField), sizeof(ScalarField), lc), "gather column ends");
+                std::vector<ScalarField> ends = compact.to_host();
+                for (size_t k = 0; k < lc; k++) ends[k] = fr_sub(ends[k], next_top[k]);
+                compact.copy_from_host(ends.data(), lc);
+                check(tkmk_memcpy_2d_d2d(d.ptr() + (m_i - 1), m_i * sizeof(ScalarField), compact.ptr(), sizeof(ScalarField), sizeof(ScalarField), lc), "scatter column ends");
+            }
+            G1Affine core = Sigma1::run_jobs({lagrange_mi_prefix->job_evals(d, "R", m_i * s_max, 1)})[0];
             const ScalarField inv_cells = fr_inv(fr_mul(fr_from_u32((uint32_t)m_i), fr_from_u32((uint32_t)s_max)));
             const Mixer &mx = mixer;
             std::vector<std::pair<ScalarField, G1Affine>> row = {{inv_cells, core},

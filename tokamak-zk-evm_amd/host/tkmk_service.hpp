@@ -23,30 +23,45 @@
 
 namespace tkmk {
 
-// One proof over the G GPUs of a node (include/tkmk_prover.h tkmk_prover_open_sharded; no reference
-// counterpart: the reference is single-device).  Every rank runs the whole prover — inputs, polynomial arithmetic and transcript are
-// replicated, so the Fiat-Shamir chain stays in lock step without a message — but holds only its 1/G of every commit table and
-// commits only its share of every polynomial; the shares meet in ONE all-gather of 144 bytes per commitment of a round.  The
-// entries of libtkmk_dist.so arrive as function pointers (the prover library does not link RCCL).
+// One proof over the G GPUs of a node (include/tkmk_prover.h tkmk_prover_open_sharded; no reference counterpart: the
+// reference is single-device).  Every rank holds 1 / G of every commit table AND of every polynomial: coefficient matrices live in the
+// COLS layout (rank r: the columns iy = r mod G), evaluations on the large domains in the ROWS layout (host/tkmk_host.hpp DistCtx,
+// include/tkmk_dist.h), a transform crosses between them with one all-to-all.  The witness side divides by placement (a placement IS a
+// column of u, v, w, b, s0, s1); a rank commits its columns of every polynomial against its columns of the table, and the shares of a
+// round's commitments meet in ONE all-gather.  Replicated: the host's parse of the three documents, the Fiat-Shamir transcript (every rank
+// derives the same challenges from the same commitments, so the rounds need no message) and the few small polynomials built from host
+// values.  The entries of libtkmk_dist.so arrive as function pointers (the prover library does not link RCCL).
 struct ShardLink {
     void *comm = nullptr;
     Shard shard;
     tkmk_error (*multi_ex_sharded)(void *, const tkmk_msm_job_ex *, int, const tkmk_msm_config *, int, tkmk_g1_projective *) = nullptr;
     tkmk_error (*broadcast_host)(void *, void *, size_t, int) = nullptr;
     tkmk_error (*device_turn)(void *, int) = nullptr;
+    tkmk_error (*all_gather_host)(void *, const void *, size_t, void *) = nullptr;
+    tkmk_error (*agree)(void *, tkmk_error) = nullptr;
+    tkmk_error (*abort)(void *) = nullptr;
+    tkmk_error (*fwd_cols_to_rows)(void *, const tkmk_fr *, size_t, size_t, size_t, size_t, int, tkmk_fr *) = nullptr;
+    tkmk_error (*inv_rows_to_cols)(void *, tkmk_fr *, size_t, size_t, int, tkmk_fr *) = nullptr;
+    tkmk_error (*rows_rotate)(void *, const tkmk_fr *, size_t, size_t, size_t, tkmk_fr *) = nullptr;
+    tkmk_error (*ring_shift)(void *, const void *, size_t, int, void *) = nullptr;
     explicit operator bool() const { return comm != nullptr; }
 };
-// for the span of one call on a sharded context: the commit batches of this thread go through the communicator, and (loopback
-// transport only) this virtual rank holds the device turn except while it waits for its peers
+// for the span of one call on a sharded context: this thread's polynomials are distributed (dist_ctx()), its commit batches go through the
+// communicator, and (loopback transport only) this virtual rank holds the device turn except while it waits for its peers
 struct ShardSpan {
     const ShardLink &link;
     explicit ShardSpan(const ShardLink &l) : link(l) {
         if (!link) return;
         check(link.device_turn(link.comm, 1), "tkmk_comm_device_turn");
         commit_comm() = CommitComm{link.comm, link.multi_ex_sharded};
+        DistCtx &dc = dist_ctx();
+        dc.comm = link.comm, dc.shard = link.shard;
+        dc.all_gather_host = link.all_gather_host, dc.fwd_cols_to_rows = link.fwd_cols_to_rows, dc.inv_rows_to_cols = link.inv_rows_to_cols;
+        dc.rows_rotate = link.rows_rotate, dc.ring_shift = link.ring_shift;
     }
     ~ShardSpan() {
         if (!link) return;
+        dist_ctx() = DistCtx{};
         commit_comm() = CommitComm{};
         (void)link.device_turn(link.comm, 0);
     }
@@ -160,6 +175,11 @@ class ProverContext {
         if (!is_pow2(sp.n)) throw Error("n is not a power of two.");
         if (!is_pow2(sp.s_max)) throw Error("s_max is not a power of two.");
         if (!is_pow2(c->m_i)) throw Error("m_I is not a power of two.");
+        if (c->link && c->link.shard.world > 1) {
+            const size_t G = c->link.shard.world;
+            if (!is_pow2(G)) throw Error("sharded prover: the number of ranks must be a power of two");
+            if (G > sp.s_max || G > std::min(sp.n, c->m_i)) throw Error("sharded prover: more ranks than the circuit has columns (s_max) or rows (n, m_I)");
+        }
         {
             const json::Value jinfo = json::read_file(lib_dir + "/subcircuitInfo.json");
             for (const json::Value &e : jinfo.items()) {
@@ -210,18 +230,31 @@ class ProverContext {
         c->n_wires_ = n_wires;
         c->iface_ = make_lists(iface), c->prv_ = make_lists(prv), c->pub_ = make_lists(pub);
 
-        // Permutation::to_poly's identity part (libs/src/iotools/mod.rs:419-437): s0[row][col] = w_x^row, s1[row][col] = w_y^col
+        // Permutation::to_poly's identity part (libs/src/iotools/mod.rs:419-437): s0[row][col] = w_x^row, s1[row][col] = w_y^col — this rank's
+        // columns of them (COLS layout: local column k is column rank + G k; all columns on one GPU)
         {
             const size_t m_i = c->m_i, s_max = sp.s_max;
-            std::vector<ScalarField> ones(m_i * s_max, fr_from_u32(1));
+            const Shard sh = c->link ? c->link.shard : Shard{};
+            const size_t lc = sh.cols_of(s_max);
+            std::vector<ScalarField> ones(m_i * lc, fr_from_u32(1));
             DeviceVec<ScalarField> base = DeviceVec<ScalarField>::from_host(ones);
             ScalarField wx = root_of_unity(m_i), wy = root_of_unity(s_max), one = fr_from_u32(1);
-            c->s0_identity_ = DeviceVec<ScalarField>(m_i * s_max), c->s1_identity_ = DeviceVec<ScalarField>(m_i * s_max);
-            check(tkmk_poly_scale_coeffs(base.ptr(), (uint32_t)m_i, (uint32_t)s_max, &wx, &one, c->s0_identity_.ptr(), nullptr), "s0 powers");
-            check(tkmk_poly_scale_coeffs(base.ptr(), (uint32_t)m_i, (uint32_t)s_max, &one, &wy, c->s1_identity_.ptr(), nullptr), "s1 powers");
-            c->xp_ = DeviceVec<ScalarField>(m_i), c->yp_ = DeviceVec<ScalarField>(s_max);
-            check(tkmk_memcpy_2d_d2d(c->xp_.ptr(), 32, c->s0_identity_.ptr(), 32 * s_max, 32, m_i), "x powers");   // column 0 of s0
-            check(tkmk_memcpy_d2d(c->yp_.ptr(), c->s1_identity_.ptr(), 32 * s_max), "y powers");                   // row 0 of s1
+            const ScalarField wy_g = fr_pow(wy, sh.world), wy_r = fr_pow(wy, sh.rank);
+            c->s0_identity_ = DeviceVec<ScalarField>(m_i * lc), c->s1_identity_ = DeviceVec<ScalarField>(m_i * lc);
+            check(tkmk_poly_scale_coeffs(base.ptr(), (uint32_t)m_i, (uint32_t)lc, &wx, &one, c->s0_identity_.ptr(), nullptr), "s0 powers");
+            check(tkmk_poly_scale_coeffs(base.ptr(), (uint32_t)m_i, (uint32_t)lc, &one, &wy_g, c->s1_identity_.ptr(), nullptr), "s1 powers");
+            if (sh.rank) {
+                tkmk_vecops_config vc = dev_cfg();
+                vc.is_a_on_device = false;
+                check(bls12_381_scalar_mul_vec(&wy_r, c->s1_identity_.ptr(), m_i * lc, &vc, c->s1_identity_.ptr()), "s1 powers");
+            }
+            // the two power tables the redirected cells read (indexed by the GLOBAL X / Y of a permutation entry): whole on every rank
+            std::vector<ScalarField> xp(m_i), yp(s_max);
+            ScalarField acc = one;
+            for (size_t i = 0; i < m_i; i++) xp[i] = acc, acc = fr_mul(acc, wx);
+            acc = one;
+            for (size_t j = 0; j < s_max; j++) yp[j] = acc, acc = fr_mul(acc, wy);
+            c->xp_ = DeviceVec<ScalarField>::from_host(xp), c->yp_ = DeviceVec<ScalarField>::from_host(yp);
         }
 
         host_trace("open: loading the CRS");
@@ -255,17 +288,20 @@ class ProverContext {
                         c->lagrange_n_.reset(new Sigma1(s1.lagrange_of(n, s_max)));
                     }
                 } else {
-                    // sharded: the group transforms run over the WHOLE grid on every rank (the inverse NTT over G1 points and the prefix
-                    // sums are not sharded: one-time work, seconds), each rank keeps its rows and expands only those into a commit table
+                    // sharded: the group transforms run over the WHOLE grid on every rank (one-time work, seconds); each rank keeps its
+                    // columns — a plain table over its own m_I x (s_max / G) part of the grid, committed against its own columns of the
+                    // evaluations (COLS layout on both sides) — and, of the walk-ordered prefix sums, the stretches of its columns
+                    // (the walk goes down column 0, then column 1, ...: one row of the s_max x m_I grid per column)
                     if (!whole_grid || !*whole_grid) throw Error("sharded open: the whole xy_powers grid was not handed over");
                     const Sigma1 &whole = **whole_grid;
                     const Shard sh = c->link.shard;
+                    const size_t lc = sh.cols_of(s_max);
                     DeviceVec<G1Affine> lam_mi = whole.lagrange_points(m_i, s_max);
                     {
                         DeviceVec<G1Affine> pre = Sigma1::lagrange_prefix_points(lam_mi, m_i, s_max);
-                        c->lagrange_mi_prefix_.reset(new Sigma1(Sigma1::rows_of_grid(pre, m_i * s_max, 1, sh), m_i * s_max, 1, s1.table_c(), sh));
+                        c->lagrange_mi_prefix_.reset(new Sigma1(Sigma1::rows_of_grid(pre, s_max, m_i, sh), lc * m_i, 1, s1.table_c()));
                     }
-                    std::unique_ptr<Sigma1> local_mi(new Sigma1(Sigma1::rows_of_grid(lam_mi, m_i, s_max, sh), m_i, s_max, s1.table_c(), sh));
+                    std::unique_ptr<Sigma1> local_mi(new Sigma1(Sigma1::cols_of_grid(lam_mi, m_i, s_max, sh), m_i, lc, s1.table_c()));
                     lam_mi = DeviceVec<G1Affine>();
                     if (m_i == n) {
                         c->lagrange_n_ = std::move(local_mi);
@@ -274,7 +310,7 @@ class ProverContext {
                         c->lagrange_mi_own_ = std::move(local_mi);
                         c->lagrange_mi_ = c->lagrange_mi_own_.get();
                         DeviceVec<G1Affine> lam_n = whole.lagrange_points(n, s_max);
-                        c->lagrange_n_.reset(new Sigma1(Sigma1::rows_of_grid(lam_n, n, s_max, sh), n, s_max, s1.table_c(), sh));
+                        c->lagrange_n_.reset(new Sigma1(Sigma1::cols_of_grid(lam_n, n, s_max, sh), n, lc, s1.table_c()));
                     }
                 }
             }
@@ -330,14 +366,28 @@ class ProverContext {
                 }
                 dst.swap(d2), srcx.swap(x2), srcy.swap(y2);
             }
-            // Permutation::to_poly (libs/src/iotools/mod.rs:419-455)
+            // Permutation::to_poly (libs/src/iotools/mod.rs:419-455).  Sharded: this rank redirects the cells of its own columns
+            // (col = rank mod G; local cell row * lc + col / G); the sources X, Y stay global indices into the two power tables
+            const Shard sh = link ? link.shard : Shard{};
+            const size_t lc = sh.cols_of(s_max);
+            if (sh.world > 1) {
+                std::vector<uint32_t> d2, x2, y2;
+                for (size_t e = 0; e < dst.size(); e++) {
+                    const uint32_t row = dst[e] / (uint32_t)s_max, col = dst[e] % (uint32_t)s_max;
+                    if (col % sh.world != sh.rank) continue;
+                    d2.push_back(row * (uint32_t)lc + col / sh.world), x2.push_back(srcx[e]), y2.push_back(srcy[e]);
+                }
+                dst.swap(d2), srcx.swap(x2), srcy.swap(y2);
+            }
             DeviceVec<ScalarField> e0 = s0_identity_.clone(), e1 = s1_identity_.clone();
             if (!dst.empty()) {
                 d_dst = DeviceVec<uint32_t>::from_host(dst), d_x = DeviceVec<uint32_t>::from_host(srcx), d_y = DeviceVec<uint32_t>::from_host(srcy);
                 check(tkmk_fr_scatter_table(xp_.ptr(), xp_.len(), d_x.ptr(), d_dst.ptr(), dst.size(), e0.ptr(), e0.len(), nullptr), "tkmk_fr_scatter_table");
                 check(tkmk_fr_scatter_table(yp_.ptr(), yp_.len(), d_y.ptr(), d_dst.ptr(), dst.size(), e1.ptr(), e1.len(), nullptr), "tkmk_fr_scatter_table");
             }
-            p->s0XY = Poly::from_rou_evals(e0, m_i, s_max), p->s1XY = Poly::from_rou_evals(e1, m_i, s_max);
+            p->s0XY = Poly::from_rou_evals_cols(e0, m_i, s_max), p->s1XY = Poly::from_rou_evals_cols(e1, m_i, s_max);
+            p->s0_ev = std::move(e0), p->s1_ev = std::move(e1);   // prove1 forms f and g on the grid from these
+            p->s0_identity = &s0_identity_, p->s1_identity = &s1_identity_;
         }
         MappedFile pv_file(synth_dir + "/placementVariables.json");
         WitnessLayout W = parse_placement_variables_fast(pv_file.data(), pv_file.size(), n_wires_, [&](uint64_t total) { return staging(total); }, threads);
@@ -349,16 +399,24 @@ class ProverContext {
             a_pub_user = hex_list(jinst.at("a_pub_user"));
             a_pub_block = hex_list(jinst.at("a_pub_block"));
         }
-        // placements grouped by kind: slot list, variable offsets, position of each kind's run
-        std::vector<uint32_t> kind_first(K + 1, 0), slots(P ? P : 1);
-        std::vector<uint64_t> offs(P ? P : 1);
-        for (size_t q = 0; q < P; q++) kind_first[W.id[q] + 1]++;
+        // placements grouped by kind: slot list, variable offsets, position of each kind's run.  Sharded: a placement is a column of
+        // u, v, w, b — this rank takes the placements q = rank mod G; `slots` are their local columns q / G, `gslots` the global ones
+        // (the binding tables are indexed by the global slot)
+        const Shard sh = link ? link.shard : Shard{};
+        const size_t lc = sh.cols_of(s_max);
+        std::vector<uint32_t> mine_q;
+        for (size_t q = sh.rank; q < P; q += sh.world) mine_q.push_back((uint32_t)q);
+        const size_t PL = mine_q.size();
+        std::vector<uint32_t> kind_first(K + 1, 0), slots(PL ? PL : 1), gslots(PL ? PL : 1), ids_local(PL ? PL : 1);
+        std::vector<uint64_t> offs(PL ? PL : 1), offs_local(PL ? PL : 1);
+        for (size_t k = 0; k < PL; k++) kind_first[W.id[mine_q[k]] + 1]++, ids_local[k] = W.id[mine_q[k]], offs_local[k] = W.off[mine_q[k]];
         for (size_t k = 0; k < K; k++) kind_first[k + 1] += kind_first[k];
         {
             std::vector<uint32_t> cur(kind_first.begin(), kind_first.end() - 1);
-            for (size_t q = 0; q < P; q++) {
+            for (size_t k = 0; k < PL; k++) {
+                const uint32_t q = mine_q[k];
                 uint32_t at = cur[W.id[q]]++;
-                slots[at] = (uint32_t)q, offs[at] = W.off[q];
+                slots[at] = (uint32_t)k, gslots[at] = q, offs[at] = W.off[q];
             }
         }
         tm.parse = Prover::now() - t0;
@@ -367,19 +425,19 @@ class ProverContext {
         const double t1 = Prover::now();
         DeviceVec<ScalarField> d_vars((size_t)W.total + 1);
         if (W.total) check(tkmk_memcpy_h2d(d_vars.ptr(), pinned_, (size_t)W.total * sizeof(ScalarField)), "witness upload");
-        DeviceVec<uint32_t> d_id = DeviceVec<uint32_t>::from_host(W.id.empty() ? std::vector<uint32_t>{0} : W.id);
-        DeviceVec<uint64_t> d_off = DeviceVec<uint64_t>::from_host(W.off.empty() ? std::vector<uint64_t>{0} : W.off);
-        DeviceVec<uint32_t> d_slots = DeviceVec<uint32_t>::from_host(slots);
+        DeviceVec<uint32_t> d_id = DeviceVec<uint32_t>::from_host(ids_local);
+        DeviceVec<uint64_t> d_off = DeviceVec<uint64_t>::from_host(offs_local);
+        DeviceVec<uint32_t> d_slots = DeviceVec<uint32_t>::from_host(slots), d_gslots = DeviceVec<uint32_t>::from_host(gslots);
         DeviceVec<uint64_t> d_offs = DeviceVec<uint64_t>::from_host(offs);
         tm.upload = Prover::now() - t1;
 
         // ---- polynomials
         const double t2 = Prover::now();
-        {   // read_R1CS_gen_uvwXY (libs/src/iotools/mod.rs:1287-1420)
-            DeviceVec<ScalarField> u(n * s_max), v(n * s_max), w(n * s_max);
-            check(tkmk_r1cs_library_eval(lib_, d_vars.ptr(), d_id.ptr(), d_off.ptr(), (uint32_t)P, (uint32_t)n, (uint32_t)s_max, u.ptr(), v.ptr(), w.ptr(), nullptr),
+        {   // read_R1CS_gen_uvwXY (libs/src/iotools/mod.rs:1287-1420): one column per placement — this rank's placements, its columns
+            DeviceVec<ScalarField> u(n * lc), v(n * lc), w(n * lc);
+            check(tkmk_r1cs_library_eval(lib_, d_vars.ptr(), d_id.ptr(), d_off.ptr(), (uint32_t)PL, (uint32_t)n, (uint32_t)lc, u.ptr(), v.ptr(), w.ptr(), nullptr),
                   "tkmk_r1cs_library_eval");
-            p->uXY = Poly::from_rou_evals(u, n, s_max), p->vXY = Poly::from_rou_evals(v, n, s_max), p->wXY = Poly::from_rou_evals(w, n, s_max);
+            p->uXY = Poly::from_rou_evals_cols(u, n, s_max), p->vXY = Poly::from_rou_evals_cols(v, n, s_max), p->wXY = Poly::from_rou_evals_cols(w, n, s_max);
             if (lagrange_n_) p->u_ev = std::move(u), p->v_ev = std::move(v), p->w_ev = std::move(w);   // prove0 commits from these
         }
         // gen_bXY + the (scalar, CRS row) lists of O_mid / O_prv / O_pub_free, kind by kind
@@ -390,33 +448,45 @@ class ProverContext {
             mid_at[k] = n_mid, prv_at[k] = n_prv, pub_at[k] = n_pub;
             n_mid += cnt * iface_.count(k), n_prv += cnt * prv_.count(k), n_pub += cnt * pub_.count(k);
         }
-        // nVar checks of encode_statement_common (libs/src/group_structures/mod.rs:231-264, 294-296)
+        // nVar checks of encode_statement_common (libs/src/group_structures/mod.rs:231-264, 294-296), over ALL placements
         {
             std::vector<PlacementVariables> shape(P);
-            for (size_t q = 0; q < P; q++) shape[q].subcircuitId = W.id[q];
-            if (n_mid != count_o_mid_nvar(shape, infos) || n_prv != count_o_prv_nvar(shape, infos)) throw Error("nVar mismatch while encoding statement");
+            uint64_t all_mid = 0, all_prv = 0;
+            for (size_t q = 0; q < P; q++) shape[q].subcircuitId = W.id[q], all_mid += iface_.count(W.id[q]), all_prv += prv_.count(W.id[q]);
+            if (all_mid != count_o_mid_nvar(shape, infos) || all_prv != count_o_prv_nvar(shape, infos)) throw Error("nVar mismatch while encoding statement");
         }
         if (n_mid >= (1ull << 31) || n_prv >= (1ull << 31)) throw Error("binding commitment too large");
-        DeviceVec<ScalarField> b_ev(m_i * s_max), mid_sc(n_mid + 1), prv_sc(n_prv + 1), pub_sc(n_pub + 1);
+        DeviceVec<ScalarField> b_ev(m_i * lc), mid_sc(n_mid + 1), prv_sc(n_prv + 1), pub_sc(n_pub + 1);
         DeviceVec<uint32_t> mid_ix(n_mid + 1), prv_ix(n_prv + 1), pub_ix(n_pub + 1);
-        check(tkmk_memset(b_ev.ptr(), 0, m_i * s_max * sizeof(ScalarField)), "memset");
+        if (m_i * lc) check(tkmk_memset(b_ev.ptr(), 0, m_i * lc * sizeof(ScalarField)), "memset");
         for (size_t k = 0; k < K; k++) {
             uint32_t cnt = kind_first[k + 1] - kind_first[k];
             if (!cnt) continue;
             const uint64_t *vo = d_offs.ptr() + kind_first[k];
-            const uint32_t *sl = d_slots.ptr() + kind_first[k];
-            check(tkmk_witness_route(d_vars.ptr(), vo, sl, cnt, iface_.wire.ptr() + iface_.first[k], iface_.row.ptr() + iface_.first[k], iface_.count(k), b_ev.ptr(),
-                                     (uint32_t)s_max, mid_sc.ptr() + mid_at[k], mid_ix.ptr() + mid_at[k], (uint32_t)s_max, 1, nullptr),
-                  "tkmk_witness_route");
-            check(tkmk_witness_route(d_vars.ptr(), vo, sl, cnt, prv_.wire.ptr() + prv_.first[k], prv_.row.ptr() + prv_.first[k], prv_.count(k), nullptr, 0,
+            const uint32_t *sl = d_slots.ptr() + kind_first[k], *gsl = d_gslots.ptr() + kind_first[k];
+            if (sh.world == 1) {
+                check(tkmk_witness_route(d_vars.ptr(), vo, sl, cnt, iface_.wire.ptr() + iface_.first[k], iface_.row.ptr() + iface_.first[k], iface_.count(k), b_ev.ptr(),
+                                         (uint32_t)s_max, mid_sc.ptr() + mid_at[k], mid_ix.ptr() + mid_at[k], (uint32_t)s_max, 1, nullptr),
+                      "tkmk_witness_route");
+            } else {
+                // the interface matrix takes the LOCAL column of a placement, the binding table's row index its GLOBAL slot: two calls
+                check(tkmk_witness_route(d_vars.ptr(), vo, sl, cnt, iface_.wire.ptr() + iface_.first[k], iface_.row.ptr() + iface_.first[k], iface_.count(k), b_ev.ptr(),
+                                         (uint32_t)lc, nullptr, nullptr, 0, 0, nullptr),
+                      "tkmk_witness_route");
+                check(tkmk_witness_route(d_vars.ptr(), vo, gsl, cnt, iface_.wire.ptr() + iface_.first[k], iface_.row.ptr() + iface_.first[k], iface_.count(k), nullptr, 0,
+                                         mid_sc.ptr() + mid_at[k], mid_ix.ptr() + mid_at[k], (uint32_t)s_max, 1, nullptr),
+                      "tkmk_witness_route");
+            }
+            check(tkmk_witness_route(d_vars.ptr(), vo, gsl, cnt, prv_.wire.ptr() + prv_.first[k], prv_.row.ptr() + prv_.first[k], prv_.count(k), nullptr, 0,
                                      prv_sc.ptr() + prv_at[k], prv_ix.ptr() + prv_at[k], (uint32_t)s_max, 1, nullptr),
                   "tkmk_witness_route");
-            check(tkmk_witness_route(d_vars.ptr(), vo, sl, cnt, pub_.wire.ptr() + pub_.first[k], pub_.row.ptr() + pub_.first[k], pub_.count(k), nullptr, 0,
+            check(tkmk_witness_route(d_vars.ptr(), vo, gsl, cnt, pub_.wire.ptr() + pub_.first[k], pub_.row.ptr() + pub_.first[k], pub_.count(k), nullptr, 0,
                                      pub_sc.ptr() + pub_at[k], pub_ix.ptr() + pub_at[k], 1, 0, nullptr),
                   "tkmk_witness_route");
         }
-        p->bXY = Poly::from_rou_evals(b_ev, m_i, s_max);
-        if (lagrange_mi_) p->b_ev = std::move(b_ev), p->lagrange_n = lagrange_n_.get(), p->lagrange_mi = lagrange_mi_, p->lagrange_mi_prefix = lagrange_mi_prefix_.get();
+        p->bXY = Poly::from_rou_evals_cols(b_ev, m_i, s_max);
+        p->b_ev = std::move(b_ev);   // prove1 forms f and g on the grid from it; with the Lagrange tables prove0 commits B from it too
+        if (lagrange_mi_) p->lagrange_n = lagrange_n_.get(), p->lagrange_mi = lagrange_mi_, p->lagrange_mi_prefix = lagrange_mi_prefix_.get();
         p->rXY = Poly::zero();
         p->a_free_X = gen_a_free_X(a_pub_user, a_pub_block, sp);
         p->t_n = vanishing(n, true), p->t_mi = vanishing(m_i, true), p->t_smax = vanishing(s_max, false);
@@ -427,12 +497,10 @@ class ProverContext {
         const double t3 = Prover::now();
         const Mixer &mx = mixer;
         Binding b;
-        // sharded: the binding tables are replicated and a rank commits its slice [cnt r / G, cnt (r + 1) / G) of the (scalar, row) list
-        const Shard sh = link ? link.shard : Shard{};
-        auto indexed = [sh](const DeviceVec<ScalarField> &sc, const DeviceVec<uint32_t> &ix, uint64_t cnt, const DeviceVec<G1Affine> &table) {
-            const uint64_t lo = cnt * sh.rank / sh.world, hi = cnt * (sh.rank + 1) / sh.world;
+        // sharded: the binding tables are replicated and a rank commits the (scalar, row) lists of its own placements
+        auto indexed = [](const DeviceVec<ScalarField> &sc, const DeviceVec<uint32_t> &ix, uint64_t cnt, const DeviceVec<G1Affine> &table) {
             tkmk_msm_job_ex j{};
-            j.scalars = sc.ptr() + lo, j.bases = table.ptr(), j.msm_size = (int)(hi - lo), j.base_index = ix.ptr() + lo, j.base_table_len = table.len();
+            j.scalars = sc.ptr(), j.bases = table.ptr(), j.msm_size = (int)cnt, j.base_index = ix.ptr(), j.base_table_len = table.len();
             return j;
         };
         std::vector<tkmk_msm_job_ex> binding_jobs = {sigma->sigma1.job(p->a_free_X, "A_free"), indexed(pub_sc, pub_ix, n_pub, sigma->gamma_inv_o_inst),
@@ -500,14 +568,23 @@ class ProverContext {
         if (link) check(link.broadcast_host(link.comm, &mixer, sizeof mixer, 0), "tkmk_comm_broadcast_host");
         std::pair<std::unique_ptr<Prover>, Binding> pb;
         std::unique_ptr<PendingBinding> pending;   // declared after pb: destroyed (and thereby waited for) BEFORE the prover whose a_free_X it reads
-        pb = init(synth_dir, mixer, tm, &pending);
-        if (flags & 2) pb.first->lagrange_n = pb.first->lagrange_mi = pb.first->lagrange_mi_prefix = nullptr;
         std::map<std::string, double> times;
         Proof proof;
         try {
+            pb = init(synth_dir, mixer, tm, &pending);
+            if (flags & 2) pb.first->lagrange_n = pb.first->lagrange_mi = pb.first->lagrange_mi_prefix = nullptr;
             proof = run_rounds(*pb.first, pb.second, &times, (flags & 1) != 0);
-        } catch (...) {
+        } catch (const Error &e) {
             if (pending && pending->cores.valid()) pending->cores.wait();   // the batch reads a_free_X of the prover about to go
+            // A rank that leaves between two collectives must not leave its peers waiting in the next one.  What the replicated inputs
+            // decide — a malformed document, a shape that does not fit (invalid argument / pointer) — fails every rank at the same point
+            // and the communicator lives on; a failure only this rank may have had (memory, a device or transport error) aborts it.
+            const bool replicated_cause = e.code == TKMK_ERR_INVALID_ARGUMENT || e.code == TKMK_ERR_INVALID_POINTER;
+            if (link && link.shard.world > 1 && !replicated_cause) (void)link.abort(link.comm);
+            throw;
+        } catch (...) {
+            if (pending && pending->cores.valid()) pending->cores.wait();
+            if (link && link.shard.world > 1) (void)link.abort(link.comm);
             throw;
         }
         if (pending) {   // collect the binding commitments issued during init
@@ -519,14 +596,20 @@ class ProverContext {
         int k = 0;
         for (const char *name : {"prove0", "prove1", "prove2", "prove3", "prove4"}) tm.prove[k++] = times[name];
         const double tw = Prover::now();
-        if (!out_dir.empty()) {
+        // sharded: the ranks hold one and the same proof; they agree that all of them got there, and rank 0 alone writes the file
+        // (G writers truncating one path at once is how a reader sees half a document)
+        if (link && link.shard.world > 1) check(link.agree(link.comm, TKMK_SUCCESS), "tkmk_comm_agree");
+        if (!out_dir.empty() && (!link || link.shard.rank == 0)) {
             ::mkdir(out_dir.c_str(), 0777);
-            std::string path = out_dir + "/proof.json";
-            std::ofstream f(path);
-            if (!f) throw Error("cannot write " + path);
-            f << proof.to_json();
-            f.close();
-            if (!f) throw Error("cannot write " + path);
+            const std::string path = out_dir + "/proof.json", tmp_path = path + ".tmp";
+            {
+                std::ofstream f(tmp_path);
+                if (!f) throw Error("cannot write " + tmp_path);
+                f << proof.to_json();
+                f.close();
+                if (!f) throw Error("cannot write " + tmp_path);
+            }
+            if (::rename(tmp_path.c_str(), path.c_str()) != 0) throw Error("cannot write " + path);
         }
         tm.write = Prover::now() - tw;
         tm.total = Prover::now() - t0;

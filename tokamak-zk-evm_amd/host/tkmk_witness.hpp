@@ -220,7 +220,7 @@ inline DensePolynomialExt gen_a_free_X(const std::vector<ScalarField> &a_pub_use
     std::vector<ScalarField> v(a_pub_user.begin(), a_pub_user.begin() + sp.l_user);
     v.insert(v.end(), a_pub_block.begin(), a_pub_block.begin() + (sp.l_free - sp.l_user));
     DeviceVec<ScalarField> ev = DeviceVec<ScalarField>::from_host(v);
-    return DensePolynomialExt::from_rou_evals(ev, sp.l_free, 1);
+    return DensePolynomialExt::from_rou_evals_rep(ev, sp.l_free, 1);   // the public inputs: the same on every rank
 }
 
 }  // namespace tkmk

@@ -91,7 +91,7 @@ SYMBOLS = [
     "bls12_381_scalar_sub_vec", "bls12_381_scalar_mul_vec", "bls12_381_vector_sum", "bls12_381_vector_product",
     "bls12_381_matrix_transpose", "tkmk_vec_suffix_product", "tkmk_fr_random_device", "tkmk_gather_rows_device", "tkmk_g1_batch_scalar_mul_device", "tkmk_profile_enable",
     "tkmk_profile_reset", "tkmk_profile_get", "tkmk_diag_bench", "tkmk_diag_field_mul", "tkmk_poly_find_degree",
-    "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_mul_ones_x", "tkmk_poly_expr_eval", "tkmk_poly_expr_eval_views", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
+    "tkmk_poly_place", "tkmk_poly_scale_coeffs", "tkmk_poly_mul_x_minus_one_evals", "tkmk_poly_mul_ones_x", "tkmk_poly_expr_eval", "tkmk_poly_expr_eval_views", "tkmk_poly_expr_eval_views_slab", "tkmk_poly_eval_x", "tkmk_poly_eval_y", "tkmk_poly_eval",
     "tkmk_poly_div_by_vanishing_opt", "tkmk_poly_div_by_ruffini", "tkmk_r1cs_eval_rows",
     "tkmk_msm_multi_ex", "bls12_381_msm_convert_bases", "tkmk_r1cs_library_create", "tkmk_r1cs_library_destroy", "tkmk_r1cs_library_eval",
     "tkmk_witness_route", "tkmk_fr_scatter_table", "tkmk_msm_set_pipeline_streams", "tkmk_msm_get_pipeline_streams", "tkmk_host_malloc", "tkmk_host_free", "tkmk_stats_reset", "tkmk_stats_get",

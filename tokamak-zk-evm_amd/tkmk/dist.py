@@ -15,7 +15,10 @@ _lib = None
 # every symbol include/tkmk_dist.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["tkmk_comm_unique_id", "tkmk_comm_init", "tkmk_comm_init_loopback", "tkmk_comm_is_loopback", "tkmk_comm_device_turn",
            "tkmk_comm_broadcast_host", "tkmk_comm_destroy", "tkmk_comm_rank",
-           "tkmk_comm_size", "tkmk_dist_last_error", "tkmk_msm_sharded", "tkmk_msm_multi_ex_sharded", "tkmk_bintt_sharded"]
+           "tkmk_comm_size", "tkmk_dist_last_error", "tkmk_msm_sharded", "tkmk_msm_multi_ex_sharded", "tkmk_bintt_sharded",
+           "tkmk_comm_all_gather_host", "tkmk_comm_all_gather_dev", "tkmk_comm_agree", "tkmk_comm_abort", "tkmk_dist_fwd_cols_to_rows",
+           "tkmk_dist_inv_rows_to_cols", "tkmk_dist_rows_rotate", "tkmk_comm_ring_shift", "tkmk_comm_describe"]
+SKIP_X_PASS, SKIP_Y_PASS = 1, 2          # TKMK_DIST_* of include/tkmk_dist.h
 
 
 def lib():
@@ -30,6 +33,8 @@ def lib():
         _lib.tkmk_comm_rank.argtypes = [ctypes.c_void_p]
         _lib.tkmk_comm_size.argtypes = [ctypes.c_void_p]
         _lib.tkmk_comm_is_loopback.argtypes = [ctypes.c_void_p]
+        _lib.tkmk_comm_abort.argtypes = [ctypes.c_void_p]
+        _lib.tkmk_comm_agree.argtypes = [ctypes.c_void_p, ctypes.c_int]
     return _lib
 
 
@@ -89,6 +94,52 @@ class Comm:
         out = tkmk.DeviceBuffer(32 * x_size * (y_size // self.world)) if out is None else out
         _check(lib().tkmk_bintt_sharded(self._h, tkmk._p(slab), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size), 1 if inverse else 0,
                                         tkmk._p(coset_x), tkmk._p(coset_y), tkmk._p(out)), "tkmk_bintt_sharded")
+        return out
+
+    def all_gather_host(self, data):
+        """data: bytes-like of one fixed length on every rank -> list of world byte strings"""
+        send = np.frombuffer(bytes(data), np.uint8)
+        recv = np.empty(send.size * self.world, np.uint8)
+        _check(lib().tkmk_comm_all_gather_host(self._h, tkmk._p(send), ctypes.c_size_t(send.size), tkmk._p(recv)), "tkmk_comm_all_gather_host")
+        return [recv[q * send.size:(q + 1) * send.size].tobytes() for q in range(self.world)]
+
+    def describe(self):
+        """this rank's line (dict): transport, size, rank, RCCL's own count / rank, RCCL version, device PCI bus id and UUID"""
+        import json
+        buf = ctypes.create_string_buffer(512)
+        _check(lib().tkmk_comm_describe(self._h, buf, ctypes.c_size_t(512)), "tkmk_comm_describe")
+        return json.loads(buf.value.decode())
+
+    def describe_all(self):
+        """every rank's line, gathered OVER THIS COMMUNICATOR (collective: all ranks call it)"""
+        import json
+        mine = json.dumps(self.describe()).encode().ljust(512, b" ")
+        return [json.loads(b.decode()) for b in self.all_gather_host(mine)]
+
+    def agree(self, status=0):
+        _check(lib().tkmk_comm_agree(self._h, int(status)), "tkmk_comm_agree")
+
+    def abort(self):
+        lib().tkmk_comm_abort(self._h)
+
+    def fwd_cols_to_rows(self, cols, in_x, in_y, x_size, y_size, flags=0):
+        """cols: DeviceBuffer, this rank's in_x x (in_y / G) COLS matrix -> DeviceBuffer with its (x_size / G) x y_size ROWS slab"""
+        out = tkmk.DeviceBuffer(32 * (x_size // self.world) * y_size)
+        _check(lib().tkmk_dist_fwd_cols_to_rows(self._h, tkmk._p(cols), ctypes.c_size_t(in_x), ctypes.c_size_t(in_y), ctypes.c_size_t(x_size),
+                                                ctypes.c_size_t(y_size), int(flags), tkmk._p(out)), "tkmk_dist_fwd_cols_to_rows")
+        return out
+
+    def inv_rows_to_cols(self, rows, x_size, y_size, flags=0):
+        """rows: DeviceBuffer, this rank's ROWS slab (overwritten) -> DeviceBuffer with its x_size x (y_size / G) COLS matrix"""
+        out = tkmk.DeviceBuffer(32 * x_size * (y_size // self.world))
+        _check(lib().tkmk_dist_inv_rows_to_cols(self._h, tkmk._p(rows), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size), int(flags), tkmk._p(out)),
+               "tkmk_dist_inv_rows_to_cols")
+        return out
+
+    def rows_rotate(self, slab, h, y_size, rot):
+        out = tkmk.DeviceBuffer(32 * h * y_size)
+        _check(lib().tkmk_dist_rows_rotate(self._h, tkmk._p(slab), ctypes.c_size_t(h), ctypes.c_size_t(y_size), ctypes.c_size_t(rot), tkmk._p(out)),
+               "tkmk_dist_rows_rotate")
         return out
 
     def close(self):
