@@ -18,8 +18,20 @@
  * (0,0) = point at infinity; G1 projective = {x, y, z} 144 B, homogeneous (X/Z, Y/Z), z = 0 = infinity.
  *
  * ERRORS: every function returns a tkmk_error (0 = success); nothing throws or aborts across the ABI.
- * THREADING: calls may be issued from one host thread at a time per stream (the reference issues all
- * device calls from its main thread: SURVEY.md §8b); the NTT domain is process-global like ICICLE's.
+ * THREADING (the contract, in full):
+ *   - one host thread at a time PER STREAM: every entry keeps its scratch in a grow-only arena that belongs to the stream it is
+ *     given (stream_handle / the `stream` argument; NULL = the default stream), so two threads may call concurrently only if they
+ *     name DIFFERENT streams (the reference issues all device calls from its main thread: SURVEY.md section 8b);
+ *   - one MSM BATCH at a time per process: bls12_381_msm (batch or single), tkmk_msm_multi and tkmk_msm_multi_ex run their
+ *     jobs over a process-wide set of pipeline streams and pinned result buffers behind one lock, held from the first job's launch
+ *     to the last job's result — a second thread's MSM call waits for the whole batch of the first (results are unaffected; the
+ *     resident prover's binding-commitment helper thread relies on exactly this);
+ *   - process-global state: the NTT domain (like ICICLE's; initialise / grow it from one thread while no transform runs), the
+ *     device binding (tkmk_set_device: one device per process), the allocator's cache, the pipeline width
+ *     (tkmk_msm_set_pipeline_streams), the profile / stats counters;
+ *   - libtkmk_prover.so: a context issues everything on the default stream, so the library serialises tkmk_prover_open / _prove /
+ *     _close of UNSHARDED contexts of one process behind one lock (two contexts prove one after the other, byte for byte as they
+ *     would alone); a sharded context's ranks are one process per GPU (or take turns through the loopback communicator).
  * There is NO CPU fallback: without a usable gfx950 device every compute entry returns
  * TKMK_ERR_NO_DEVICE.
  */

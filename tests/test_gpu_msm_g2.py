@@ -42,7 +42,7 @@ def test_g2_msm_vs_oracle(gpu, oracle, n):
 
 
 def test_g2_msm_edge_cases(gpu, oracle):
-    n = 300
+    n = 128                                         # (the oracle's naive G2 MSM is what this test's time goes to)
     p = oracle.g2.random_bases(7, n).reshape(n, 192).copy()
     vals = [0, 1, R - 1, R - 2, 2, (1 << 255) % R, (1 << 254), R >> 1] + [int.from_bytes(bytes(oracle.fr_random(5, n)[32 * i:32 * i + 32]), "little") for i in range(8, n)]
     p[3] = 0                                        # an infinity record among the bases
@@ -59,7 +59,7 @@ def test_g2_msm_edge_cases(gpu, oracle):
     assert (_affine(gpu.msm_g2(s, np.zeros(192 * n, np.uint8)))[0] == zero).all()
     assert (_affine(gpu.msm_g2(np.zeros(0, np.uint8), np.zeros(0, np.uint8), msm_size=0))[0] == zero).all()
     # one heavily repeated scalar: one giant bucket per window (the queued big-bucket path)
-    n2 = 5000
+    n2 = 1500
     p2 = oracle.g2.random_bases(8, n2)
     s2 = np.tile(_scalars([0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % R]), n2)
     assert (_affine(gpu.msm_g2(s2, p2))[0] == oracle.g2.msm(s2, p2)).all()

@@ -71,6 +71,9 @@ def test_binaries_open_the_real_library_and_the_proof_verifies(gpu, runtime):
         assert runtime["library"] in runtime["logs"][name], name
     assert verify_files.verify(runtime["library"], d["synthesizer"], d["setup"], d["prove"])
     assert not verify_files.verify(runtime["library"], d["synthesizer"], d["setup"], d["prove"], tamper_public_input=True)
+    # and from the verifier's own files alone, as tokamak-cli's verify stage has them (sigma_verify.json instead of the prover's CRS)
+    assert verify_files.verify(runtime["library"], d["synthesizer"], d["setup"], d["prove"], from_sigma_verify=True)
+    assert not verify_files.verify(runtime["library"], d["synthesizer"], d["setup"], d["prove"], tamper_public_input=True, from_sigma_verify=True)
 
 
 def test_crs_sections_have_the_sizes_the_real_parameters_dictate(gpu, runtime):

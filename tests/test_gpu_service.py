@@ -307,3 +307,73 @@ def test_msm_table_jobs_wide_windows_single_bucket_set(gpu, oracle, c):
     if c > 16:      # too small for a wide window: refused, not silently narrowed
         with pytest.raises(tk.TkmkError):
             tk.msm_multi_ex([dict(scalars=d_coeffs, bases=d_table, n=1000, table_len=rows * cols, table=(c, windows))], bases_form=tk.BASES_CONVERTED)
+
+
+def test_two_contexts_prove_concurrently_in_one_process(gpu, oracle, tmp_path):
+    """include/tkmk.h THREADING: two UNSHARDED contexts of one process take turns on the default stream behind the prover library's lock —
+    two threads proving two different circuits at the same time get, byte for byte, the proofs they get one after the other"""
+    import threading
+    import synth_circuit
+    from test_gpu_prove import _stage_crs_file, seeded_mixer
+    from tkmk import service
+    jobs = []
+    for k, (seed, shape) in enumerate([(91, dict(s_max=8, n_gate_kinds=2)), (92, dict(s_max=16, n_gate_kinds=3, n_out=2, n_in=3, n_prv=9, used_placements=11))]):
+        d = tmp_path / ("c%d" % k)
+        d.mkdir()
+        inst = synth_circuit.build(str(d), random.Random(seed), **shape)
+        _stage_crs_file(gpu, oracle, inst, str(d / "crs"))
+        jobs.append((inst, str(d / "crs"), _mixer_file(d, seeded_mixer(seed))))
+    provers = [service.Prover(inst["qap"], crs, testing=True) for inst, crs, _ in jobs]
+    try:
+        alone = [p.prove(inst["synth"], None, testing_mixer_json=m)[0] for p, (inst, _, m) in zip(provers, jobs)]
+        together, errors = [None, None], []
+
+        def body(k):
+            try:
+                for _ in range(3):
+                    together[k] = provers[k].prove(jobs[k][0]["synth"], None, testing_mixer_json=jobs[k][2])[0]
+            except BaseException as e:      # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=body, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert together == alone
+    finally:
+        for p in provers:
+            p.close()
+
+
+def test_helper_thread_pipeline_width_and_profiling_do_not_change_a_byte(gpu, oracle, tmp_path, monkeypatch):
+    """the binding batch on its helper thread (TKMK_PROVER_ASYNC_BINDING, default on) against in line, three pipeline streams against one,
+    the event profiler on against off: one and the same proof.json for the same blinding scalars"""
+    import synth_circuit
+    from test_gpu_prove import _stage_crs_file, seeded_mixer
+    from tkmk import service
+    inst = synth_circuit.build(str(tmp_path), random.Random(93), s_max=16, n_gate_kinds=3, n_out=2, n_in=3, n_prv=9, used_placements=13, bit_fraction=0.5)
+    crs_dir = str(tmp_path / "crs")
+    _stage_crs_file(gpu, oracle, inst, crs_dir)
+    mixer_path = _mixer_file(tmp_path, seeded_mixer(93))
+    monkeypatch.setenv("TKMK_PROVER_TABLE_C", "12")
+    docs = {}
+    with service.Prover(inst["qap"], crs_dir, testing=True) as p:
+        docs["default"] = p.prove(inst["synth"], None, testing_mixer_json=mixer_path)[0]
+        gpu.profile_enable(True)
+        docs["profiling"] = p.prove(inst["synth"], None, testing_mixer_json=mixer_path)[0]
+        gpu.profile_enable(False)
+        gpu.msm_set_pipeline_streams(1)               # also turns the helper thread off for this proof (the serialised profiling pass)
+        docs["one stream"] = p.prove(inst["synth"], None, testing_mixer_json=mixer_path)[0]
+        gpu.msm_set_pipeline_streams(0)
+    # the switch is read once per process: a second process with the helper thread off
+    import subprocess
+    import sys
+    code = ("import sys, json; sys.path[:0] = %r\nfrom tkmk import service\nimport tkmk\ntkmk.set_device(0)\n"
+            "p = service.Prover(%r, %r, testing=True)\nprint(json.dumps(p.prove(%r, None, testing_mixer_json=%r)[0]))\n") % (
+        [os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "tokamak-zk-evm_amd")], inst["qap"], crs_dir, inst["synth"], mixer_path)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, TKMK_PROVER_ASYNC_BINDING="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    docs["binding in line"] = json.loads(r.stdout.strip().splitlines()[-1])
+    for k, d in docs.items():
+        assert d == docs["default"], k

@@ -168,3 +168,85 @@ def test_production_shape_sharded_over_two_virtual_ranks(gpu):
     finally:
         shutil.rmtree(files["tmp"], ignore_errors=True)
         gpu.release_scratch()
+
+
+def test_an_input_error_only_one_rank_can_see_is_every_ranks_error(gpu, oracle, tmp_path, monkeypatch):
+    """a rank converts only its own placements' values, so a bad hex digit inside placement 1 is seen by rank 1 alone — the ranks agree on
+    the outcome of the input phase before any of them goes on: EVERY rank reports the error (none proves on with a peer missing), the
+    communicator is not torn down, and the next proof on the repaired document is the single-GPU proof again"""
+    import synth_circuit
+    from test_gpu_prove import _stage_crs_file, seeded_mixer
+    from tkmk import dist, service
+    world = 4
+    inst = synth_circuit.build(str(tmp_path), random.Random(68), s_max=8, n_gate_kinds=2, used_placements=8)
+    crs_dir = str(tmp_path / "crs")
+    _stage_crs_file(gpu, oracle, inst, crs_dir)
+    mixer_path = _mixer_file(tmp_path, seeded_mixer(68))
+    with service.Prover(inst["qap"], crs_dir, testing=True) as single:
+        want, _ = single.prove(inst["synth"], None, testing_mixer_json=mixer_path)
+    comms = dist.loopback_comms(world)
+    provers = _open_ranks(dist, service, comms, inst["qap"], crs_dir)
+    by_rank = {p.comm.rank: p for p in provers}
+    pv_path = os.path.join(inst["synth"], "placementVariables.json")
+    pv = json.load(open(pv_path))
+    try:
+        bad = json.loads(json.dumps(pv))
+        bad[1]["variables"][2] = "0xzz"                         # placement 1 belongs to rank 1 of 4
+        json.dump(bad, open(pv_path, "w"))
+
+        def attempt(c):
+            try:
+                by_rank[c.rank].prove(inst["synth"], None, testing_mixer_json=mixer_path)
+                return "proved"
+            except service.ProverError as e:
+                return str(e)
+        res = dist.run_ranks(comms, attempt)
+        assert all(r != "proved" for r in res), res
+        assert "invalid hex digit" in res[1] and all("another rank" in res[r] for r in (0, 2, 3)), res
+        json.dump(pv, open(pv_path, "w"))
+        docs = dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(inst["synth"], None, testing_mixer_json=mixer_path)[0])
+        assert all(d == want for d in docs)
+    finally:
+        for p in provers:
+            p.close()
+        for c in comms:
+            c.close()
+
+
+def test_the_ranks_divide_the_polynomial_work(gpu, oracle, tmp_path, monkeypatch):
+    """the library's own work counters over one proof: ALL G virtual ranks together (they share this process's counters) transform and
+    stream about what the single-GPU context does alone — each rank 1 / G of it — where the round-3 prover replicated both on every rank
+    (G times the single figure).  Counting conventions: a bivariate call counts its elements once, the sharded transform's two 1-D
+    passes once each (so 2 x for the transforms); the streaming passes (poly.elements) count the elements they touch."""
+    import synth_circuit
+    from test_gpu_prove import _stage_crs_file, seeded_mixer
+    from tkmk import dist, service
+    world = 4
+    inst = synth_circuit.build(str(tmp_path), random.Random(69), s_max=32, n_gate_kinds=4, n_out=6, n_in=10, n_prv=40, k_out=2, k_pub=3, l_free=8, l_extra=3)
+    crs_dir = str(tmp_path / "crs")
+    _stage_crs_file(gpu, oracle, inst, crs_dir)
+    mixer_path = _mixer_file(tmp_path, seeded_mixer(69))
+    monkeypatch.setenv("TKMK_PROVER_TABLE_C", "0")
+    with service.Prover(inst["qap"], crs_dir, testing=True) as single:
+        single.prove(inst["synth"], None, testing_mixer_json=mixer_path)
+        gpu.native_stats_reset()
+        want, _ = single.prove(inst["synth"], None, testing_mixer_json=mixer_path)
+        one = gpu.native_stats()
+    comms = dist.loopback_comms(world)
+    provers = _open_ranks(dist, service, comms, inst["qap"], crs_dir)
+    by_rank = {p.comm.rank: p for p in provers}
+    try:
+        dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(inst["synth"], None, testing_mixer_json=mixer_path))
+        gpu.native_stats_reset()
+        docs = dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(inst["synth"], None, testing_mixer_json=mixer_path)[0])
+        allr = gpu.native_stats()
+        assert all(d == want for d in docs)
+        per_rank = {k: v / world for k, v in allr.items()}
+        assert per_rank["ntt.elements"] <= 2.3 * one["ntt.elements"] / world, (per_rank, one)
+        assert per_rank["poly.elements"] <= 1.6 * one["poly.elements"] / world, (per_rank, one)
+        assert per_rank["msm.points"] <= 1.3 * one["msm.points"] / world + 4096, (per_rank, one)
+    finally:
+        for p in provers:
+            p.close()
+        for c in comms:
+            c.close()

@@ -25,7 +25,21 @@ def crs_sections(crs_dir, setup_params=None):
     return rkyv.decode_combined_sigma(buf, expect=None if setup_params is None else rkyv.expect_for(setup_params))
 
 
-def verify(qap_dir, synth_dir, crs_dir, out_dir, tamper_public_input=False, seed=5):
+def sigma_verify_points(crs_dir):
+    """the verifier's reference string as the reference's `verify` reads it (verify-rust/src/lib.rs:68-71): <crs_dir>/sigma_verify.json,
+    SigmaVerify { G, H, sigma_1 { x, y }, sigma_2 { alpha .. y }, lagrange_KL } with every coordinate one big-endian hex number
+    (G1serde / G2serde, libs/src/iotools/mod.rs:986-1059) -> (crs_g1 dict of 96-byte affine records, sigma2 dict of decoded G2 points)"""
+    from tkmk import g2
+    sv = json.load(open(os.path.join(crs_dir, "sigma_verify.json")))
+    g1 = lambda pt: np.frombuffer(int(pt["x"], 16).to_bytes(48, "little") + int(pt["y"], 16).to_bytes(48, "little"), np.uint8).copy()     # noqa: E731
+    crs_g1 = {"G": g1(sv["G"]), "x": g1(sv["sigma_1"]["x"]), "y": g1(sv["sigma_1"]["y"]), "lagrange_KL": g1(sv["lagrange_KL"])}
+    sigma2 = {"H": g2.from_hex_pair(sv["H"]["x"], sv["H"]["y"])}
+    for name, pt in sv["sigma_2"].items():
+        sigma2[name] = g2.from_hex_pair(pt["x"], pt["y"])
+    return crs_g1, sigma2
+
+
+def verify(qap_dir, synth_dir, crs_dir, out_dir, tamper_public_input=False, seed=5, from_sigma_verify=False):
     """-> True iff <out_dir>/proof.json verifies against <out_dir>/preprocess.json (made with bin/preprocess when absent), the public
     inputs of <synth_dir>/instance.json and the CRS in <crs_dir>"""
     import prove_ref
@@ -54,11 +68,16 @@ def verify(qap_dir, synth_dir, crs_dir, out_dir, tamper_public_input=False, seed
     a_eval = prove_ref.interpolate([[v] for v in a], sp["l_free"], 1).eval(chi, zeta)          # Instance::gen_a_free_X, then eval
     if tamper_public_input:
         a_eval = (a_eval + 1) % prove_ref.R
-    sections = crs_sections(crs_dir, sp)
-    crs_g1 = {k: np.asarray(crsmod.single_g1(sections, k)) for k in ("G", "x", "y", "lagrange_KL")}
-    recs = np.asarray(sections["g2"]).reshape(10, 192)
-    if not recs.any():
-        raise ValueError("the CRS holds no Sigma2 (all-zero G2 section): every pairing would be 1 and the check vacuous")
-    sigma2 = {name: g2.decode(recs[i]) for i, name in enumerate(crsmod.G2_POINTS)}
+    if from_sigma_verify:      # the files the reference's verifier reads, and nothing else of the CRS
+        crs_g1, sigma2 = sigma_verify_points(crs_dir)
+        if set(sigma2) != set(crsmod.G2_POINTS):
+            raise ValueError("sigma_verify.json: unexpected Sigma2 entries")
+    else:
+        sections = crs_sections(crs_dir, sp)
+        crs_g1 = {k: np.asarray(crsmod.single_g1(sections, k)) for k in ("G", "x", "y", "lagrange_KL")}
+        recs = np.asarray(sections["g2"]).reshape(10, 192)
+        if not recs.any():
+            raise ValueError("the CRS holds no Sigma2 (all-zero G2 section): every pairing would be 1 and the check vacuous")
+        sigma2 = {name: g2.decode(recs[i]) for i, name in enumerate(crsmod.G2_POINTS)}
     kappa2 = random.Random(seed).randrange(1, prove_ref.R)
     return bool(prove_ref.verify_snark_pairing(points, scalars, ch, sp, crs_g1, pre_points, sigma2, a_eval, kappa2))

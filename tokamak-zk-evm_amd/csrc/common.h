@@ -81,7 +81,7 @@ struct tk_prof {
 };
 
 // work counters behind tkmk_stats_get (runtime.hip)
-enum { TK_STAT_MSM_POINTS = 0, TK_STAT_MSM_CALLS, TK_STAT_NTT_ELEMENTS, TK_STAT_NTT_CALLS, TK_STAT_COUNT };
+enum { TK_STAT_MSM_POINTS = 0, TK_STAT_MSM_CALLS, TK_STAT_NTT_ELEMENTS, TK_STAT_NTT_CALLS, TK_STAT_POLY_ELEMENTS, TK_STAT_COUNT };
 void tk_stat_add(int which, uint64_t v);
 unsigned long long *tk_stat_device_entries();   // device cell counting the bucket additions issued (sorted-list lengths); nullptr on failure
 

@@ -189,6 +189,7 @@ static tkmk_error expr_eval_impl(const tkmk_expr_instr *prog, uint32_t n_instr, 
                                  uint32_t n_consts, uint32_t x_size, uint32_t y_size, tkmk_fr *out_dev, tkmk_stream stream, uint32_t x_global,
                                  uint32_t x_first) {
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)x_size * y_size);
     if (!x_global) x_global = x_size, x_first = 0;
     for (uint32_t k = 0; k < n_consts; k++) {
         fr_t c;

@@ -288,6 +288,7 @@ TK_API tkmk_error tkmk_poly_find_degree(const tkmk_fr *coeffs_dev, uint32_t x_si
     if (!coeffs_dev || !x_degree || !y_degree) return TKMK_ERR_INVALID_POINTER;
     if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)x_size * y_size);   // elements this streaming pass touches (bench.py / the sharded prover's per-rank accounting)
     hipStream_t s = tk_stream(stream);
     tk_frame frame(s);
     tk_scratch d;
@@ -309,6 +310,7 @@ TK_API tkmk_error tkmk_poly_place(const tkmk_fr *src_dev, uint32_t sx, uint32_t 
     if (!src_dev || !dst_dev) return TKMK_ERR_INVALID_POINTER;
     if (!sx || !sy || !dx || !dy || (const void *)src_dev == (void *)dst_dev) return TKMK_ERR_INVALID_ARGUMENT;
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)dx * dy);   // elements this streaming pass touches (bench.py / the sharded prover's per-rank accounting)
     hipStream_t s = tk_stream(stream);
     hipLaunchKernelGGL(k_place, stream_grid((uint64_t)dx * dy), 256, 0, s, (const fr_t *)src_dev, sx, sy, (fr_t *)dst_dev, dx, dy, off_x,
                        off_y);
@@ -331,6 +333,7 @@ TK_API tkmk_error tkmk_poly_lincomb(uint32_t n_terms, const tkmk_fr *coeffs_host
         if (!x_sizes[t] || !y_sizes[t] || x_sizes[t] + ox > out_xs || y_sizes[t] + oy > out_ys) return TKMK_ERR_INVALID_ARGUMENT;
     }
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)out_xs * out_ys);   // elements this streaming pass touches (bench.py / the sharded prover's per-rank accounting)
     hipStream_t s = tk_stream(stream);
     if (n_terms == 0) {
         TK_HIP(hipMemsetAsync(out_dev, 0, (size_t)out_xs * out_ys * sizeof(fr_t), s));
@@ -385,6 +388,7 @@ TK_API tkmk_error tkmk_poly_scale_coeffs(const tkmk_fr *src_dev, uint32_t x_size
     if (!src_dev || !dst_dev) return TKMK_ERR_INVALID_POINTER;
     if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)x_size * y_size);   // elements this streaming pass touches (bench.py / the sharded prover's per-rank accounting)
     hipStream_t s = tk_stream(stream);
     tk_frame frame(s);
     tk_scratch tx, ty;
@@ -465,6 +469,7 @@ TK_API tkmk_error tkmk_poly_mul_ones_x(const tkmk_fr *p_dev, uint32_t x_size, ui
     uint32_t WS_BLOCK = 64;   // rows per running-sum block: the largest power of two <= 64 that divides m
     while (m % WS_BLOCK) WS_BLOCK >>= 1;
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)out_x_size * y_size);   // elements this streaming pass touches (bench.py / the sharded prover's per-rank accounting)
     hipStream_t s = tk_stream(stream);
     tk_frame frame(s);
     const uint32_t nb = (x_size + WS_BLOCK - 1) / WS_BLOCK, ob = (out_x_size + WS_BLOCK - 1) / WS_BLOCK;
@@ -503,6 +508,7 @@ TK_API tkmk_error tkmk_poly_eval_x(const tkmk_fr *coeffs_dev, uint32_t x_size, u
     if (!coeffs_dev || !x || !out_dev) return TKMK_ERR_INVALID_POINTER;
     if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)x_size * y_size);   // elements this streaming pass touches (bench.py / the sharded prover's per-rank accounting)
     hipStream_t s = tk_stream(stream);
     tk_frame frame(s);
     tk_scratch tx, part;
@@ -535,6 +541,7 @@ TK_API tkmk_error tkmk_poly_eval(const tkmk_fr *coeffs_dev, uint32_t x_size, uin
     if (!coeffs_dev || !x || !y || !out_host) return TKMK_ERR_INVALID_POINTER;
     if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)x_size * y_size);   // elements this streaming pass touches (bench.py / the sharded prover's per-rank accounting)
     hipStream_t s = tk_stream(stream);
     tk_frame frame(s);
     tk_scratch tx, ty, rows, res;
@@ -557,6 +564,7 @@ TK_API tkmk_error tkmk_poly_div_by_vanishing_opt(const tkmk_fr *p_dev, uint32_t 
     if (!p_dev || !quo_x_dev || !quo_y_dev) return TKMK_ERR_INVALID_POINTER;
     if (!c || !d || (c & (c - 1)) || (d & (d - 1)) || !x_size || !y_size || x_size % c || y_size % d) return TKMK_ERR_INVALID_ARGUMENT;
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)x_size * y_size);   // elements this streaming pass touches (bench.py / the sharded prover's per-rank accounting)
     hipStream_t s = tk_stream(stream);
     tk_frame frame(s);
     tk_scratch acc;
@@ -575,6 +583,7 @@ TK_API tkmk_error tkmk_poly_div_by_ruffini(const tkmk_fr *p_dev, uint32_t x_size
     if (!p_dev || !x || !y || !q_x_dev || !q_y_dev || !r_host) return TKMK_ERR_INVALID_POINTER;
     if (!x_size || !y_size) return TKMK_ERR_INVALID_ARGUMENT;
     TK_TRY(tk_require_device());
+    tk_stat_add(TK_STAT_POLY_ELEMENTS, (uint64_t)x_size * y_size);   // elements this streaming pass touches (bench.py / the sharded prover's per-rank accounting)
     hipStream_t s = tk_stream(stream);
     tk_frame frame(s);
     tk_scratch rx, rem;

@@ -648,7 +648,7 @@ TK_API tkmk_error tkmk_stats_get(const char *name, uint64_t *value) {
         *value = v;
         return TKMK_SUCCESS;
     }
-    static const char *names[TK_STAT_COUNT] = {"msm.points", "msm.calls", "ntt.elements", "ntt.calls"};
+    static const char *names[TK_STAT_COUNT] = {"msm.points", "msm.calls", "ntt.elements", "ntt.calls", "poly.elements"};
     for (int i = 0; i < TK_STAT_COUNT; i++)
         if (std::string(name) == names[i]) {
             *value = g_stat[i].load();

@@ -5,6 +5,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/tkmk_prover.h"
@@ -18,6 +19,16 @@ struct tkmk_prover {
 };
 
 static thread_local std::string g_last_error;
+// libtkmk_hip.so takes calls from ONE host thread at a time per stream (include/tkmk.h "Threading"), and a prover context issues all its
+// work on the default stream: two contexts of one process therefore take turns, whole calls at a time.  (The virtual ranks of a sharded
+// prover over the loopback transport take turns through the communicator's device turn instead; RCCL ranks are one process per GPU.)
+static std::mutex g_default_stream_mu;
+struct DefaultStreamTurn {
+    std::unique_lock<std::mutex> lk;
+    explicit DefaultStreamTurn(bool sharded) : lk(g_default_stream_mu, std::defer_lock) {
+        if (!sharded) lk.lock();
+    }
+};
 
 template <class F>
 static tkmk_error guarded(F &&fn) {
@@ -41,6 +52,7 @@ TKP_API tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const ch
         int ndev = 0;
         if (tkmk_device_count(&ndev) != TKMK_SUCCESS || ndev < 1) throw Error(TKMK_ERR_NO_DEVICE, "tkmk_prover_open: no HIP device (the MI355X backend has no CPU fallback)");
         std::string crs = crs_dir;
+        DefaultStreamTurn turn(false);
         std::unique_ptr<tkmk_prover> p(new tkmk_prover());
         p->ctx = ProverContext::open(subcircuit_library_dir, crs, [&](const SetupParams &sp, std::string &source) { return load_prover_sigma(crs, sp, source, resident_table_c(sp)); });
         *out = p.release();
@@ -133,6 +145,7 @@ TKP_API tkmk_error tkmk_prover_prove_ex(tkmk_prover *p, const char *synthesizer_
         Mixer mixer = Mixer::random();
 #endif
         ProveTiming tm;
+        DefaultStreamTurn turn((bool)p->ctx->link);
         Proof proof = p->ctx->prove(synthesizer_dir, output_dir ? output_dir : "", mixer, &tm, flags);
         if (timing) {
             timing->parse_s = tm.parse, timing->upload_s = tm.upload, timing->build_s = tm.build, timing->binding_s = tm.binding;
@@ -152,7 +165,10 @@ TKP_API tkmk_error tkmk_prover_prove_ex(tkmk_prover *p, const char *synthesizer_
 
 TKP_API tkmk_error tkmk_prover_close(tkmk_prover *p) {
     if (!p) return TKMK_SUCCESS;
-    return guarded([&] { delete p; });
+    return guarded([&] {
+        DefaultStreamTurn turn((bool)p->ctx->link);
+        delete p;
+    });
 }
 TKP_API void tkmk_prover_free_string(char *s) { std::free(s); }
 TKP_API const char *tkmk_prover_last_error(void) { return g_last_error.c_str(); }

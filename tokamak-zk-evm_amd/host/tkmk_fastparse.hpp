@@ -422,8 +422,12 @@ struct WitnessLayout {
 
 // n_wires[id] = variables a placement of kind `id` must carry (SubcircuitInfo::Nwires = flattenMap.len(); the reference checks it in
 // gen_bXY and in the R1CS evaluation).  alloc(total) returns the buffer the values are written to.
+// world / rank (a sharded prover, host/tkmk_service.hpp): only the placements q = rank mod world are converted and stored — off[] and
+// total then describe the buffer of THOSE placements (off[q] of another rank's placement is meaningless); the kinds (id[]) of all
+// placements are still read, the structure of the whole document is still checked.
 inline WitnessLayout parse_placement_variables_fast(const char *t, size_t n, const std::vector<uint32_t> &n_wires,
-                                                    const std::function<ScalarField *(uint64_t)> &alloc, unsigned threads) {
+                                                    const std::function<ScalarField *(uint64_t)> &alloc, unsigned threads, uint32_t world = 1,
+                                                    uint32_t rank = 0) {
     using namespace fastparse;
     const char *doc = "placementVariables.json";
     WitnessLayout L;
@@ -481,7 +485,7 @@ inline WitnessLayout parse_placement_variables_fast(const char *t, size_t n, con
     L.off.resize(P);
     for (size_t q = 0; q < P; q++) {
         L.off[q] = L.total;
-        L.total += n_wires[L.id[q]];
+        if (q % world == rank) L.total += n_wires[L.id[q]];
     }
     ScalarField *vars = alloc(L.total);
     // pass 2: every object in full; values straight to their final position
@@ -490,6 +494,7 @@ inline WitnessLayout parse_placement_variables_fast(const char *t, size_t n, con
         for (;;) {
             size_t q = next.fetch_add(1);
             if (q >= P) break;
+            if (q % world != rank) continue;   // another rank's placement: that rank converts (and checks) its values
             size_t end = q + 1 < P ? start[q + 1] : n;
             Scanner s{t, start[q] + 1, end, doc};
             ScalarField *dst = vars + L.off[q];

@@ -389,20 +389,34 @@ class ProverContext {
             p->s0_ev = std::move(e0), p->s1_ev = std::move(e1);   // prove1 forms f and g on the grid from these
             p->s0_identity = &s0_identity_, p->s1_identity = &s1_identity_;
         }
-        MappedFile pv_file(synth_dir + "/placementVariables.json");
-        WitnessLayout W = parse_placement_variables_fast(pv_file.data(), pv_file.size(), n_wires_, [&](uint64_t total) { return staging(total); }, threads);
-        const size_t P = W.id.size();
-        if (P > s_max) throw Error("placement_variables length exceeds s_max.");
+        // Sharded: every rank reads the whole document's structure and every placement's kind, but converts (and thereby checks) only the
+        // values of its own placements — so an input error may show on one rank only.  The ranks therefore AGREE on the outcome of this
+        // phase before any of them goes on: a malformed document is then the same error on every rank, at the same point.
+        const Shard sh = link ? link.shard : Shard{};
+        WitnessLayout W;
         std::vector<ScalarField> a_pub_user, a_pub_block;
-        {
+        std::string input_error;
+        try {
+            MappedFile pv_file(synth_dir + "/placementVariables.json");
+            W = parse_placement_variables_fast(pv_file.data(), pv_file.size(), n_wires_, [&](uint64_t total) { return staging(total); }, threads, sh.world, sh.rank);
+            if (W.id.size() > s_max) throw Error("placement_variables length exceeds s_max.");
             const json::Value jinst = json::read_file(synth_dir + "/instance.json");
             a_pub_user = hex_list(jinst.at("a_pub_user"));
             a_pub_block = hex_list(jinst.at("a_pub_block"));
+        } catch (const std::exception &e) {
+            if (sh.world == 1) throw;
+            input_error = e.what();
+            if (input_error.empty()) input_error = "input error";
         }
+        if (sh.world > 1) {
+            const tkmk_error verdict = link.agree(link.comm, input_error.empty() ? TKMK_SUCCESS : TKMK_ERR_INVALID_ARGUMENT);
+            if (!input_error.empty()) throw Error(input_error);
+            if (verdict != TKMK_SUCCESS) throw Error("another rank of the sharded prover could not read its share of the synthesizer's documents");
+        }
+        const size_t P = W.id.size();
         // placements grouped by kind: slot list, variable offsets, position of each kind's run.  Sharded: a placement is a column of
         // u, v, w, b — this rank takes the placements q = rank mod G; `slots` are their local columns q / G, `gslots` the global ones
         // (the binding tables are indexed by the global slot)
-        const Shard sh = link ? link.shard : Shard{};
         const size_t lc = sh.cols_of(s_max);
         std::vector<uint32_t> mine_q;
         for (size_t q = sh.rank; q < P; q += sh.world) mine_q.push_back((uint32_t)q);

@@ -627,7 +627,7 @@ def native_stats_reset():
 def native_stats():
     """work the library was asked to do since the last reset, counted inside the library (whichever host side called it)"""
     out = {}
-    for name in ("msm.points", "msm.calls", "msm.bucket_additions", "ntt.elements", "ntt.calls"):
+    for name in ("msm.points", "msm.calls", "msm.bucket_additions", "ntt.elements", "ntt.calls", "poly.elements"):
         v = ctypes.c_uint64()
         _check(lib().tkmk_stats_get(name.encode(), ctypes.byref(v)), "tkmk_stats_get")
         out[name] = v.value
