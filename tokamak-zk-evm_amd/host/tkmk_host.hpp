@@ -160,7 +160,13 @@ class DensePolynomialExt {
     }
     // host values: the same on every rank, hence replicated
     static DensePolynomialExt from_coeffs(const std::vector<ScalarField> &coeffs, size_t x_size, size_t y_size) {
-        return from_coeffs(DeviceVec<ScalarField>::from_host(coeffs), x_size, y_size, true);
+        DensePolynomialExt p = from_coeffs(DeviceVec<ScalarField>::from_host(coeffs), x_size, y_size, true);
+        int64_t xd = -1, yd = -1;   // the values are here: their exact degree costs nothing
+        for (size_t i = 0; i < x_size; i++)
+            for (size_t j = 0; j < y_size; j++)
+                if (!fr_is_zero(coeffs[i * y_size + j])) xd = std::max<int64_t>(xd, (int64_t)i), yd = std::max<int64_t>(yd, (int64_t)j);
+        p.x_degree = xd, p.y_degree = yd;
+        return p;
     }
     // from_rou_evals (mod.rs:1615-1644): inverse _biNTT of device-resident evaluations.  Sharded prover: `evals` is this rank's ROWS slab
     // (h x y_size), the result a distributed COLS matrix (one all-to-all).
@@ -293,6 +299,39 @@ class DensePolynomialExt {
     }
     std::pair<int64_t, int64_t> degree() const { return {x_degree, y_degree}; }
 
+    // ---- degrees: kept as UPPER BOUNDS through every operation instead of measured (r4) ----
+    // The reference measures a matrix's degree (find_degree: a pass over the matrix and a host round trip, mod.rs:1480-1515) wherever it
+    // needs its shape: before every commit, product, vanishing division and K0 product — 26 times per proof.  Here x_degree / y_degree
+    // carry a bound that every operation maintains exactly as the algebra gives it (a sum's degree is at most the largest operand's plus
+    // its shift, a product's the sum, a quotient's the difference; polynomials built from host values get their exact degree from those
+    // values), and the shape decisions read the bound.  For generic inputs the bounds ARE the degrees (the 19 boxes of
+    // tests/golden/encode_dims.json are reproduced: tests/test_gpu_fullsize.py); for a degenerate input (a leading coefficient that happens
+    // to vanish) a matrix may be one power of two larger than the reference's and a commit run over a few zero coefficients more — the
+    // polynomials, hence the proof bytes, are the same.  TKMK_PROVER_EXACT_DEGREES=1 restores the measuring form; the testing-mode builds
+    // measure as well and refuse a bound that lies below a measured degree.
+    static bool measure_degrees() {
+        static const bool on = [] {
+            const char *e = getenv("TKMK_PROVER_EXACT_DEGREES");
+            return e && atoi(e) != 0;
+        }();
+        return on;
+    }
+    // the degree the shape decisions use
+    std::pair<int64_t, int64_t> shape_degree() const {
+        if (measure_degrees()) return find_degree();
+#ifdef TKMK_TESTING_MODE
+        auto [xd, yd] = find_degree();
+        if (xd > x_degree || yd > y_degree)
+            throw Error("degree bound violated: measured (" + std::to_string(xd) + ", " + std::to_string(yd) + ") above the bound (" + std::to_string(x_degree) + ", " +
+                        std::to_string(y_degree) + ")");
+#endif
+        return {std::min<int64_t>(x_degree, (int64_t)x_size - 1), std::min<int64_t>(y_degree, (int64_t)y_size - 1)};
+    }
+    DensePolynomialExt &&with_degree(int64_t xd, int64_t yd) && {
+        x_degree = std::min<int64_t>(xd, (int64_t)x_size - 1), y_degree = std::min<int64_t>(yd, (int64_t)y_size - 1);
+        return std::move(*this);
+    }
+
     // find_degree (mod.rs:1480-1515)
     std::pair<int64_t, int64_t> find_degree() const {
         int64_t xd = -1, yd = -1;
@@ -317,10 +356,11 @@ class DensePolynomialExt {
         }
         poly = std::move(dst);
         x_size = nx, y_size = ny;
+        x_degree = std::min<int64_t>(x_degree, (int64_t)nx - 1), y_degree = std::min<int64_t>(y_degree, (int64_t)ny - 1);
     }
     // optimize_size (mod.rs:1808-1818)
     void optimize_size() {
-        auto [xd, yd] = find_degree();
+        auto [xd, yd] = shape_degree();
         x_degree = xd, y_degree = yd;
         if (xd + 1 == 0 || yd + 1 == 0) return;
         resize((size_t)(xd + 1), (size_t)(yd + 1));
@@ -337,17 +377,17 @@ class DensePolynomialExt {
             check(tkmk_poly_place(poly.ptr(), (uint32_t)x_size, (uint32_t)sl, dst.ptr(), (uint32_t)nx, (uint32_t)dl, (uint32_t)x_exponent,
                                   (uint32_t)y_exponent, nullptr),
                   "mul_monomial");
-        return from_coeffs(std::move(dst), nx, ny, rep);
+        return from_coeffs(std::move(dst), nx, ny, rep).with_degree(x_degree < 0 ? -1 : x_degree + (int64_t)x_exponent, y_degree < 0 ? -1 : y_degree + (int64_t)y_exponent);
     }
     // scale_coeffs_x / scale_coeffs_y (mod.rs:1553-1613).  Distributed: local column k is global column r + G k, so the Y factor of
     // element (i, k) is fy^r (fy^G)^k.
     DensePolynomialExt scale_coeffs(const ScalarField *fx, const ScalarField *fy) const {
         const size_t lc = ly();
         DeviceVec<ScalarField> dst(x_size * lc);
-        if (!lc) return from_coeffs(std::move(dst), x_size, y_size, rep);
+        if (!lc) return from_coeffs(std::move(dst), x_size, y_size, rep).with_degree(x_degree, y_degree);
         if (!distributed() || !fy) {
             check(tkmk_poly_scale_coeffs(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, fx, fy, dst.ptr(), nullptr), "_scale_coeffs");
-            return from_coeffs(std::move(dst), x_size, y_size, rep);
+            return from_coeffs(std::move(dst), x_size, y_size, rep).with_degree(x_degree, y_degree);
         }
         const DistCtx &dc = dist_ctx();
         const ScalarField fy_g = fr_pow(*fy, dc.G()), fy_r = fr_pow(*fy, dc.r());
@@ -357,7 +397,7 @@ class DensePolynomialExt {
             c.is_a_on_device = false;
             check(bls12_381_scalar_mul_vec(&fy_r, dst.ptr(), dst.len(), &c, dst.ptr()), "_scale_coeffs");
         }
-        return from_coeffs(std::move(dst), x_size, y_size, false);
+        return from_coeffs(std::move(dst), x_size, y_size, false).with_degree(x_degree, y_degree);
     }
     DensePolynomialExt scale_coeffs_x(const ScalarField &f) const { return scale_coeffs(&f, nullptr); }
     DensePolynomialExt scale_coeffs_y(const ScalarField &f) const { return scale_coeffs(nullptr, &f); }
@@ -366,7 +406,7 @@ class DensePolynomialExt {
         const size_t lc = ly();
         DeviceVec<ScalarField> out(lc);
         if (lc) check(tkmk_poly_eval_x(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, &x, out.ptr(), nullptr), "eval_x");
-        return from_coeffs(std::move(out), 1, y_size, rep);
+        return from_coeffs(std::move(out), 1, y_size, rep).with_degree(x_degree < 0 ? -1 : 0, y_degree);
     }
     DensePolynomialExt eval_y(const ScalarField &y) const {
         if (distributed()) throw Error("eval_y: not used by the sharded prover");
@@ -406,7 +446,7 @@ class DensePolynomialExt {
         auto [l, r] = same_shape(a, b);
         tkmk_vecops_config c = dev_cfg();
         check(bls12_381_vector_add(l.poly.ptr(), r.poly.ptr(), l.poly.len(), &c, l.poly.ptr()), "add");
-        return from_coeffs(std::move(l.poly), l.x_size, l.y_size);
+        return from_coeffs(std::move(l.poly), l.x_size, l.y_size).with_degree(std::max(a.x_degree, b.x_degree), std::max(a.y_degree, b.y_degree));
     }
     friend DensePolynomialExt operator-(const DensePolynomialExt &a, const DensePolynomialExt &b) {
         if (dist_ctx().on()) {
@@ -418,14 +458,14 @@ class DensePolynomialExt {
         auto [l, r] = same_shape(a, b);
         tkmk_vecops_config c = dev_cfg();
         check(bls12_381_vector_sub(l.poly.ptr(), r.poly.ptr(), l.poly.len(), &c, l.poly.ptr()), "sub");
-        return from_coeffs(std::move(l.poly), l.x_size, l.y_size);
+        return from_coeffs(std::move(l.poly), l.x_size, l.y_size).with_degree(std::max(a.x_degree, b.x_degree), std::max(a.y_degree, b.y_degree));
     }
     friend DensePolynomialExt operator*(const DensePolynomialExt &a, const ScalarField &s) {
         DensePolynomialExt out = a.clone();
         tkmk_vecops_config c = dev_cfg();
         c.is_a_on_device = false;
         if (out.poly.len()) check(bls12_381_scalar_mul_vec(&s, out.poly.ptr(), out.poly.len(), &c, out.poly.ptr()), "scalar_mul");
-        return from_coeffs(std::move(out.poly), out.x_size, out.y_size, out.rep);
+        return from_coeffs(std::move(out.poly), out.x_size, out.y_size, out.rep).with_degree(a.x_degree, a.y_degree);
     }
     // sum_t c_t * X^ox_t Y^oy_t * p_t in ONE pass (tkmk_poly_lincomb): poly_comb! and the `&a * &s`, `&a + &b`, mul_monomial chains
     // around it (prove/src/lib.rs:30-124), which cost one pass and one temporary per operator when evaluated step by step
@@ -439,9 +479,11 @@ class DensePolynomialExt {
         if (terms.empty()) return zero();
         size_t nx = 1, ny = 1;
         bool all_rep = true;
+        int64_t bx = -1, by = -1;   // the sum's degree is at most the largest (operand degree + shift)
         for (const Term &t : terms) {
             nx = std::max(nx, next_pow2(t.p->x_size + t.ox)), ny = std::max(ny, next_pow2(t.p->y_size + t.oy));
             all_rep = all_rep && !t.p->distributed();
+            if (t.p->x_degree >= 0 && t.p->y_degree >= 0 && !fr_is_zero(t.c)) bx = std::max<int64_t>(bx, t.p->x_degree + t.ox), by = std::max<int64_t>(by, t.p->y_degree + t.oy);
         }
         const DistCtx &dc = dist_ctx();
         // sharded prover: operands that are all replicated and small give a replicated result (every rank computes the same few values);
@@ -496,12 +538,12 @@ class DensePolynomialExt {
                       "tkmk_poly_lincomb");
             if (!temps.empty()) check(tkmk_device_synchronize(), "synchronize");   // the temporaries go out of scope here
         }
-        return from_coeffs(std::move(out), nx, ny, out_rep);
+        return from_coeffs(std::move(out), nx, ny, out_rep).with_degree(bx, by);
     }
     // _mul (mod.rs:1846-1996)
     friend DensePolynomialExt operator*(const DensePolynomialExt &a, const DensePolynomialExt &b) {
-        auto [lx, ly] = a.find_degree();
-        auto [rx, ry] = b.find_degree();
+        auto [lx, ly] = a.shape_degree();
+        auto [rx, ry] = b.shape_degree();
         if (lx + ly == 0 && rx + ry > 0) return b * a.get_coeff(0, 0);
         if (rx + ry == 0 && lx + ly > 0) return a * b.get_coeff(0, 0);
         if (rx + ry == 0 && lx + ly == 0) {
@@ -516,21 +558,20 @@ class DensePolynomialExt {
         DeviceVec<ScalarField> le = a.evals_on(xs, ys), re = b.evals_on(xs, ys);
         tkmk_vecops_config c = dev_cfg();
         check(bls12_381_vector_mul(le.ptr(), re.ptr(), le.len(), &c, le.ptr()), "mul");
-        return from_rou_evals_consume(std::move(le), xs, ys);
+        return from_rou_evals_consume(std::move(le), xs, ys).with_degree(lx + rx, ly + ry);
     }
 
     // this * scale * (1 + X + ... + X^(m-1)); with scale = 1/m the factor is K_0 = unit evaluations at index 0 of the m-th roots
     // (the reference multiplies by it with `&K0 * &poly`, three NTTs: lib.rs:2238-2246, 3012-3040)
     DensePolynomialExt mul_ones_x(size_t m, const ScalarField &scale) const {
-        auto [xd, yd] = find_degree();
-        (void)yd;
+        auto [xd, yd] = shape_degree();
         if (xd < 0) return zero();
         size_t ox = next_pow2((size_t)xd + m);
         const size_t lc = ly();
         DeviceVec<ScalarField> out(ox * lc);
         host_trace("mul_ones_x %zu x %zu by m = %zu", x_size, y_size, m);
         if (lc) check(tkmk_poly_mul_ones_x(poly.ptr(), (uint32_t)x_size, (uint32_t)lc, (uint32_t)m, &scale, (uint32_t)ox, out.ptr(), nullptr), "mul_ones_x");
-        return from_coeffs(std::move(out), ox, y_size, rep);
+        return from_coeffs(std::move(out), ox, y_size, rep).with_degree(xd + (int64_t)m - 1, yd);
     }
     // div_by_vanishing_opt (mod.rs:2284-2410).  Distributed: every row is local, and the Y recurrence's stride d is a multiple of G, so a
     // column's predecessor j - d lives on the same rank d / G local columns earlier: both passes are local.
@@ -552,9 +593,13 @@ class DensePolynomialExt {
         check(tkmk_poly_div_by_vanishing_opt(poly.ptr(), (uint32_t)xs, (uint32_t)ysl, (uint32_t)c, (uint32_t)dl, qx.ptr(), qy.ptr(), nullptr),
               "div_by_vanishing_opt");
         DensePolynomialExt quo_x = from_coeffs(std::move(qx), xs, ys, rep), quo_y = from_coeffs(std::move(qy), c, ys, rep);
-        if (xs > c) quo_x.x_degree = (int64_t)(xs - c) - 1, quo_x.y_degree = (int64_t)ys - 1;
+        // degree bounds of the quotients of an EXACT division P = Q_X (X^c - 1) + Q_Y (Y^d - 1) with deg_x Q_Y < c: deg_x Q_X <= deg_x P - c
+        // (rows above that are zero: the top c rows of the recurrence vanish by exactness and the zero propagates down through the rows
+        // where P has none), deg_y Q_X <= deg_y P, deg_y Q_Y <= deg_y P - d.  (The reference writes x_size - c - 1 etc. into the fields —
+        // the matrix shape — and measures again before it commits.)
+        if (xs > c) quo_x.x_degree = std::min<int64_t>(x_degree - (int64_t)c, (int64_t)(xs - c) - 1), quo_x.y_degree = std::min<int64_t>(y_degree, (int64_t)ys - 1);
         else quo_x.x_degree = quo_x.y_degree = -1;
-        if (ys > d) quo_y.x_degree = (int64_t)c - 1, quo_y.y_degree = (int64_t)(ys - d) - 1;
+        if (ys > d) quo_y.x_degree = (int64_t)c - 1, quo_y.y_degree = std::min<int64_t>(y_degree - (int64_t)d, (int64_t)(ys - d) - 1);
         else quo_y.x_degree = quo_y.y_degree = -1;
         return {std::move(quo_x), std::move(quo_y)};
     }
@@ -565,7 +610,8 @@ class DensePolynomialExt {
         if (!distributed()) {
             DeviceVec<ScalarField> qx(x_size * y_size), qy(y_size);
             check(tkmk_poly_div_by_ruffini(poly.ptr(), (uint32_t)x_size, (uint32_t)y_size, &x, &y, qx.ptr(), qy.ptr(), &r, nullptr), "div_by_ruffini");
-            return {from_coeffs(std::move(qx), x_size, y_size, rep), from_coeffs(std::move(qy), 1, y_size, rep), r};
+            return {from_coeffs(std::move(qx), x_size, y_size, rep).with_degree(std::max<int64_t>(x_degree - 1, 0), y_degree),
+                    from_coeffs(std::move(qy), 1, y_size, rep).with_degree(0, std::max<int64_t>(y_degree - 1, 0)), r};
         }
         const DistCtx &dc = dist_ctx();
         const size_t lc = ly(), G = dc.G();
@@ -581,7 +627,8 @@ class DensePolynomialExt {
         DeviceVec<ScalarField> row = DeviceVec<ScalarField>::from_host(whole), qrow(y_size), qy(y_size);
         // P(x, Y) as a 1 x y_size matrix: its "X division" is trivial (one row), its Y division is the one wanted
         check(tkmk_poly_div_by_ruffini(row.ptr(), 1, (uint32_t)y_size, &x, &y, qrow.ptr(), qy.ptr(), &r, nullptr), "div_by_ruffini");
-        return {from_coeffs(std::move(qx), x_size, y_size, false), from_coeffs(std::move(qy), 1, y_size, true), r};
+        return {from_coeffs(std::move(qx), x_size, y_size, false).with_degree(std::max<int64_t>(x_degree - 1, 0), y_degree),
+                from_coeffs(std::move(qy), 1, y_size, true).with_degree(0, std::max<int64_t>(y_degree - 1, 0)), r};
     }
 };
 
@@ -644,7 +691,7 @@ class PolyExpr {
         switch (kind) {
             case Poly: {
                 auto it = memo.find(leaf);
-                if (it == memo.end()) it = memo.emplace(leaf, leaf->find_degree()).first;
+                if (it == memo.end()) it = memo.emplace(leaf, leaf->shape_degree()).first;
                 return it->second;
             }
             case Scalar: return fr_is_zero(scalar_) ? std::make_pair<int64_t, int64_t>(-1, -1) : std::make_pair<int64_t, int64_t>(0, 0);
@@ -741,7 +788,7 @@ class PolyExpr {
                                                  out.ptr(), nullptr),
                   "tkmk_poly_expr_eval_views_slab");
             check(tkmk_device_synchronize(), "synchronize");   // the rotated copies go out of scope
-            return DensePolynomialExt::from_rou_evals_consume(std::move(out), target_x_size, target_y_size);
+            return DensePolynomialExt::from_rou_evals_consume(std::move(out), target_x_size, target_y_size).with_degree(d.first, d.second);
         }
         if (fits) {
             // leaves as VIEWS: an X-only (Y-only) polynomial is transformed in one dimension and broadcast; a root-shifted leaf
@@ -763,10 +810,10 @@ class PolyExpr {
             check(tkmk_poly_expr_eval_views(pg.code.data(), (uint32_t)pg.code.size(), views.data(), (uint32_t)views.size(), pg.consts.data(),
                                             (uint32_t)pg.consts.size(), (uint32_t)target_x_size, (uint32_t)target_y_size, out.ptr(), nullptr),
                   "tkmk_poly_expr_eval_views");
-            return DensePolynomialExt::from_rou_evals(out, target_x_size, target_y_size);
+            return DensePolynomialExt::from_rou_evals(out, target_x_size, target_y_size).with_degree(d.first, d.second);
         }
         DeviceVec<ScalarField> evals = on_domain(target_x_size, target_y_size, cache);
-        return DensePolynomialExt::from_rou_evals(evals, target_x_size, target_y_size);
+        return DensePolynomialExt::from_rou_evals(evals, target_x_size, target_y_size).with_degree(d.first, d.second);
     }
 
   private:
@@ -1001,8 +1048,12 @@ class Sigma1 {
     uint32_t table_c() const { return table_c_; }
     // the MSM job of one commit: coefficient box x CRS sub-grid, both as views (msm_size 0 for the zero polynomial)
     tkmk_msm_job_ex job(DensePolynomialExt &poly, const char *name = nullptr) const {
-        poly.optimize_size();
-        size_t tx = (size_t)(poly.x_degree + 1), ty = (size_t)(poly.y_degree + 1);
+        // the box the MSM runs over: the polynomial's degree bound (DensePolynomialExt::shape_degree) — or its MEASURED degree when the
+        // caller records the boxes (the reference's own encode_poly measures: iotools/mod.rs:2055-2060; tests/golden/encode_dims.json).
+        // A view addresses the box inside the matrix as it is: nothing is resized or copied.
+        const auto deg = commit_box_sink() ? poly.find_degree() : poly.shape_degree();
+        size_t tx = (size_t)(deg.first + 1), ty = (size_t)(deg.second + 1);
+        if (deg.first < 0 || deg.second < 0) tx = ty = 0;
         if (tx > rs_x_ || ty > rs_y_) throw Error("Insufficient length of sigma.sigma_1.xy_powers");
         if (auto *sink = commit_box_sink()) sink->push_back({name ? name : "?", tx, ty, "coeff"});
         // this rank's columns of the box: grid columns r, r + G, ... < ty = columns 0 .. mine - 1 of the local table, and the same columns
