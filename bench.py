@@ -25,7 +25,7 @@ roofline (same JSON line): the dominant kernel of a proof, k_accumulate_chunks (
 duration is measured live with HIP events recorded on the launch stream (tkmk_profile_*: recorded without synchronising) in a
 SERIALISED PROFILING PASS run right after the timed region: the same proofs with the multi-MSM pipeline narrowed to one internal
 stream (tkmk_msm_set_pipeline_streams(1)), so that no two kernels of a commit batch overlap and a section's time is the kernel's own
-— what `rocprofv3 --kernel-trace --stats` reports per launch (profiles/r03_prove_configs3_kernel_stats_1stream.csv is the same
+— what `rocprofv3 --kernel-trace --stats` reports per launch (profiles/r04_prove_configs3_kernel_stats_1stream.csv is the same
 command with TKMK_MSM_STREAMS=1).  In the timed region itself three streams time-slice the device: events there bracket queueing
 behind the other streams' kernels, so those figures are kept apart and labelled queue_inclusive.  algorithmic bytes = 128 B per
 committed point (scalar + base read once) / launch time, against 8 TB/s; `traffic` from the committed
@@ -282,8 +282,8 @@ def main():
                                        "algorithm (DESIGN.md section 4 lists the algebraically equal forms used)",
                            "constraint_slots_per_proof": slots, "r1cs_rows_per_proof": files["r1cs_rows"], "proofs_per_step": jobs_in_flight,
                            "host_side": "native C++ (libtkmk_prover.so over the C ABI of libtkmk_hip.so)",
-                           "sharding": ("ONE proof over %d GPUs (tkmk_prover_open_sharded): commit tables and commitments sharded by grid row, one "
-                                        "all-gather of 144 B per commitment of a round; inputs, polynomial arithmetic and transcript replicated" % world) if one_proof
+                           "sharding": ("ONE proof over %d GPUs (tkmk_prover_open_sharded): commit tables, transforms, streaming passes and the witness "
+                                        "side divided by columns r mod N; one all-to-all per transform, one all-gather per commit batch; transcript replicated" % world) if one_proof
                            else "independent proofs per GPU" if world > 1 else "none"},
                 "r1cs_rows_per_s": files["r1cs_rows"] * jobs_in_flight * args.steps / elapsed,
                 "per_proof_s": {k: round(v, 5) for k, v in med.items()},
@@ -300,7 +300,7 @@ def main():
                 "serialised_pass": {"ran": serial, "pipeline_streams": 1 if serial else streams_default, "proofs": ser_proofs, "ms_per_step": ser_elapsed / ser_proofs * 1e3,
                                     "bracketed_kernels_ms_per_proof": round(sum(v["ms_per_proof"] for v in sections.values()) + ntt_ms, 3),
                                     "note": "untimed for the headline; same proofs with tkmk_msm_set_pipeline_streams(1): section times are "
-                                            "kernel durations as rocprofv3 reports them (profiles/r03_prove_configs3_kernel_stats_1stream.csv)"},
+                                            "kernel durations as rocprofv3 reports them (profiles/r04_prove_configs3_kernel_stats_1stream.csv)"},
                 "kernel_ms_per_proof_queue_inclusive": dict(q_sections, ntt_passes=round(q_ntt_ms, 3), pipeline_streams=streams_default,
                                                             note="HIP events in the timed region: with several streams in flight an event pair "
                                                                  "also brackets the wait behind the other streams' kernels; NOT kernel time"),
@@ -314,7 +314,7 @@ def main():
                 adds = ser_stats.get("msm.bucket_additions", 0)
                 mads = adds * MADS_PER_BUCKET_ADD / (acc_ms * 1e-3)
                 out["roofline"] = {"bound": "hbm", "kernel": "k_accumulate_chunks", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles("prove_accumulate_configs3_r03" if args.s_max == 1024 else None),
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles("prove_accumulate_configs3_r04" if args.s_max == 1024 else None),
                                    "avg_launch_ms": avg_ms, "launches": acc_cnt, "launches_per_proof": acc_cnt / ser_proofs,
                                    "algorithmic_bytes_per_launch": alg, "share_of_step": (acc_ms / ser_proofs) / (elapsed / args.steps * 1e3),
                                    "measured_in": measured_in,

@@ -333,6 +333,12 @@ tkmk_error bls12_381_matrix_transpose(const tkmk_fr *in, uint32_t rows, uint32_t
  * --------------------------------------------------------------------------------------------- */
 tkmk_error tkmk_g1_ntt(const tkmk_g1_affine *in_dev, int bases_form, uint32_t in_stride, uint32_t x_size, uint32_t y_size, tkmk_ntt_dir dir,
                        tkmk_g1_affine *out_dev, tkmk_stream stream);
+/* the same with either pass switched off (axes = TKMK_G1_NTT_AXIS_X | _Y is tkmk_g1_ntt): _Y alone transforms the x_size rows, _X alone
+ * the y_size columns — a sharded prover context runs each over its own part of the grid with a change of layout in between */
+#define TKMK_G1_NTT_AXIS_X 1
+#define TKMK_G1_NTT_AXIS_Y 2
+tkmk_error tkmk_g1_ntt_axes(const tkmk_g1_affine *in_dev, int bases_form, uint32_t in_stride, uint32_t x_size, uint32_t y_size, tkmk_ntt_dir dir,
+                            int axes, tkmk_g1_affine *out_dev, tkmk_stream stream);
 /* Prefix sums of points: out[j] = sum_{j' <= j} in[idx(j')], idx(j) = j, or (j % rows) * cols + j / rows with `transposed` (the rows x cols
  * row-major table walked column by column).  With the Lagrange-basis points in the order of prove1's running product (lib.rs:1858-1866) this
  * is the table over which a PIECEWISE-CONSTANT evaluation vector commits as an MSM of its few jumps: sum_j r_j L_j = sum_j (r_j - r_{j+1}) S_j,

@@ -84,6 +84,10 @@ tkmk_error tkmk_dist_fwd_cols_to_rows(tkmk_comm *comm, const tkmk_fr *in_cols_de
 /* inverse transform of x_size x y_size ROWS evaluations -> COLS coefficients (x_size x (y_size / G)); in_rows_dev is overwritten.
  * (= tkmk_bintt inverse on the whole matrix).  flags as above. */
 tkmk_error tkmk_dist_inv_rows_to_cols(tkmk_comm *comm, tkmk_fr *in_rows_dev, size_t x_size, size_t y_size, int flags, tkmk_fr *out_cols_dev);
+/* the change of layout alone for records of any size that is a multiple of 16 bytes (G1 affine points: 96): COLS x_size x (y_size / G)
+ * <-> ROWS (x_size / G) x y_size, one all-to-all each — the group transforms behind the Lagrange-basis tables use them at open */
+tkmk_error tkmk_dist_relayout_cols_to_rows(tkmk_comm *comm, const void *in_cols_dev, size_t x_size, size_t y_size, size_t record_bytes, void *out_rows_dev);
+tkmk_error tkmk_dist_relayout_rows_to_cols(tkmk_comm *comm, const void *in_rows_dev, size_t x_size, size_t y_size, size_t record_bytes, void *out_cols_dev);
 /* out (h x y_size) = this rank's ROWS slab of the matrix rotated down by rot <= h rows, cyclically over all G h rows: the evaluations of
  * p(w^-rot X, Y) from those of p.  One all-gather of rot rows per rank. */
 tkmk_error tkmk_dist_rows_rotate(tkmk_comm *comm, const tkmk_fr *slab_dev, size_t h, size_t y_size, size_t rot, tkmk_fr *out_dev);

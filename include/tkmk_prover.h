@@ -44,19 +44,25 @@ typedef struct {          /* seconds */
  * sums in prove1's walk order 5.2 GB; the binding tables 4.2 GB; the subcircuit library and the NTT domain < 1 GB — 36 GB of the 288 —
  * and 7.6 s at open (2.7 s table expansion, 3.3 s group NTT behind the Lagrange table, 1.3 s prefix sums and their expansion; production
  * shape 1.9 s).  TKMK_PROVER_LAGRANGE=0 drops the second and third items (U, V, W, B, R are then committed from coefficients).  A
- * sharded context (tkmk_prover_open_sharded) keeps 1 / G of the first three per GPU. */
+ * sharded context (tkmk_prover_open_sharded) keeps 1 / G of the first three per GPU and does 1 / G of their one-time work. */
 tkmk_error tkmk_prover_open(const char *subcircuit_library_dir, const char *crs_dir, tkmk_prover **out);
-/* ONE proof over the G GPUs of a node (the reference is single-device, so nothing is replaced): rank
- * r of the communicator `comm` (a tkmk_comm of include/tkmk_dist.h, made by the host: one process per GPU over RCCL) keeps the grid rows
- * ix = r mod G of every commit table — xy_powers, the Lagrange-basis tables and their prefix sums: resident HBM and the table expansion
- * at open divide by G — and commits its rows of every polynomial; inputs, polynomial arithmetic and the Fiat-Shamir transcript are
- * replicated (every rank reads the same files and computes the same challenges), so the only exchange is ONE all-gather of 144 bytes
- * per commitment of a round (tkmk_msm_multi_ex_sharded) plus one broadcast of rank 0's blinding scalars per proof.  Every rank must
- * call _open_sharded and then every _prove / _prove_ex with the same arguments; every rank gets the same proof, byte for byte the one
- * the single-GPU context gives for the same blinding scalars (tests/test_gpu_sharded_prover.py, over the loopback transport).  The
- * binding tables stay replicated: their index-list commitments are split by list position.  What is NOT divided: the per-proof
- * polynomial arithmetic (replicated) and, at open, the group transforms behind the Lagrange-basis tables (every rank runs them over
- * the whole grid and keeps its rows).  libtkmk_dist.so must be in the process (it is: the host made `comm` with it). */
+/* ONE proof over the G GPUs of a node (the reference is single-device, so nothing is replaced).  G is a power of
+ * two, at most min(n, m_I, s_max).  Rank r of the communicator `comm` (a tkmk_comm of include/tkmk_dist.h, made by the host: one process
+ * per GPU over RCCL) holds the COLUMNS iy = r mod G of everything: of every commit table — xy_powers, the Lagrange-basis tables and their
+ * prefix sums: resident HBM and the work at open (table expansion AND the group transforms behind the Lagrange tables) divide by G — and
+ * of every coefficient matrix of a proof, so that the divisions, window sums and shifts along X, both passes of the vanishing division
+ * and the commits are local to a rank; evaluations on the large domains live in row slabs, and a bivariate transform crosses between
+ * the two layouts with ONE all-to-all.  The witness side divides by placement (a placement is a column of u, v, w, b): a rank converts,
+ * uploads, evaluates and routes its own placements only.  Replicated: the Fiat-Shamir transcript (every rank derives the same challenges
+ * from the same gathered commitments) and the small polynomials built from host values.  Exchanges per proof: one all-gather per commit
+ * batch (144 B per commitment + a status block), one all-to-all per transform, a ring shift per Y-shifted term, all-gathers of a few
+ * values (evaluation partials, remainder rows), one broadcast of rank 0's blinding scalars; DESIGN.md section 6 counts them.
+ * Every rank must call _open_sharded and then every _prove / _prove_ex with the same arguments; every rank gets the same proof, byte for
+ * byte the one the single-GPU context gives for the same blinding scalars (tests/test_gpu_sharded_prover.py, G = 2, 4, 8 over the
+ * loopback transport); RANK 0 ALONE writes <output_dir>/proof.json (temporary file + rename), after all ranks agreed that they
+ * finished.  An input error only one rank can see is agreed on and reported by all; a rank that fails for a reason its peers cannot share
+ * (memory, device, transport) aborts the communicator (tkmk_comm_abort) so that they fail instead of waiting — the contexts of an aborted
+ * communicator can only be closed.  libtkmk_dist.so must be in the process (it is: the host made `comm` with it). */
 tkmk_error tkmk_prover_open_sharded(void *comm, const char *subcircuit_library_dir, const char *crs_dir, tkmk_prover **out);
 int tkmk_prover_world_size(const tkmk_prover *p);   /* 1 for a context made by tkmk_prover_open */
 /* output_dir may be NULL (no file is written); proof_json_out (optional) receives a malloc'ed copy of the document, to be

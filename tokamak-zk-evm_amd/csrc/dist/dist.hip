@@ -577,30 +577,31 @@ TKD_API tkmk_error tkmk_bintt_sharded(tkmk_comm *c, tkmk_fr *in_slab_dev, size_t
 // ---------------------------------------------------------------------------------------------------------------------------------
 typedef uint4 fr_half;   // a field element travels as two 16-byte halves
 
-// out (h x Y, ROWS) from the received blocks: block p = rank p's (h x lyb) piece of my rows; element (i, j): j < in_y ? B[j % G][i][j / G] : 0
+// out (h x Y, ROWS) from the received blocks: block p = rank p's (h x lyb) piece of my rows; element (i, j): j < in_y ? B[j % G][i][j / G] : 0.
+// An element is a record of `hv` 16-byte pieces (2: a field element; 6: a G1 affine point).
 __global__ void k_unpack_cols_to_rows(const fr_half *__restrict__ blocks, fr_half *__restrict__ out, uint32_t h, uint32_t Y, uint32_t in_y, uint32_t G,
-                                      uint32_t lyb) {
-    const uint64_t total = (uint64_t)h * Y;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+                                      uint32_t lyb, uint32_t hv) {
+    const uint64_t total = (uint64_t)h * Y * hv;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = t / hv;
+        const uint32_t piece = (uint32_t)(t - e * hv);
         const uint32_t i = (uint32_t)(e / Y), j = (uint32_t)(e - (uint64_t)i * Y);
-        fr_half lo = make_uint4(0, 0, 0, 0), hi = lo;
-        if (j < in_y) {
-            const uint64_t at = ((uint64_t)(j % G) * h + i) * lyb + j / G;
-            lo = blocks[2 * at], hi = blocks[2 * at + 1];
-        }
-        out[2 * e] = lo, out[2 * e + 1] = hi;
+        fr_half v = make_uint4(0, 0, 0, 0);
+        if (j < in_y) v = blocks[(((uint64_t)(j % G) * h + i) * lyb + j / G) * hv + piece];
+        out[t] = v;
     }
 }
 // send blocks from a ROWS slab (h x Y): block p = (h x ly) piece with my rows and the columns p + G k
-__global__ void k_pack_rows_to_cols(const fr_half *__restrict__ slab, fr_half *__restrict__ blocks, uint32_t h, uint32_t Y, uint32_t G, uint32_t ly) {
-    const uint64_t total = (uint64_t)h * Y;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        // e enumerates the DESTINATION (p, i, k) so that stores are contiguous; loads stride by G elements
+__global__ void k_pack_rows_to_cols(const fr_half *__restrict__ slab, fr_half *__restrict__ blocks, uint32_t h, uint32_t Y, uint32_t G, uint32_t ly, uint32_t hv) {
+    const uint64_t total = (uint64_t)h * Y * hv;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        // t enumerates the DESTINATION (p, i, k, piece) so that stores are contiguous; loads stride by G records
+        const uint64_t e = t / hv;
+        const uint32_t piece = (uint32_t)(t - e * hv);
         const uint32_t p = (uint32_t)(e / ((uint64_t)h * ly));
         const uint64_t rem = e - (uint64_t)p * h * ly;
         const uint32_t i = (uint32_t)(rem / ly), k = (uint32_t)(rem - (uint64_t)i * ly);
-        const uint64_t src = (uint64_t)i * Y + p + (uint64_t)G * k;
-        blocks[2 * e] = slab[2 * src], blocks[2 * e + 1] = slab[2 * src + 1];
+        blocks[t] = slab[((uint64_t)i * Y + p + (uint64_t)G * k) * hv + piece];
     }
 }
 static unsigned copy_grid(uint64_t total) {
@@ -644,8 +645,8 @@ TKD_API tkmk_error tkmk_dist_fwd_cols_to_rows(tkmk_comm *c, const tkmk_fr *in_co
         return ea;
     }
     // 3. interleave the received column sets into whole rows (columns past in_y are the zero padding), 4. Y pass over the local rows
-    hipLaunchKernelGGL(k_unpack_cols_to_rows, copy_grid((uint64_t)h * y_size), 256, 0, 0, (const fr_half *)d_b, (fr_half *)out_rows_dev, (uint32_t)h, (uint32_t)y_size,
-                       (uint32_t)in_y, (uint32_t)G, (uint32_t)lyb);
+    hipLaunchKernelGGL(k_unpack_cols_to_rows, copy_grid((uint64_t)h * y_size * 2), 256, 0, 0, (const fr_half *)d_b, (fr_half *)out_rows_dev, (uint32_t)h, (uint32_t)y_size,
+                       (uint32_t)in_y, (uint32_t)G, (uint32_t)lyb, 2u);
     hipError_t he = hipGetLastError();
     if (he == hipSuccess) he = hipDeviceSynchronize();
     (void)tkmk_free(d_a), (void)tkmk_free(d_b);
@@ -676,8 +677,8 @@ TKD_API tkmk_error tkmk_dist_inv_rows_to_cols(tkmk_comm *c, tkmk_fr *in_rows_dev
     if (e == TKMK_SUCCESS) e = tkmk_device_synchronize();
     // 2. pack the column set of every destination, ONE all-to-all; the block from rank q is rows [q h, (q + 1) h) of my columns: in place
     if (e == TKMK_SUCCESS) {
-        hipLaunchKernelGGL(k_pack_rows_to_cols, copy_grid((uint64_t)h * y_size), 256, 0, 0, (const fr_half *)in_rows_dev, (fr_half *)d_send, (uint32_t)h, (uint32_t)y_size,
-                           (uint32_t)G, (uint32_t)ly);
+        hipLaunchKernelGGL(k_pack_rows_to_cols, copy_grid((uint64_t)h * y_size * 2), 256, 0, 0, (const fr_half *)in_rows_dev, (fr_half *)d_send, (uint32_t)h, (uint32_t)y_size,
+                           (uint32_t)G, (uint32_t)ly, 2u);
         hipError_t he = hipGetLastError();
         if (he == hipSuccess) he = hipDeviceSynchronize();
         if (he != hipSuccess) e = TKMK_ERR_UNKNOWN;
@@ -715,5 +716,52 @@ TKD_API tkmk_error tkmk_dist_rows_rotate(tkmk_comm *c, const tkmk_fr *slab_dev, 
         if (ea == TKMK_SUCCESS && h > rot) ea = tkmk_memcpy_d2d((uint8_t *)out_dev + rot * row, slab_dev, (h - rot) * row);
     }
     (void)tkmk_free(d_all);
+    return ea;
+}
+
+// The same change of layout for records of any size that is a multiple of 16 bytes (a G1 affine point: 96) — what the group transforms
+// behind the Lagrange-basis commit tables move at open (host/tkmk_service.hpp): COLS x_size x (y_size / G) -> ROWS (x_size / G) x y_size
+// and back, one all-to-all each, no transform.
+TKD_API tkmk_error tkmk_dist_relayout_cols_to_rows(tkmk_comm *c, const void *in_cols_dev, size_t x_size, size_t y_size, size_t record_bytes, void *out_rows_dev) {
+    if (!c || !in_cols_dev || !out_rows_dev) return TKMK_ERR_INVALID_POINTER;
+    const size_t G = (size_t)c->world;
+    if (!pow2(G) || !pow2(x_size) || !pow2(y_size) || x_size < G || y_size < G || !record_bytes || record_bytes % 16) return TKMK_ERR_INVALID_ARGUMENT;
+    device_turn turn(c);
+    const size_t ly = y_size / G, h = x_size / G, hv = record_bytes / 16;
+    void *d_b = nullptr;
+    tkmk_error e = tkmk_malloc(&d_b, x_size * ly * record_bytes);
+    if (e == TKMK_SUCCESS) e = tkmk_device_synchronize();
+    tkmk_error ea = agree(c, turn, e, "tkmk_dist_relayout_cols_to_rows");
+    if (ea == TKMK_SUCCESS) ea = transport_all_to_all(c, turn, in_cols_dev, d_b, h * ly * record_bytes);
+    if (ea != TKMK_SUCCESS) {
+        (void)tkmk_free(d_b);
+        return ea;
+    }
+    hipLaunchKernelGGL(k_unpack_cols_to_rows, copy_grid((uint64_t)h * y_size * hv), 256, 0, 0, (const fr_half *)d_b, (fr_half *)out_rows_dev, (uint32_t)h, (uint32_t)y_size,
+                       (uint32_t)y_size, (uint32_t)G, (uint32_t)ly, (uint32_t)hv);
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    (void)tkmk_free(d_b);
+    if (he != hipSuccess) return fail(TKMK_ERR_UNKNOWN, std::string("k_unpack_cols_to_rows: ") + hipGetErrorString(he));
+    return TKMK_SUCCESS;
+}
+TKD_API tkmk_error tkmk_dist_relayout_rows_to_cols(tkmk_comm *c, const void *in_rows_dev, size_t x_size, size_t y_size, size_t record_bytes, void *out_cols_dev) {
+    if (!c || !in_rows_dev || !out_cols_dev) return TKMK_ERR_INVALID_POINTER;
+    const size_t G = (size_t)c->world;
+    if (!pow2(G) || !pow2(x_size) || !pow2(y_size) || x_size < G || y_size < G || !record_bytes || record_bytes % 16) return TKMK_ERR_INVALID_ARGUMENT;
+    device_turn turn(c);
+    const size_t ly = y_size / G, h = x_size / G, hv = record_bytes / 16;
+    void *d_send = nullptr;
+    tkmk_error e = tkmk_malloc(&d_send, h * y_size * record_bytes);
+    if (e == TKMK_SUCCESS) {
+        hipLaunchKernelGGL(k_pack_rows_to_cols, copy_grid((uint64_t)h * y_size * hv), 256, 0, 0, (const fr_half *)in_rows_dev, (fr_half *)d_send, (uint32_t)h, (uint32_t)y_size,
+                           (uint32_t)G, (uint32_t)ly, (uint32_t)hv);
+        hipError_t he = hipGetLastError();
+        if (he == hipSuccess) he = hipDeviceSynchronize();
+        if (he != hipSuccess) e = TKMK_ERR_UNKNOWN;
+    }
+    tkmk_error ea = agree(c, turn, e, "tkmk_dist_relayout_rows_to_cols");
+    if (ea == TKMK_SUCCESS) ea = transport_all_to_all(c, turn, d_send, out_cols_dev, h * ly * record_bytes);
+    (void)tkmk_free(d_send);
     return ea;
 }

@@ -150,7 +150,16 @@ fr_t fr_from_abi(const tkmk_fr &v) {
 
 TK_API tkmk_error tkmk_g1_ntt(const tkmk_g1_affine *in_dev, int bases_form, uint32_t in_stride, uint32_t x_size, uint32_t y_size, tkmk_ntt_dir dir,
                               tkmk_g1_affine *out_dev, tkmk_stream stream) {
+    return tkmk_g1_ntt_axes(in_dev, bases_form, in_stride, x_size, y_size, dir, TKMK_G1_NTT_AXIS_X | TKMK_G1_NTT_AXIS_Y, out_dev, stream);
+}
+
+// the same with either pass switched off: AXIS_Y alone = x_size independent transforms of length y_size along the rows, AXIS_X alone =
+// y_size transforms of length x_size along the columns.  A sharded context runs the X pass over its own columns of the grid and the Y
+// pass over its own rows, with a change of layout in between (host/tkmk_service.hpp): 1 / G of the group transform per rank.
+TK_API tkmk_error tkmk_g1_ntt_axes(const tkmk_g1_affine *in_dev, int bases_form, uint32_t in_stride, uint32_t x_size, uint32_t y_size, tkmk_ntt_dir dir,
+                                   int axes, tkmk_g1_affine *out_dev, tkmk_stream stream) {
     if (!in_dev || !out_dev) return TKMK_ERR_INVALID_POINTER;
+    if (axes & ~(TKMK_G1_NTT_AXIS_X | TKMK_G1_NTT_AXIS_Y)) return TKMK_ERR_INVALID_ARGUMENT;
     if (!x_size || !y_size || (x_size & (x_size - 1)) || (y_size & (y_size - 1)) || in_stride < y_size) return TKMK_ERR_INVALID_ARGUMENT;
     if (bases_form != TKMK_BASES_PLAIN && bases_form != TKMK_BASES_MONTGOMERY && bases_form != TKMK_BASES_CONVERTED) return TKMK_ERR_INVALID_ARGUMENT;
     if ((uint64_t)x_size * y_size >= (1ull << 31)) return TKMK_ERR_INVALID_ARGUMENT;
@@ -198,8 +207,8 @@ TK_API tkmk_error tkmk_g1_ntt(const tkmk_g1_affine *in_dev, int bases_form, uint
             std::swap(cur, nxt);
         }
     };
-    axis(y_size, 1, y_size, x_size, d_twy.as<fr_t>());   // along Y inside every row
-    axis(x_size, y_size, 1, y_size, d_twx.as<fr_t>());   // along X inside every column
+    if (axes & TKMK_G1_NTT_AXIS_Y) axis(y_size, 1, y_size, x_size, d_twy.as<fr_t>());   // along Y inside every row
+    if (axes & TKMK_G1_NTT_AXIS_X) axis(x_size, y_size, 1, y_size, d_twx.as<fr_t>());   // along X inside every column
     hipLaunchKernelGGL(k_g1ntt_store, tk_div_up(n, 128), 128, 0, s, (const g1_xyzz_t *)cur, n, (g1_affine_t *)out_dev);
     TK_HIP(hipGetLastError());
     TK_HIP(hipStreamSynchronize(s));   // the host twiddle vectors and the frame's scratch end with this call

@@ -63,21 +63,38 @@ struct lincomb_args_t {
     uint8_t kind[LC_MAX_TERMS];               // 0: c * p, 1: + p, 2: - p  (unit coefficients skip the product)
     uint32_t n;
 };
-__global__ __launch_bounds__(256) void k_lincomb(lincomb_args_t a, fr_t *__restrict__ out, uint32_t dx, uint32_t dy) {
-    uint64_t total = (uint64_t)dx * dy;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t i = (uint32_t)(e / dy), j = (uint32_t)(e - (uint64_t)i * dy);
-        fr_t acc = Fr::zero();
+// Two adjacent elements of a row per lane and step (dy even: 64 contiguous bytes per operand and lane in flight, the row / column of the
+// pair computed once — by shift and mask when dy is a power of two, which every matrix of the polynomial layer is); a lane of an odd-width
+// matrix takes one element.  HBM-streaming: FETCH x 2 + WRITE over the launch time is quoted in DESIGN.md section 5.
+template <int V>
+__global__ __launch_bounds__(256) void k_lincomb(lincomb_args_t a, fr_t *__restrict__ out, uint32_t dx, uint32_t dy, int dy_shift) {
+    const uint64_t total = (uint64_t)dx * dy / V;   // V-element groups
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = g * V;
+        uint32_t i, j;
+        if (dy_shift >= 0) i = (uint32_t)(e >> dy_shift), j = (uint32_t)e & (dy - 1);
+        else i = (uint32_t)(e / dy), j = (uint32_t)(e - (uint64_t)i * dy);
+        fr_t acc[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[v] = Fr::zero();
         for (uint32_t t = 0; t < a.n; t++) {
-            uint32_t ii = i - a.ox[t], jj = j - a.oy[t];      // unsigned wrap makes "below the offset" fail the range test too
-            if (ii < a.xs[t] && jj < a.ys[t]) {
-                fr_t v = Fr::canon(tk_load(a.p[t] + (uint64_t)ii * a.ys[t] + jj));
-                if (a.kind[t] == 1) acc = Fr::add(acc, v);
-                else if (a.kind[t] == 2) acc = Fr::sub(acc, v);
-                else acc = Fr::add(acc, Fr::mul(v, a.c[t]));
+            const uint32_t ii = i - a.ox[t];      // unsigned wrap makes "below the offset" fail the range test too
+            if (ii >= a.xs[t]) continue;
+            const fr_t *row = a.p[t] + (uint64_t)ii * a.ys[t];
+            const uint32_t kind = a.kind[t];
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                const uint32_t jj = j + v - a.oy[t];
+                if (jj < a.ys[t]) {
+                    fr_t x = Fr::canon(tk_load(row + jj));
+                    if (kind == 1) acc[v] = Fr::add(acc[v], x);
+                    else if (kind == 2) acc[v] = Fr::sub(acc[v], x);
+                    else acc[v] = Fr::add(acc[v], Fr::mul(x, a.c[t]));
+                }
             }
         }
-        tk_store(out + e, acc);
+#pragma unroll
+        for (int v = 0; v < V; v++) tk_store(out + e + v, acc[v]);
     }
 }
 
@@ -369,7 +386,11 @@ TK_API tkmk_error tkmk_poly_lincomb(uint32_t n_terms, const tkmk_fr *coeffs_host
             dst = nxt.as<fr_t>();
             partial = nxt;
         }
-        hipLaunchKernelGGL(k_lincomb, stream_grid((uint64_t)out_xs * out_ys), 256, 0, s, a, dst, out_xs, out_ys);
+        int dy_shift = -1;
+        if ((out_ys & (out_ys - 1)) == 0)
+            for (dy_shift = 0; (1u << dy_shift) < out_ys; dy_shift++) {}
+        if (out_ys % 2 == 0) hipLaunchKernelGGL(k_lincomb<2>, stream_grid((uint64_t)out_xs * out_ys / 2), 256, 0, s, a, dst, out_xs, out_ys, dy_shift);
+        else hipLaunchKernelGGL(k_lincomb<1>, stream_grid((uint64_t)out_xs * out_ys), 256, 0, s, a, dst, out_xs, out_ys, dy_shift);
         TK_HIP(hipGetLastError());
         carry = dst;
     }

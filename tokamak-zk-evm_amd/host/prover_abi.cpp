@@ -97,6 +97,8 @@ static ShardLink link_for(void *comm) {
     l.inv_rows_to_cols = (decltype(l.inv_rows_to_cols))sym("tkmk_dist_inv_rows_to_cols");
     l.rows_rotate = (decltype(l.rows_rotate))sym("tkmk_dist_rows_rotate");
     l.ring_shift = (decltype(l.ring_shift))sym("tkmk_comm_ring_shift");
+    l.relayout_cols_to_rows = (decltype(l.relayout_cols_to_rows))sym("tkmk_dist_relayout_cols_to_rows");
+    l.relayout_rows_to_cols = (decltype(l.relayout_rows_to_cols))sym("tkmk_dist_relayout_rows_to_cols");
     int world = ((int (*)(const void *))sym("tkmk_comm_size"))(comm), rank = ((int (*)(const void *))sym("tkmk_comm_rank"))(comm);
     if (world < 1 || rank < 0 || rank >= world) throw Error("tkmk_prover_open_sharded: invalid communicator");
     l.shard = Shard{(uint32_t)world, (uint32_t)rank};
@@ -111,10 +113,8 @@ TKP_API tkmk_error tkmk_prover_open_sharded(void *comm, const char *subcircuit_l
         ShardLink link = link_for(comm);
         std::string crs = crs_dir;
         std::unique_ptr<tkmk_prover> p(new tkmk_prover());
-        std::unique_ptr<Sigma1> whole;
         p->ctx = ProverContext::open(
-            subcircuit_library_dir, crs,
-            [&](const SetupParams &sp, std::string &source) { return load_prover_sigma(crs, sp, source, resident_table_c(sp), link.shard, &whole); }, link, &whole);
+            subcircuit_library_dir, crs, [&](const SetupParams &sp, std::string &source) { return load_prover_sigma(crs, sp, source, resident_table_c(sp), link.shard); }, link);
         *out = p.release();
     });
 }

@@ -1022,6 +1022,8 @@ class Sigma1 {
     size_t rs_x() const { return rs_x_; }
     size_t rs_y() const { return rs_y_; }
     size_t table_len() const { return rs_x_ * local_cols_; }   // rows of one table level on THIS rank
+    size_t local_cols() const { return local_cols_; }
+    const G1Affine *level0() const { return xy_powers_.ptr(); }   // this rank's rs_x x local_cols monomial points, resident (converted) form
     const Shard &shard() const { return shard_; }
     // columns r, r + G, ... of a row-major rs_x x rs_y grid of points: what rank r of G keeps (one strided copy on the device: local
     // element (i, k) = grid element (i, r + G k) = flat index r + G (i lc + k) when G divides rs_y)

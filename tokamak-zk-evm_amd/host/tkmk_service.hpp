@@ -44,6 +44,8 @@ struct ShardLink {
     tkmk_error (*inv_rows_to_cols)(void *, tkmk_fr *, size_t, size_t, int, tkmk_fr *) = nullptr;
     tkmk_error (*rows_rotate)(void *, const tkmk_fr *, size_t, size_t, size_t, tkmk_fr *) = nullptr;
     tkmk_error (*ring_shift)(void *, const void *, size_t, int, void *) = nullptr;
+    tkmk_error (*relayout_cols_to_rows)(void *, const void *, size_t, size_t, size_t, void *) = nullptr;
+    tkmk_error (*relayout_rows_to_cols)(void *, const void *, size_t, size_t, size_t, void *) = nullptr;
     explicit operator bool() const { return comm != nullptr; }
 };
 // for the span of one call on a sharded context: this thread's polynomials are distributed (dist_ctx()), its commit batches go through the
@@ -158,11 +160,11 @@ class ProverContext {
 
     // circuit-static state: subcircuit library from <lib_dir>, reference string from <crs_dir> (combined_sigma.rkyv, or the flat
     // combined_sigma.tkcrs payload when only that is present)
-    // link set: load_sigma returns this rank's rows of xy_powers and hands the whole grid over through *whole_grid (dropped here once
-    // the Lagrange-basis tables are cut from it)
+    // link set: load_sigma returns this rank's columns of xy_powers; everything derived from them (table expansion, the Lagrange-basis
+    // tables and their prefix sums) is made from those columns, 1 / G of the work per rank
     static std::unique_ptr<ProverContext> open(const std::string &lib_dir, const std::string &crs_dir,
                                                const std::function<std::unique_ptr<ProverSigma>(const SetupParams &, std::string &)> &load_sigma,
-                                               const ShardLink &link = ShardLink{}, std::unique_ptr<Sigma1> *whole_grid = nullptr) {
+                                               const ShardLink &link = ShardLink{}) {
         std::unique_ptr<ProverContext> c(new ProverContext());
         c->link = link;
         ShardSpan span(c->link);
@@ -288,33 +290,86 @@ class ProverContext {
                         c->lagrange_n_.reset(new Sigma1(s1.lagrange_of(n, s_max)));
                     }
                 } else {
-                    // sharded: the group transforms run over the WHOLE grid on every rank (one-time work, seconds); each rank keeps its
-                    // columns — a plain table over its own m_I x (s_max / G) part of the grid, committed against its own columns of the
-                    // evaluations (COLS layout on both sides) — and, of the walk-ordered prefix sums, the stretches of its columns
-                    // (the walk goes down column 0, then column 1, ...: one row of the s_max x m_I grid per column)
-                    if (!whole_grid || !*whole_grid) throw Error("sharded open: the whole xy_powers grid was not handed over");
-                    const Sigma1 &whole = **whole_grid;
+                    // sharded: the group transforms are divided like the field transforms of a proof (r4).  The inverse NTT over G1 points runs
+                    // its X pass over this rank's columns of the monomial grid (the level-0 part of its own commit table), changes layout
+                    // (one all-to-all of 96-byte points), runs its Y pass over this rank's rows, and changes back: 1 / G of the
+                    // butterflies per rank, and the result IS this rank's columns of the Lagrange-basis grid — a plain table over its own
+                    // m_I x (s_max / G) part, committed against its own columns of the evaluations (COLS layout on both sides).
                     const Shard sh = c->link.shard;
-                    const size_t lc = sh.cols_of(s_max);
-                    DeviceVec<G1Affine> lam_mi = whole.lagrange_points(m_i, s_max);
+                    const ShardLink &lk = c->link;
+                    const size_t G = sh.world, lc = sh.cols_of(s_max);
+                    auto lagrange_cols = [&](size_t xs, size_t ys) {   // -> plain affine, xs x (ys / G)
+                        const size_t lcs = ys / G, h = xs / G;
+                        DeviceVec<G1Affine> a(xs * lcs), rows(h * ys), b(h * ys);
+                        host_trace("lagrange_points %zu x %zu (rank %u of %zu)", xs, ys, sh.rank, G);
+                        check(tkmk_g1_ntt_axes(s1.level0(), TKMK_BASES_CONVERTED, (uint32_t)s1.local_cols(), (uint32_t)xs, (uint32_t)lcs, TKMK_NTT_INVERSE, TKMK_G1_NTT_AXIS_X,
+                                               a.ptr(), nullptr),
+                              "tkmk_g1_ntt_axes");
+                        check(lk.relayout_cols_to_rows(lk.comm, a.ptr(), xs, ys, sizeof(G1Affine), rows.ptr()), "tkmk_dist_relayout_cols_to_rows");
+                        check(tkmk_g1_ntt_axes(rows.ptr(), TKMK_BASES_PLAIN, (uint32_t)ys, (uint32_t)h, (uint32_t)ys, TKMK_NTT_INVERSE, TKMK_G1_NTT_AXIS_Y, b.ptr(), nullptr),
+                              "tkmk_g1_ntt_axes");
+                        check(lk.relayout_rows_to_cols(lk.comm, b.ptr(), xs, ys, sizeof(G1Affine), a.ptr()), "tkmk_dist_relayout_rows_to_cols");
+                        return a;
+                    };
+                    DeviceVec<G1Affine> lam_mi = lagrange_cols(m_i, s_max);
                     {
-                        DeviceVec<G1Affine> pre = Sigma1::lagrange_prefix_points(lam_mi, m_i, s_max);
-                        c->lagrange_mi_prefix_.reset(new Sigma1(Sigma1::rows_of_grid(pre, s_max, m_i, sh), lc * m_i, 1, s1.table_c()));
+                        // the walk-ordered prefix sums S_j = sum_{j' <= j} Lambda_walk(j') of prove1, this rank's stretches of them (the walk
+                        // goes down column 0, then column 1, ...).  My columns in walk order, the column totals of ALL ranks gathered
+                        // (s_max points), and in front of every one of my columns ONE extra point = the sum of the other ranks' columns the
+                        // walk passes between my previous column and this one: the ordinary running sum over that sequence is the global one.
+                        DeviceVec<G1Affine> walk(lc * m_i);
+                        for (size_t k = 0; k < lc; k++)
+                            check(tkmk_memcpy_2d_d2d(walk.ptr() + k * m_i, sizeof(G1Affine), lam_mi.ptr() + k, lc * sizeof(G1Affine), sizeof(G1Affine), m_i), "walk order");
+                        std::vector<ScalarField> ones_h(std::max<size_t>(m_i, G), fr_from_u32(1));
+                        DeviceVec<ScalarField> ones = DeviceVec<ScalarField>::from_host(ones_h);
+                        std::vector<tkmk_msm_job_ex> jobs(lc);
+                        for (size_t k = 0; k < lc; k++) {
+                            tkmk_msm_job_ex j{};
+                            j.scalars = ones.ptr(), j.bases = walk.ptr() + k * m_i, j.msm_size = (int)m_i, j.base_table_len = m_i;
+                            jobs[k] = j;
+                        }
+                        tkmk_msm_config mc = Sigma1::device_cfg();
+                        std::vector<tkmk_g1_projective> tot(lc);
+                        check(tkmk_msm_multi_ex(jobs.data(), (int)lc, &mc, TKMK_BASES_PLAIN, tot.data()), "column totals");
+                        std::vector<G1Affine> mine(lc), all(lc * G);
+                        for (size_t k = 0; k < lc; k++) mine[k] = Sigma1::to_affine(tot[k]);
+                        check(lk.all_gather_host(lk.comm, mine.data(), lc * sizeof(G1Affine), all.data()), "tkmk_comm_all_gather_host");
+                        auto total_of = [&](size_t col) { return all[(col % G) * lc + col / G]; };
+                        std::vector<G1Affine> between(lc, G1Affine{});   // (0, 0) = the point at infinity
+                        if (G > 1) {
+                            std::vector<ScalarField> sc(lc * (G - 1), fr_from_u32(1));
+                            std::vector<G1Affine> pts(lc * (G - 1), G1Affine{});
+                            for (size_t k = 0; k < lc; k++) {
+                                const size_t lo = k ? sh.rank + G * (k - 1) + 1 : 0, hi = sh.rank + G * k;   // the other ranks' columns in [lo, hi)
+                                for (size_t col = lo, at = 0; col < hi; col++, at++) pts[k * (G - 1) + at] = total_of(col);
+                            }
+                            tkmk_msm_config hc = tkmk_msm_default_config();
+                            hc.batch_size = (int)lc, hc.are_points_shared_in_batch = false;
+                            std::vector<tkmk_g1_projective> res(lc);
+                            check(bls12_381_msm(sc.data(), pts.data(), (int)(G - 1), &hc, res.data()), "sums between my columns");
+                            for (size_t k = 0; k < lc; k++) between[k] = Sigma1::to_affine(res[k]);
+                        }
+                        DeviceVec<G1Affine> seq(lc * (m_i + 1)), sums(lc * (m_i + 1)), pre(lc * m_i);
+                        for (size_t k = 0; k < lc; k++) {
+                            check(tkmk_memcpy_h2d(seq.ptr() + k * (m_i + 1), &between[k], sizeof(G1Affine)), "offset point");
+                            check(tkmk_memcpy_d2d(seq.ptr() + k * (m_i + 1) + 1, walk.ptr() + k * m_i, m_i * sizeof(G1Affine)), "walk order");
+                        }
+                        check(tkmk_g1_prefix_sums(seq.ptr(), TKMK_BASES_PLAIN, (uint32_t)(lc * (m_i + 1)), 1, 0, sums.ptr(), nullptr), "tkmk_g1_prefix_sums");
+                        for (size_t k = 0; k < lc; k++)
+                            check(tkmk_memcpy_d2d(pre.ptr() + k * m_i, sums.ptr() + k * (m_i + 1) + 1, m_i * sizeof(G1Affine)), "strip offsets");
+                        c->lagrange_mi_prefix_.reset(new Sigma1(std::move(pre), lc * m_i, 1, s1.table_c()));
                     }
-                    std::unique_ptr<Sigma1> local_mi(new Sigma1(Sigma1::cols_of_grid(lam_mi, m_i, s_max, sh), m_i, lc, s1.table_c()));
-                    lam_mi = DeviceVec<G1Affine>();
+                    std::unique_ptr<Sigma1> local_mi(new Sigma1(std::move(lam_mi), m_i, lc, s1.table_c()));
                     if (m_i == n) {
                         c->lagrange_n_ = std::move(local_mi);
                         c->lagrange_mi_ = c->lagrange_n_.get();
                     } else {
                         c->lagrange_mi_own_ = std::move(local_mi);
                         c->lagrange_mi_ = c->lagrange_mi_own_.get();
-                        DeviceVec<G1Affine> lam_n = whole.lagrange_points(n, s_max);
-                        c->lagrange_n_.reset(new Sigma1(Sigma1::cols_of_grid(lam_n, n, s_max, sh), n, lc, s1.table_c()));
+                        c->lagrange_n_.reset(new Sigma1(lagrange_cols(n, s_max), n, lc, s1.table_c()));
                     }
                 }
             }
-            if (whole_grid) whole_grid->reset();   // the whole grid has served its purpose: 1/G of it stays resident
         }
         host_trace("open: Lagrange polynomials");
         c->lagrange_ = Prover::LagrangePolys::make(c->m_i, c->sp.s_max);

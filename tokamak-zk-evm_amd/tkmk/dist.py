@@ -17,7 +17,8 @@ SYMBOLS = ["tkmk_comm_unique_id", "tkmk_comm_init", "tkmk_comm_init_loopback", "
            "tkmk_comm_broadcast_host", "tkmk_comm_destroy", "tkmk_comm_rank",
            "tkmk_comm_size", "tkmk_dist_last_error", "tkmk_msm_sharded", "tkmk_msm_multi_ex_sharded", "tkmk_bintt_sharded",
            "tkmk_comm_all_gather_host", "tkmk_comm_all_gather_dev", "tkmk_comm_agree", "tkmk_comm_abort", "tkmk_dist_fwd_cols_to_rows",
-           "tkmk_dist_inv_rows_to_cols", "tkmk_dist_rows_rotate", "tkmk_comm_ring_shift", "tkmk_comm_describe"]
+           "tkmk_dist_inv_rows_to_cols", "tkmk_dist_rows_rotate", "tkmk_comm_ring_shift", "tkmk_comm_describe", "tkmk_dist_relayout_cols_to_rows",
+           "tkmk_dist_relayout_rows_to_cols"]
 SKIP_X_PASS, SKIP_Y_PASS = 1, 2          # TKMK_DIST_* of include/tkmk_dist.h
 
 
