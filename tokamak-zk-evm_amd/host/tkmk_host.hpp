@@ -484,7 +484,15 @@ class DensePolynomialExt {
             nx = std::max(nx, next_pow2(t.p->x_size + t.ox)), ny = std::max(ny, next_pow2(t.p->y_size + t.oy));
             all_rep = all_rep && !t.p->distributed();
             if (t.p->x_degree >= 0 && t.p->y_degree >= 0 && !fr_is_zero(t.c)) bx = std::max<int64_t>(bx, t.p->x_degree + t.ox), by = std::max<int64_t>(by, t.p->y_degree + t.oy);
+#ifdef TKMK_TESTING_MODE
+            (void)t.p->shape_degree();   // the row truncation below trusts the operands' bounds: the testing builds measure them
+#endif
         }
+        // The sum has no more rows than its degree bound says, whatever the operands' matrices are allocated to (a vanishing quotient sits
+        // in its numerator's 4 m_I rows although it has fewer than 2 m_I): the output gets next_pow2(bound + 1) rows and every operand is
+        // read up to there only — the rows beyond hold zeros by the same bounds.  (Columns keep their allocated width: the kernel takes one
+        // number for an operand's width and stride.)
+        if (!measure_degrees()) nx = std::min(nx, next_pow2((size_t)std::max<int64_t>(bx, 0) + 1));
         const DistCtx &dc = dist_ctx();
         // sharded prover: operands that are all replicated and small give a replicated result (every rank computes the same few values);
         // anything else is a distributed matrix, each rank combining its columns of every operand
@@ -496,8 +504,10 @@ class DensePolynomialExt {
         std::vector<DeviceVec<ScalarField>> temps;   // local column sets of replicated operands, columns received from the neighbour for Y shifts
         for (const Term &t : terms) {
             const DensePolynomialExt &p = *t.p;
+            if (t.ox >= nx) continue;                                        // wholly beyond the bound: a zero polynomial
+            const uint32_t rows_in = (uint32_t)std::min<size_t>(p.x_size, nx - t.ox);   // rows of this operand that land inside the output
             if (out_rep) {
-                c.push_back(t.c), ptr.push_back(p.poly.ptr()), xs.push_back((uint32_t)p.x_size), ys.push_back((uint32_t)p.y_size), ox.push_back(t.ox), oy.push_back(t.oy);
+                c.push_back(t.c), ptr.push_back(p.poly.ptr()), xs.push_back(rows_in), ys.push_back((uint32_t)p.y_size), ox.push_back(t.ox), oy.push_back(t.oy);
                 continue;
             }
             const uint32_t G = dc.G(), r = dc.r();
@@ -505,7 +515,7 @@ class DensePolynomialExt {
                 // a replicated operand contributes its columns r, r + G, ...: a strided copy of that set (a Y shift that is not a multiple
                 // of G is applied to the whole small matrix first)
                 DensePolynomialExt d = (t.oy % G) ? p.mul_monomial(0, t.oy).to_distributed() : p.to_distributed();
-                const size_t lc = d.ly(), lx = d.x_size;
+                const size_t lc = d.ly(), lx = std::min<size_t>(d.x_size, nx - t.ox);
                 temps.push_back(std::move(d.poly));
                 if (!lc) continue;
                 c.push_back(t.c), ptr.push_back(temps.back().ptr()), xs.push_back((uint32_t)lx), ys.push_back((uint32_t)lc), ox.push_back(t.ox);
@@ -515,7 +525,7 @@ class DensePolynomialExt {
             const size_t lc = p.ly();
             if (t.oy % G == 0) {
                 if (!lc) continue;
-                c.push_back(t.c), ptr.push_back(p.poly.ptr()), xs.push_back((uint32_t)p.x_size), ys.push_back((uint32_t)lc), ox.push_back(t.ox), oy.push_back(t.oy / G);
+                c.push_back(t.c), ptr.push_back(p.poly.ptr()), xs.push_back(rows_in), ys.push_back((uint32_t)lc), ox.push_back(t.ox), oy.push_back(t.oy / G);
                 continue;
             }
             // Y^oy p: global column j of p becomes column j + oy.  With s = oy mod G, my local column k (global r + G k) receives the
@@ -525,7 +535,7 @@ class DensePolynomialExt {
             const uint32_t sft = t.oy % G;
             temps.emplace_back(p.x_size * lc);
             check(dc.ring_shift(dc.comm, p.poly.ptr(), p.x_size * lc * sizeof(ScalarField), (int)sft, temps.back().ptr()), "tkmk_comm_ring_shift");
-            c.push_back(t.c), ptr.push_back(temps.back().ptr()), xs.push_back((uint32_t)p.x_size), ys.push_back((uint32_t)lc), ox.push_back(t.ox);
+            c.push_back(t.c), ptr.push_back(temps.back().ptr()), xs.push_back(rows_in), ys.push_back((uint32_t)lc), ox.push_back(t.ox);
             oy.push_back(t.oy / G + (r < sft ? 1u : 0u));
         }
         const size_t out_l = local_cols(ny, out_rep);

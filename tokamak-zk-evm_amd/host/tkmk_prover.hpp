@@ -8,6 +8,7 @@
 #include <array>
 #include <chrono>
 #include <functional>
+#include <future>
 #include <initializer_list>
 #include <map>
 #include <memory>
@@ -301,6 +302,24 @@ class Prover {
         return *lagrange;
     }
     std::map<std::string, double> timing;
+    // EARLY COMMITS (a resident single-GPU context sets commit_stream): the commitments of a round that do not wait for the round's
+    // polynomial work — prove0's U, V, W, B from the evaluations init left behind, prove4's M_X, M_Y, N_Y from R and the round-3 openings —
+    // are issued from a helper thread on their own stream BEFORE that work starts and collected after the round's last commit batch.
+    // They are the sparse or small MSMs whose time goes to sorts and latency-bound tails; those now run under the transforms and
+    // streaming passes of the same round instead of behind them.  Same jobs, same points: not a byte of the proof changes
+    // (TKMK_PROVER_EARLY_COMMITS=0 restores the in-line order).
+    tkmk_stream commit_stream = nullptr;
+    bool can_commit_early() const {
+        static const bool enabled = [] {
+            const char *e = getenv("TKMK_PROVER_EARLY_COMMITS");
+            return !(e && atoi(e) == 0);
+        }();
+        return enabled && commit_stream && !dist_ctx().on() && !commit_comm().comm && !commit_box_sink() && tkmk_msm_get_pipeline_streams() > 1;
+    }
+    std::future<std::vector<G1Affine>> commit_early(std::vector<tkmk_msm_job_ex> jobs) const {
+        tkmk_stream st = commit_stream;
+        return std::async(std::launch::async, [jobs, st] { return Sigma1::run_jobs(jobs, st); });
+    }
 
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -390,34 +409,48 @@ class Prover {
         using namespace prover_detail;
         const Mixer &mx = mixer;
         size_t n = sp.n, s_max = sp.s_max;
+        const bool from_evaluations = lagrange_n && lagrange_mi && u_ev.len() && v_ev.len() && w_ev.len() && b_ev.len();
+        // the evaluation-basis commits need nothing this round computes: they start now, under the transforms of p0 and its division
+        std::future<std::vector<G1Affine>> early;
+        if (from_evaluations && can_commit_early())
+            early = commit_early({lagrange_n->job_evals(u_ev, "U", n, s_max), lagrange_n->job_evals(v_ev, "V", n, s_max), lagrange_n->job_evals(w_ev, "W", n, s_max),
+                                  lagrange_mi->job_evals(b_ev, "B", m_i, s_max)});
         Poly p0XY = uXY * vXY - wXY;
         auto q01 = p0XY.div_by_vanishing_opt((int64_t)n, (int64_t)s_max);
         q0XY = std::move(q01.first), q1XY = std::move(q01.second);
         Poly rW_X = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_X.begin(), mx.rW_X.end()), 4, 1);
         Poly rW_Y = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_Y.begin(), mx.rW_Y.end()), 1, 4);
         ScalarField one = fr_one(), minus_one = fr_neg(one);
-        Poly UXY = poly_comb({{one, &uXY}, {mx.rU_X, &t_n}, {mx.rU_Y, &t_smax}});
-        Poly VXY = blinded_V();
         w_zk.reset(new Poly(low_degree_times_vanishing(mx.rW_X, n, true) + low_degree_times_vanishing(mx.rW_Y, s_max, false)));
-        Poly WXY = poly_comb({{one, &wXY}, {one, w_zk.get()}});
         Poly Q_AX_XY = poly_comb({{one, &q0XY}, {mx.rU_X, &vXY}, {mx.rV_X, &uXY}, {minus_one, &rW_X}, {fr_mul(mx.rU_X, mx.rV_X), &t_n},
                                   {fr_mul(mx.rU_Y, mx.rV_X), &t_smax}});
         Poly Q_AY_XY = poly_comb({{one, &q1XY}, {mx.rU_Y, &vXY}, {mx.rV_Y, &uXY}, {minus_one, &rW_Y}, {fr_mul(mx.rU_X, mx.rV_Y), &t_n},
                                   {fr_mul(mx.rU_Y, mx.rV_Y), &t_smax}});
         term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
-        if (lagrange_n && lagrange_mi && u_ev.len() && v_ev.len() && w_ev.len() && b_ev.len()) return prove0_from_evaluations(Q_AX_XY, Q_AY_XY);
+        if (from_evaluations) return prove0_from_evaluations(Q_AX_XY, Q_AY_XY, early);
+        Poly UXY = poly_comb({{one, &uXY}, {mx.rU_X, &t_n}, {mx.rU_Y, &t_smax}});
+        Poly VXY = blinded_V();
+        Poly WXY = poly_comb({{one, &wXY}, {one, w_zk.get()}});
         Poly BXY = poly_comb({{one, &bXY}, {one, term_b_zk.get()}});
         auto c = sigma->sigma1.encode_polys({&UXY, &VXY, &WXY, &Q_AX_XY, &Q_AY_XY, &BXY}, {"U", "V", "W", "Q_AX", "Q_AY", "B"});
         return Proof0{c[0], c[1], c[2], c[3], c[4], c[5]};
     }
     // U, V, W, B from the evaluations (same points as the coefficient route above):
     //   commit(p + sum_k c_k T^k (T^e - 1)) = (1/N) MSM(evaluations of p, Lagrange table) + sum_k c_k ([tau^(e+k)]G - [tau^k]G)
-    Proof0 prove0_from_evaluations(Poly &Q_AX_XY, Poly &Q_AY_XY) {
+    // early (valid): the four evaluation commits were issued before the round's polynomial work and are collected here
+    Proof0 prove0_from_evaluations(Poly &Q_AX_XY, Poly &Q_AY_XY, std::future<std::vector<G1Affine>> &early) {
         using namespace prover_detail;
         const Mixer &mx = mixer;
         const size_t n = sp.n, s_max = sp.s_max;
-        std::vector<G1Affine> c = Sigma1::run_jobs({lagrange_n->job_evals(u_ev, "U", n, s_max), lagrange_n->job_evals(v_ev, "V", n, s_max), lagrange_n->job_evals(w_ev, "W", n, s_max),
-                                                    sigma->sigma1.job(Q_AX_XY, "Q_AX"), sigma->sigma1.job(Q_AY_XY, "Q_AY"), lagrange_mi->job_evals(b_ev, "B", m_i, s_max)});
+        std::vector<G1Affine> c(6);
+        if (early.valid()) {
+            std::vector<G1Affine> q = Sigma1::run_jobs({sigma->sigma1.job(Q_AX_XY, "Q_AX"), sigma->sigma1.job(Q_AY_XY, "Q_AY")});
+            std::vector<G1Affine> e = early.get();
+            c = {e[0], e[1], e[2], q[0], q[1], e[3]};
+        } else {
+            c = Sigma1::run_jobs({lagrange_n->job_evals(u_ev, "U", n, s_max), lagrange_n->job_evals(v_ev, "V", n, s_max), lagrange_n->job_evals(w_ev, "W", n, s_max),
+                                  sigma->sigma1.job(Q_AX_XY, "Q_AX"), sigma->sigma1.job(Q_AY_XY, "Q_AY"), lagrange_mi->job_evals(b_ev, "B", m_i, s_max)});
+        }
         const ScalarField inv_n = fr_inv(fr_mul(fr_from_u32((uint32_t)n), fr_from_u32((uint32_t)s_max)));
         const ScalarField inv_mi = fr_inv(fr_mul(fr_from_u32((uint32_t)m_i), fr_from_u32((uint32_t)s_max)));
         using Row = std::vector<std::pair<ScalarField, G1Affine>>;
@@ -625,6 +658,16 @@ class Prover {
         ScalarField one = fr_one(), minus_one = fr_neg(one);
         auto ev = [&](const Poly &p) { return p.eval(chi, zeta); };
 
+        // M, N: openings of R at (chi / w_x, zeta) and (chi / w_x, zeta / w_y) (lib.rs:2534-2701).  First in this round (the reference has
+        // them after Pi_A; they depend on R and the round-3 openings only): their commitments can then run under everything that follows.
+        ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(s_max));
+        Poly RXY = blinded_R();
+        auto M = sub_const(RXY, proof3.R_omegaX_eval).div_by_ruffini(fr_mul(w_inv_x, chi), zeta);
+        auto N = sub_const(RXY, proof3.R_omegaX_omegaY_eval).div_by_ruffini(fr_mul(w_inv_x, chi), fr_mul(w_inv_y, zeta));
+        std::future<std::vector<G1Affine>> early;   // declared after M and N: it ends (and is waited for) before the polynomials its jobs read
+        if (!test_parts && can_commit_early())
+            early = commit_early({sigma->sigma1.job(std::get<0>(M), "M_X"), sigma->sigma1.job(std::get<1>(M), "M_Y"), sigma->sigma1.job(std::get<1>(N), "N_Y")});
+
         // Pi_A: arithmetic constraints + the opening of V (lib.rs:2383-2532)
         ScalarField t_n_eval = t_n.eval(chi, one), t_smax_eval = t_smax.eval(one, zeta), small_v_eval = ev(vXY);
         Poly rW_X = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_X.begin(), mx.rW_X.end()), 4, 1);
@@ -644,12 +687,6 @@ class Prover {
                                 {t_smax_eval, &rW_Y},
                                 {minus_one, w_zk.get()}});
         auto piA = pA_XY.div_by_ruffini(chi, zeta);
-
-        // M, N: openings of R at (chi / w_x, zeta) and (chi / w_x, zeta / w_y) (lib.rs:2534-2701)
-        ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(s_max));
-        Poly RXY = blinded_R();
-        auto M = sub_const(RXY, proof3.R_omegaX_eval).div_by_ruffini(fr_mul(w_inv_x, chi), zeta);
-        auto N = sub_const(RXY, proof3.R_omegaX_omegaY_eval).div_by_ruffini(fr_mul(w_inv_x, chi), fr_mul(w_inv_y, zeta));
 
         // Pi_C: copy constraints (lib.rs:2703-3130)
         Poly r_omegaX = rXY.scale_coeffs(&w_inv_x, nullptr);
@@ -707,6 +744,11 @@ class Prover {
             // (2^23 coefficients), Pi_CX (2^24) and Pi_B apart and adds the points
             Poly pi_x = Poly::lincomb({Term(one, &std::get<0>(piA)), Term(one, &std::get<0>(piC)), Term(k1_4, &std::get<0>(piB))});
             Poly pi_y = Poly::lincomb({Term(one, &std::get<1>(piA)), Term(one, &std::get<1>(piC))});
+            if (early.valid()) {
+                auto cc = sigma->sigma1.encode_polys({&pi_x, &pi_y}, {"Pi_X", "Pi_Y"});
+                std::vector<G1Affine> e = early.get();
+                return {Proof4{cc[0], cc[1], e[0], e[1], e[0], e[2]}, Proof4Test{}};
+            }
             auto cc = sigma->sigma1.encode_polys({&pi_x, &pi_y, &std::get<0>(M), &std::get<1>(M), &std::get<1>(N)}, {"Pi_X", "Pi_Y", "M_X", "M_Y", "N_Y"});
             return {Proof4{cc[0], cc[1], cc[2], cc[3], cc[2], cc[4]}, Proof4Test{}};
         }

@@ -114,6 +114,7 @@ class ProverContext {
     const Sigma1 *lagrange_mi_ = nullptr;                             // (= lagrange_n_ when n == m_I)
 
     tkmk_stream binding_stream_ = nullptr;                          // the helper thread's stream (PendingBinding)
+    tkmk_stream commit_stream_ = nullptr;                           // the stream of a round's early commits (Prover::commit_early)
     ScalarField *pinned_ = nullptr;                                 // witness staging
     uint64_t pinned_cap_ = 0;
     std::vector<uint32_t> n_wires_;
@@ -149,6 +150,7 @@ class ProverContext {
         if (lib_) tkmk_r1cs_library_destroy(lib_);
         if (pinned_) tkmk_host_free(pinned_);
         if (binding_stream_) tkmk_stream_destroy(binding_stream_);
+        if (commit_stream_) tkmk_stream_destroy(commit_stream_);
     }
 
     static SetupParams read_setup_params(const std::string &dir) {
@@ -392,6 +394,10 @@ class ProverContext {
         // reads the (fourteen times larger) witness document
         std::unique_ptr<Prover> p(new Prover());
         p->sp = sp, p->m_i = m_i, p->sigma = sigma.get(), p->mixer = mixer, p->lagrange = lagrange_;
+        if (!link) {
+            if (!commit_stream_) check(tkmk_stream_create(&commit_stream_), "stream_create");
+            p->commit_stream = commit_stream_;
+        }
         MappedFile perm_file(synth_dir + "/permutation.json");
         PermutationColumns perm = parse_permutation_fast(perm_file.data(), perm_file.size(), threads);
         DeviceVec<uint32_t> d_dst, d_x, d_y;   // alive until the kernels reading them have run (synchronised before init returns)
