@@ -67,7 +67,7 @@ def test_ntt_randomized(gpu, oracle, curve):
     o = oracle if curve == "bls12_381" else oracle.bn254
     gpu.init_ntt_domain_for_size(1 << 20, curve=curve)
     rnd = random.Random(77 if curve == "bls12_381" else 78)
-    for it in range(24):
+    for it in range(16):
         logn = rnd.randrange(0, 15)
         n = 1 << logn
         batch = rnd.choice((1, 1, 2, 3, 5, 8, 17, 64))

@@ -3,7 +3,7 @@ every proof point, evaluation and challenge must match, and the combined verifie
 usage: python tools/prove_fuzz.py [CASES] [FIRST_SEED] [native] [mid] [sharded]      (test infrastructure: uses the oracle)
 With `native` the proof comes from tokamak-zk-evm_amd/bin/prove-testing over files (CRS written by Sigma.write, blinding through
 --testing-mixer); with `sharded` (implies native) the same files also go through the sharded resident prover over the loopback
-transport with 2, 3 or 4 virtual ranks (tkmk_prover_open_sharded), with and without the commit / Lagrange tables, and every rank's
+transport with 2, 4 or 8 virtual ranks (tkmk_prover_open_sharded), with and without the commit / Lagrange tables, and every rank's
 document must be the binary's byte for byte."""
 import json
 import os
@@ -66,17 +66,19 @@ for seed in range(first, first + cases):
         assert scalars == ref_scalars, (seed, shape)
         if sharded:
             from tkmk import dist, service
-            world = rnd.choice([2, 3, 4])
-            os.environ["TKMK_PROVER_TABLE_C"] = rnd.choice(["12", "0"])
-            comms = dist.loopback_comms(world)
-            provers = dist.run_ranks(comms, lambda c: service.Prover(inst["qap"], os.path.join(d, "crs"), testing=True, comm=c))
-            by_rank = {p.comm.rank: p for p in provers}
-            docs = dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(inst["synth"], None, testing_mixer_json=os.path.join(d, "mixer.json"))[0])
-            for p in provers:
-                p.close()
-            for c in comms:
-                c.close()
-            assert all(doc == native_doc for doc in docs), (seed, shape, world)
+            fits = [w for w in (2, 4, 8) if w <= min(sp["n"], sp["l_D"] - sp["l"], sp["s_max"])]   # a power of two, at most the rows / columns there are
+            if fits:
+                world = rnd.choice(fits)
+                os.environ["TKMK_PROVER_TABLE_C"] = rnd.choice(["12", "0"])
+                comms = dist.loopback_comms(world)
+                provers = dist.run_ranks(comms, lambda c: service.Prover(inst["qap"], os.path.join(d, "crs"), testing=True, comm=c))
+                by_rank = {p.comm.rank: p for p in provers}
+                docs = dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(inst["synth"], None, testing_mixer_json=os.path.join(d, "mixer.json"))[0])
+                for p in provers:
+                    p.close()
+                for c in comms:
+                    c.close()
+                assert all(doc == native_doc for doc in docs), (seed, shape, world)
     else:
         prover, binding = Prover.init(inst["qap"], inst["synth"], None, mixer=mixer, testing_mode=True, sigma=sigma.prover_view())
         points, scalars, challenges, p4t, _ = run_rounds(prover, binding)
