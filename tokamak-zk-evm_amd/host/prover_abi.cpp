@@ -114,7 +114,7 @@ TKP_API tkmk_error tkmk_prover_open_sharded(void *comm, const char *subcircuit_l
         std::string crs = crs_dir;
         std::unique_ptr<tkmk_prover> p(new tkmk_prover());
         p->ctx = ProverContext::open(
-            subcircuit_library_dir, crs, [&](const SetupParams &sp, std::string &source) { return load_prover_sigma(crs, sp, source, resident_table_c(sp), link.shard); }, link);
+            subcircuit_library_dir, crs, [&](const SetupParams &sp, std::string &source) { return load_prover_sigma(crs, sp, source, resident_table_c(sp, link.shard.world), link.shard); }, link);
         *out = p.release();
     });
 }

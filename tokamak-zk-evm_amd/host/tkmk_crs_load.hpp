@@ -54,14 +54,20 @@ inline std::unique_ptr<ProverSigma> load_prover_sigma(const std::string &crs_dir
     return std::unique_ptr<ProverSigma>(new ProverSigma(ProverSigma::from_payload(crs, sp, table_c, shard, whole_grid)));
 }
 // the resident prover's default: 20-bit windows once xy_powers is large enough for the wide sort to pay (>= 2^20 points);
-// TKMK_PROVER_TABLE_C = 0 turns the table off, 13..20 picks another width
-inline uint32_t resident_table_c(const SetupParams &sp) {
+// TKMK_PROVER_TABLE_C = 0 turns the table off, 13..20 picks another width.
+// world: the ranks of a sharded context.  A rank's share of a commit has 1 / world of the points but the whole bucket set, and what a
+// commit costs per bucket (fragment combine, bucket reduction) does not divide: measured over the loopback transport at configs[3]
+// (tools/one_proof_loopback.py, profiles/r04_one_proof_loopback_table_window_by_world.json) 20-bit windows stay best at 2 and 4 ranks
+// (141 against 153 ms and 96 against 97 ms of device work per rank) and 16-bit windows win at 8 (64.6 against 70.5 ms per rank: 2^15
+// buckets instead of 2^19 for shares of 2 x 10^6 points).
+inline uint32_t resident_table_c(const SetupParams &sp, uint32_t world = 1) {
     if (const char *e = std::getenv("TKMK_PROVER_TABLE_C")) {
         int v = std::atoi(e);
         return v >= 2 && v <= 20 ? (uint32_t)v : 0;
     }
     size_t m_i = sp.l_D - sp.l, points = std::max(2 * sp.n, 2 * m_i) * 2 * sp.s_max;
-    return points >= (1u << 20) ? 20u : 0u;
+    if (points < (1u << 20)) return 0u;
+    return world >= 8 ? 16u : 20u;
 }
 
 }  // namespace tkmk
