@@ -148,3 +148,34 @@ def test_one_ranks_failure_is_an_error_on_every_rank(gpu, oracle, world):
     finally:
         for c in comms:
             c.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_relayout_of_point_records(gpu, oracle, world):
+    """tkmk_dist_relayout_cols_to_rows / _rows_to_cols on 96-byte records (G1 affine points: what the group transforms behind the
+    Lagrange-basis tables move at a sharded open) and on 32-byte ones, against numpy slicing of the whole matrix; a record size that is
+    not a multiple of 16 is refused"""
+    from tkmk import dist
+    xs, ys = 16, 8
+    comms = dist.loopback_comms(world)
+    try:
+        for rec in (96, 32, 48):
+            m = np.random.default_rng(rec).integers(0, 256, (xs, ys, rec), dtype=np.uint8)
+            to_rows = dist.run_ranks(comms, lambda c: np.asarray(c.relayout_cols_to_rows(gpu.DeviceBuffer.from_host(np.ascontiguousarray(m[:, c.rank::world]).reshape(-1)),
+                                                                                         xs, ys, rec).to_host()))
+            h = xs // world
+            for r in range(world):
+                assert (to_rows[r].reshape(h, ys, rec) == m[r * h:(r + 1) * h]).all(), (rec, r)
+            back = dist.run_ranks(comms, lambda c: np.asarray(c.relayout_rows_to_cols(gpu.DeviceBuffer.from_host(np.ascontiguousarray(m[c.rank * h:(c.rank + 1) * h]).reshape(-1)),
+                                                                                      xs, ys, rec).to_host()))
+            for r in range(world):
+                assert (back[r].reshape(xs, ys // world, rec) == m[:, r::world]).all(), (rec, r)
+
+        def bad(c):
+            with pytest.raises(dist.DistError):
+                c.relayout_cols_to_rows(gpu.DeviceBuffer(40 * xs * ys // world), xs, ys, 40)
+            return True
+        assert dist.run_ranks(comms, bad) == [True] * world
+    finally:
+        for c in comms:
+            c.close()

@@ -116,3 +116,26 @@ def test_piecewise_constant_vector_commits_through_its_jumps(gpu, oracle):
     direct = gpu.projective_to_affine_bytes(gpu.msm(oracle.to_bytes(vals, 32), lam))
     through = gpu.projective_to_affine_bytes(gpu.msm(oracle.to_bytes(diffs, 32), pre))
     assert (direct == through).all()
+
+
+@pytest.mark.parametrize("xs,ys", [(8, 4), (16, 16)])
+def test_g1_ntt_one_axis_at_a_time(gpu, oracle, xs, ys):
+    """tkmk_g1_ntt_axes: the X pass alone is ys independent transforms along the columns, the Y pass alone xs along the rows (in the
+    exponent against the oracle's 1-D batches); one after the other, in either order, they are the bivariate transform — what a sharded
+    context runs over its own columns and its own rows with a change of layout in between"""
+    n = xs * ys
+    gpu.init_ntt_domain_for_size(1 << 12)
+    h, pts = _points(gpu, oracle, 900 + n, n)
+    G = np.tile(oracle.g1_generator(), n)
+    R = oracle.R_MOD
+    both = np.asarray(gpu.g1_ntt(pts, xs, ys, inverse=True).to_host())
+    y_only = gpu.g1_ntt(pts, xs, ys, inverse=True, axes=gpu.G1_NTT_AXIS_Y)
+    x_only = gpu.g1_ntt(pts, xs, ys, inverse=True, axes=gpu.G1_NTT_AXIS_X)
+    want_y = oracle.fr_scalar_mul(oracle.to_bytes([ys % R], 32), oracle.ntt(h, ys, batch=xs, inverse=True))                       # unscaled inverse
+    want_x = oracle.fr_scalar_mul(oracle.to_bytes([xs % R], 32), oracle.ntt(h, xs, batch=ys, columns_batch=True, inverse=True))
+    assert (np.asarray(y_only.to_host()) == np.asarray(oracle.g1_batch_scalar_mul(want_y, G))).all()
+    assert (np.asarray(x_only.to_host()) == np.asarray(oracle.g1_batch_scalar_mul(want_x, G))).all()
+    assert (np.asarray(gpu.g1_ntt(y_only, xs, ys, inverse=True, axes=gpu.G1_NTT_AXIS_X).to_host()) == both).all()
+    assert (np.asarray(gpu.g1_ntt(x_only, xs, ys, inverse=True, axes=gpu.G1_NTT_AXIS_Y).to_host()) == both).all()
+    with pytest.raises(gpu.TkmkError):
+        gpu.g1_ntt(pts, xs, ys, axes=4)

@@ -474,3 +474,41 @@ def test_mul_ones_x_equals_product_with_K0(P, gpu, oracle, xs, ys, m, rows):
     # truncation: fewer output rows than the product has
     short = gpu.poly_mul_ones_x(gpu.DeviceBuffer.from_host(p), xs, ys, m, inv_m, max(1, ox // 2)).to_host()
     assert (short == got[:short.size]).all()
+
+
+def test_expr_eval_on_row_slabs_equals_the_whole_domain(gpu, oracle):
+    """tkmk_poly_expr_eval_views_slab (the sharded prover's evaluator: every rank its ROWS slab): the rows [x_first, x_first + x_rows) of a
+    domain evaluated slab by slab — matrix leaves as slabs, an X-only leaf as the slab's piece of the column vector, a Y-only leaf and a Y
+    rotation as on the whole domain, (w_x^i - 1) with the GLOBAL row index — and put together equal tkmk_poly_expr_eval_views on the whole
+    domain.  A leaf rotated along X is rolled beforehand (what tkmk_dist_rows_rotate hands a rank)."""
+    xs, ys, rows = 32, 8, 8
+    n = xs * ys
+    gpu.init_ntt_domain_for_size(1 << 12)
+    la, lb = oracle.fr_random(250, n), oracle.fr_random(251, n)
+    vx, vy = oracle.fr_random(252, xs), oracle.fr_random(253, ys)
+    k = oracle.fr_random(254, 2)
+    LEAF, CONST, ADD, SUB, MUL, SCALE, XM1 = range(7)
+    A = np.asarray(la).reshape(xs, ys, 32)
+    a_rolled = np.ascontiguousarray(np.roll(A, 2, axis=0))                       # p(w^-2 X, .): rows rotated by 2 over the WHOLE domain
+    B = np.asarray(lb).reshape(xs, ys, 32)
+    X = np.asarray(vx).reshape(xs, 32)
+    dev = lambda a: gpu.DeviceBuffer.from_host(np.ascontiguousarray(a).reshape(-1))          # noqa: E731
+    whole_leaves = [(dev(A), xs, ys, 0, 0), (dev(a_rolled), xs, ys, 0, 3), (dev(B), xs, ys, 0, 0), (dev(X), xs, 1, 0, 0), (gpu.DeviceBuffer.from_host(vy), 1, ys, 0, 5)]
+    progs = [[(LEAF, 0), (LEAF, 1), (MUL, 0), (XM1, 0), (LEAF, 2), (SUB, 0)],                 # (X - 1)(a * a') - b
+             [(LEAF, 3), (LEAF, 4), (MUL, 0), (SCALE, 1), (LEAF, 2), (ADD, 0), (XM1, 0), (CONST, 0), (ADD, 0)],
+             [(LEAF, 1)]]
+    for prog in progs:
+        want = np.asarray(gpu.poly_expr_eval_views(prog, whole_leaves, k, 2, xs, ys).to_host()).reshape(xs, ys, 32)
+        got = []
+        for first in range(0, xs, rows):
+            sl = slice(first, first + rows)
+            leaves = [(dev(A[sl]), rows, ys, 0, 0), (dev(a_rolled[sl]), rows, ys, 0, 3), (dev(B[sl]), rows, ys, 0, 0), (dev(X[sl]), rows, 1, 0, 0),
+                      (gpu.DeviceBuffer.from_host(vy), 1, ys, 0, 5)]
+            got.append(np.asarray(gpu.poly_expr_eval_views_slab(prog, leaves, k, 2, xs, first, rows, ys).to_host()).reshape(rows, ys, 32))
+        assert (np.concatenate(got) == want).all(), prog
+    one = [(dev(A[:rows]), rows, ys, 0, 0)]
+    for bad in (dict(x_global=xs, x_first=4, x_rows=rows), dict(x_global=xs, x_first=xs, x_rows=rows), dict(x_global=24, x_first=0, x_rows=rows)):
+        with pytest.raises(gpu.TkmkError):
+            gpu.poly_expr_eval_views_slab([(LEAF, 0)], one, k, 2, bad["x_global"], bad["x_first"], bad["x_rows"], ys)
+    with pytest.raises(gpu.TkmkError):                                           # a rotation along X crosses slabs: refused here
+        gpu.poly_expr_eval_views_slab([(LEAF, 0)], [(dev(A[:rows]), rows, ys, 1, 0)], k, 2, xs, 0, rows, ys)

@@ -80,7 +80,7 @@ def test_gpu_parity_tiers_under_the_alternative_generator():
     # shape sweeps, the large padded-transform shapes and the root-free polynomial bookkeeping (find_degree, resize, lincomb).
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_ntt.py", "tests/test_gpu_poly.py",
                         "tests/test_gpu_prove.py::test_prove_equals_reference_restatement_and_verifies", "tests/test_gpu_service.py::test_service_equals_python_prover_and_restatement",
-                        "-k", "in_place or bintt_vs_oracle or row_then_column or coset or mul_vs_oracle or polyexpr or leaf_views or restatement",
+                        "-k", "bintt_vs_oracle or row_then_column or coset or mul_vs_oracle or polyexpr_fused or restatement",
                         "-p", "no:cacheprovider", "-o", "addopts="], capture_output=True, text=True, timeout=3000, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 

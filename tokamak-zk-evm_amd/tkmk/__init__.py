@@ -431,12 +431,20 @@ def msm(scalars, bases, msm_size=None, batch=1, shared_points=True, c=0, bitsize
     return out
 
 
-def g1_ntt(points, x_size, y_size, inverse=False, bases_form=0, in_stride=None, out=None):
+G1_NTT_AXIS_X, G1_NTT_AXIS_Y = 1, 2        # TKMK_G1_NTT_AXIS_* of include/tkmk.h
+
+
+def g1_ntt(points, x_size, y_size, inverse=False, bases_form=0, in_stride=None, out=None, axes=None):
     """bivariate NTT over G1 points (tkmk_g1_ntt): points = DeviceBuffer of affine records, rows of in_stride (default y_size);
-    returns a DeviceBuffer of x_size * y_size plain affine records; the inverse is not scaled by 1 / (x_size * y_size)"""
+    returns a DeviceBuffer of x_size * y_size plain affine records; the inverse is not scaled by 1 / (x_size * y_size).
+    axes (tkmk_g1_ntt_axes): G1_NTT_AXIS_Y alone transforms the rows, G1_NTT_AXIS_X alone the columns"""
     out = DeviceBuffer(96 * x_size * y_size) if out is None else out
-    _check(lib().tkmk_g1_ntt(_p(points), int(bases_form), ctypes.c_uint32(in_stride if in_stride is not None else y_size), ctypes.c_uint32(x_size),
-                             ctypes.c_uint32(y_size), int(1 if inverse else 0), _p(out), None), "tkmk_g1_ntt")
+    stride = ctypes.c_uint32(in_stride if in_stride is not None else y_size)
+    if axes is None:
+        _check(lib().tkmk_g1_ntt(_p(points), int(bases_form), stride, ctypes.c_uint32(x_size), ctypes.c_uint32(y_size), int(1 if inverse else 0), _p(out), None), "tkmk_g1_ntt")
+    else:
+        _check(lib().tkmk_g1_ntt_axes(_p(points), int(bases_form), stride, ctypes.c_uint32(x_size), ctypes.c_uint32(y_size), int(1 if inverse else 0), int(axes), _p(out),
+                                      None), "tkmk_g1_ntt_axes")
     return out
 
 
@@ -691,6 +699,18 @@ def poly_expr_eval_views(prog, leaves, consts, n_consts, x_size, y_size, out=Non
     _check(lib().tkmk_poly_expr_eval_views(arr, ctypes.c_uint32(len(prog)), lv, ctypes.c_uint32(len(leaves)), _p(consts),
                                            ctypes.c_uint32(n_consts), ctypes.c_uint32(x_size), ctypes.c_uint32(y_size), _p(out), None),
            "tkmk_poly_expr_eval_views")
+    return out
+
+
+def poly_expr_eval_views_slab(prog, leaves, consts, n_consts, x_global, x_first, x_rows, y_size, out=None):
+    """tkmk_poly_expr_eval_views_slab: the evaluator on the rows [x_first, x_first + x_rows) of a domain with x_global rows; leaves as
+    poly_expr_eval_views with x_len in {x_rows, 1} and rot_x = 0"""
+    arr = (ExprInstr * len(prog))(*[ExprInstr(int(o), int(a)) for o, a in prog])
+    lv = (ExprLeaf * max(1, len(leaves)))(*[ExprLeaf(b.ptr if not isinstance(b, int) else b, int(xl), int(yl), int(rx), int(ry)) for b, xl, yl, rx, ry in leaves])
+    out = DeviceBuffer(32 * x_rows * y_size) if out is None else out
+    _check(lib().tkmk_poly_expr_eval_views_slab(arr, ctypes.c_uint32(len(prog)), lv, ctypes.c_uint32(len(leaves)), _p(consts), ctypes.c_uint32(n_consts),
+                                                ctypes.c_uint32(x_global), ctypes.c_uint32(x_first), ctypes.c_uint32(x_rows), ctypes.c_uint32(y_size), _p(out), None),
+           "tkmk_poly_expr_eval_views_slab")
     return out
 
 

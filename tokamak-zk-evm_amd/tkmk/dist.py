@@ -137,6 +137,18 @@ class Comm:
                "tkmk_dist_inv_rows_to_cols")
         return out
 
+    def relayout_cols_to_rows(self, cols, x_size, y_size, record_bytes):
+        out = tkmk.DeviceBuffer(record_bytes * (x_size // self.world) * y_size)
+        _check(lib().tkmk_dist_relayout_cols_to_rows(self._h, tkmk._p(cols), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size), ctypes.c_size_t(record_bytes), tkmk._p(out)),
+               "tkmk_dist_relayout_cols_to_rows")
+        return out
+
+    def relayout_rows_to_cols(self, rows, x_size, y_size, record_bytes):
+        out = tkmk.DeviceBuffer(record_bytes * x_size * (y_size // self.world))
+        _check(lib().tkmk_dist_relayout_rows_to_cols(self._h, tkmk._p(rows), ctypes.c_size_t(x_size), ctypes.c_size_t(y_size), ctypes.c_size_t(record_bytes), tkmk._p(out)),
+               "tkmk_dist_relayout_rows_to_cols")
+        return out
+
     def rows_rotate(self, slab, h, y_size, rot):
         out = tkmk.DeviceBuffer(32 * h * y_size)
         _check(lib().tkmk_dist_rows_rotate(self._h, tkmk._p(slab), ctypes.c_size_t(h), ctypes.c_size_t(y_size), ctypes.c_size_t(rot), tkmk._p(out)),
