@@ -389,9 +389,17 @@ class ProverContext {
         using namespace prover_detail;
         const double t0 = Prover::now();
         const size_t n = sp.n, s_max = sp.s_max, K = infos.size();
+        host_trace("init: begin");
 
-        // ---- the three per-proof documents.  permutation.json first: its two polynomials are built on the device while the host
-        // reads the (fourteen times larger) witness document
+        // ---- the three per-proof documents.  permutation.json first (every host thread, ~1 ms); then the (fourteen times larger) witness
+        // document is read on a helper — with every host thread again — while this one, mostly waiting on the device, builds the
+        // permutation's two polynomials; the two meet before the witness upload.
+        // Sharded: every rank reads the whole document's structure and every placement's kind, but converts (and thereby checks) only the
+        // values of its own placements — so an input error may show on one rank only.  The ranks therefore AGREE on the outcome of this
+        // phase before any of them goes on: a malformed document is then the same error on every rank, at the same point.
+        const Shard sh = link ? link.shard : Shard{};
+        WitnessLayout W;
+        std::vector<ScalarField> a_pub_user, a_pub_block;
         std::unique_ptr<Prover> p(new Prover());
         p->sp = sp, p->m_i = m_i, p->sigma = sigma.get(), p->mixer = mixer, p->lagrange = lagrange_;
         if (!link) {
@@ -400,6 +408,29 @@ class ProverContext {
         }
         MappedFile perm_file(synth_dir + "/permutation.json");
         PermutationColumns perm = parse_permutation_fast(perm_file.data(), perm_file.size(), threads);
+        host_trace("init: permutation.json parsed (%zu entries)", perm.size());
+        // (the helper signals as soon as the values are staged; unmapping the 88 MB document — milliseconds of page-table work — happens
+        // after the signal, beside the upload)
+        std::promise<void> witness_staged;
+        std::future<void> witness_read = witness_staged.get_future();
+        struct Joined {
+            std::thread t;
+            ~Joined() { if (t.joinable()) t.join(); }
+        } witness_reader{std::thread([&] {
+            std::unique_ptr<MappedFile> pv_file;
+            try {
+                pv_file.reset(new MappedFile(synth_dir + "/placementVariables.json"));
+                W = parse_placement_variables_fast(pv_file->data(), pv_file->size(), n_wires_, [&](uint64_t total) { return staging(total); }, threads, sh.world, sh.rank);
+                host_trace("init: placementVariables.json parsed (%zu placements, %llu values kept)", W.id.size(), (unsigned long long)W.total);
+                if (W.id.size() > s_max) throw Error("placement_variables length exceeds s_max.");
+                const json::Value jinst = json::read_file(synth_dir + "/instance.json");
+                a_pub_user = hex_list(jinst.at("a_pub_user"));
+                a_pub_block = hex_list(jinst.at("a_pub_block"));
+                witness_staged.set_value();
+            } catch (...) {
+                witness_staged.set_exception(std::current_exception());
+            }
+        })};
         DeviceVec<uint32_t> d_dst, d_x, d_y;   // alive until the kernels reading them have run (synchronised before init returns)
         {
             // Permutation::to_poly's redirects: distinct destinations (the reference's serial loop lets the last entry win)
@@ -429,7 +460,6 @@ class ProverContext {
             }
             // Permutation::to_poly (libs/src/iotools/mod.rs:419-455).  Sharded: this rank redirects the cells of its own columns
             // (col = rank mod G; local cell row * lc + col / G); the sources X, Y stay global indices into the two power tables
-            const Shard sh = link ? link.shard : Shard{};
             const size_t lc = sh.cols_of(s_max);
             if (sh.world > 1) {
                 std::vector<uint32_t> d2, x2, y2;
@@ -450,20 +480,11 @@ class ProverContext {
             p->s0_ev = std::move(e0), p->s1_ev = std::move(e1);   // prove1 forms f and g on the grid from these
             p->s0_identity = &s0_identity_, p->s1_identity = &s1_identity_;
         }
-        // Sharded: every rank reads the whole document's structure and every placement's kind, but converts (and thereby checks) only the
-        // values of its own placements — so an input error may show on one rank only.  The ranks therefore AGREE on the outcome of this
-        // phase before any of them goes on: a malformed document is then the same error on every rank, at the same point.
-        const Shard sh = link ? link.shard : Shard{};
-        WitnessLayout W;
-        std::vector<ScalarField> a_pub_user, a_pub_block;
+        host_trace("init: s0 / s1 issued");
         std::string input_error;
         try {
-            MappedFile pv_file(synth_dir + "/placementVariables.json");
-            W = parse_placement_variables_fast(pv_file.data(), pv_file.size(), n_wires_, [&](uint64_t total) { return staging(total); }, threads, sh.world, sh.rank);
-            if (W.id.size() > s_max) throw Error("placement_variables length exceeds s_max.");
-            const json::Value jinst = json::read_file(synth_dir + "/instance.json");
-            a_pub_user = hex_list(jinst.at("a_pub_user"));
-            a_pub_block = hex_list(jinst.at("a_pub_block"));
+            witness_read.get();
+            host_trace("init: witness documents joined");
         } catch (const std::exception &e) {
             if (sh.world == 1) throw;
             input_error = e.what();
