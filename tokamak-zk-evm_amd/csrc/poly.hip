@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_place(const fr_t *__restrict__ src, uin
 // The reference's poly_comb! (prove/src/lib.rs:30-38) and the operator chains around it (&a * &s, &a + &b, mul_monomial:
 // libs/src/bivariate_polynomial/mod.rs:532-1281, 1820-1844) cost one full pass and one temporary of the OUTPUT size per operator;
 // a 6-term combination is ~35 passes over 2^22..2^25 elements.  Here it is one pass.
-#define LC_MAX_TERMS 16
+#define LC_MAX_TERMS 24
 struct lincomb_args_t {
     const fr_t *p[LC_MAX_TERMS];
     fr_t c[LC_MAX_TERMS];                     // Montgomery form (plain * Montgomery -> plain)

@@ -502,6 +502,7 @@ class DensePolynomialExt {
         std::vector<const tkmk_fr *> ptr;
         std::vector<uint32_t> xs, ys, ox, oy;
         std::vector<DeviceVec<ScalarField>> temps;   // local column sets of replicated operands, columns received from the neighbour for Y shifts
+        std::vector<std::tuple<const DensePolynomialExt *, uint32_t, const tkmk_fr *>> fetched;
         for (const Term &t : terms) {
             const DensePolynomialExt &p = *t.p;
             if (t.ox >= nx) continue;                                        // wholly beyond the bound: a zero polynomial
@@ -533,14 +534,26 @@ class DensePolynomialExt {
             // rank, fetched once (ring shift), then an ordinary local column offset
             if (p.y_size % G) throw Error("lincomb: a Y shift needs at least one column per rank");
             const uint32_t sft = t.oy % G;
-            temps.emplace_back(p.x_size * lc);
-            check(dc.ring_shift(dc.comm, p.poly.ptr(), p.x_size * lc * sizeof(ScalarField), (int)sft, temps.back().ptr()), "tkmk_comm_ring_shift");
-            c.push_back(t.c), ptr.push_back(temps.back().ptr()), xs.push_back(rows_in), ys.push_back((uint32_t)lc), ox.push_back(t.ox);
+            const tkmk_fr *shifted = nullptr;   // the same operand under the same rotation again (X^a Y p and X^b Y p): one exchange serves both
+            for (const auto &f : fetched)
+                if (std::get<0>(f) == &p && std::get<1>(f) == sft) shifted = std::get<2>(f);
+            if (!shifted) {
+                temps.emplace_back(p.x_size * lc);
+                check(dc.ring_shift(dc.comm, p.poly.ptr(), p.x_size * lc * sizeof(ScalarField), (int)sft, temps.back().ptr()), "tkmk_comm_ring_shift");
+                shifted = temps.back().ptr();
+                fetched.emplace_back(&p, sft, shifted);
+            }
+            c.push_back(t.c), ptr.push_back(shifted), xs.push_back(rows_in), ys.push_back((uint32_t)lc), ox.push_back(t.ox);
             oy.push_back(t.oy / G + (r < sft ? 1u : 0u));
         }
         const size_t out_l = local_cols(ny, out_rep);
         DeviceVec<ScalarField> out(nx * out_l);
         if (out_l) {
+            if (host_trace_on()) {
+                size_t in_elems = 0;
+                for (size_t t = 0; t < ptr.size(); t++) in_elems += (size_t)xs[t] * ys[t];
+                host_trace("lincomb %zu terms -> %zu x %zu (operands %.1f MB, output %.1f MB)", ptr.size(), nx, out_l, in_elems * 32e-6, nx * out_l * 32e-6);
+            }
             if (ptr.empty()) check(tkmk_memset(out.ptr(), 0, nx * out_l * sizeof(ScalarField)), "lincomb");
             else
                 check(tkmk_poly_lincomb((uint32_t)ptr.size(), c.data(), ptr.data(), xs.data(), ys.data(), ox.data(), oy.data(), out.ptr(), (uint32_t)nx, (uint32_t)out_l,

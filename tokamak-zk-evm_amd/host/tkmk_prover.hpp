@@ -197,6 +197,45 @@ using Term = Poly::Term;   // {coefficient, polynomial, X shift, Y shift}
 
 // poly_comb! (lib.rs:30-38): sum of c_i * p_i — one fused pass over the operands (tkmk_poly_lincomb)
 inline Poly poly_comb(std::initializer_list<Term> terms) { return Poly::lincomb(std::vector<Term>(terms)); }
+// A linear combination kept symbolic until its matrix is needed.  Sums, scalar multiples and monomial shifts of combinations are
+// combinations of the same operands: a chain of poly_comb! / `&a * &s` / `&a + &b` / mul_monomial steps, each of which the reference
+// (and a step-by-step transcription) materialises as a matrix of the output's size, becomes ONE pass over the base operands with the
+// coefficients multiplied out on the host.  Field arithmetic is exact, so the coefficients of the result are the same numbers.
+struct Lin {
+    std::vector<Term> t;
+    Lin() {}
+    Lin &add(const ScalarField &c, const Poly &p, uint32_t ox = 0, uint32_t oy = 0) {
+        t.emplace_back(c, &p, ox, oy);
+        return *this;
+    }
+    Lin &add(const ScalarField &c, const Lin &o, uint32_t ox = 0, uint32_t oy = 0) {
+        for (const Term &x : o.t) t.emplace_back(fr_mul(c, x.c), x.p, x.ox + ox, x.oy + oy);
+        return *this;
+    }
+    Lin &add(const std::vector<Term> &terms) {
+        t.insert(t.end(), terms.begin(), terms.end());
+        return *this;
+    }
+    // equal (operand, shift) pairs merged, zero coefficients dropped; large operands first (a combination of more terms than one launch
+    // takes is folded in groups: the small ones then share the last group)
+    std::vector<Term> merged() const {
+        std::vector<Term> m;
+        for (const Term &x : t) {
+            bool found = false;
+            for (Term &y : m)
+                if (y.p == x.p && y.ox == x.ox && y.oy == x.oy) {
+                    y.c = fr_add(y.c, x.c), found = true;
+                    break;
+                }
+            if (!found) m.push_back(x);
+        }
+        m.erase(std::remove_if(m.begin(), m.end(), [](const Term &x) { return fr_is_zero(x.c); }), m.end());
+        std::stable_sort(m.begin(), m.end(), [](const Term &a, const Term &b) { return a.p->x_size * a.p->y_size > b.p->x_size * b.p->y_size; });
+        return m;
+    }
+    Poly materialize() const { return Poly::lincomb(merged()); }
+};
+inline Poly constant_poly(const ScalarField &c) { return Poly::from_coeffs(std::vector<ScalarField>{c}, 1, 1); }
 inline Poly sparse(const std::vector<std::pair<size_t, ScalarField>> &entries, size_t xs, size_t ys) {
     std::vector<ScalarField> c(xs * ys);
     for (auto &e : entries) c.at(e.first) = e.second;
@@ -276,6 +315,9 @@ class Prover {
     Poly bXY, uXY, vXY, wXY, rXY, a_free_X, t_n, t_mi, t_smax, s0XY, s1XY;
     Poly q0XY, q1XY, q2XY, q3XY;
     std::unique_ptr<Poly> w_zk, term_b_zk;   // ProverCache (lib.rs:297-301)
+    // the same two polynomials as their X-only and Y-only summands (a column and a row): what prove4's fused combinations read instead
+    // of the 2 m_I x 2 s_max matrix of zeros their sum is stored as
+    std::unique_ptr<Poly> w_zk_x, w_zk_y, b_zk_x, b_zk_y;
     // the Lagrange polynomials of prove2 / prove4 (lib.rs:2018-2100) depend on the setup parameters only: a resident context
     // builds them once and shares them; a stand-alone Prover builds them on first use
     struct LagrangePolys {
@@ -634,16 +676,24 @@ class Prover {
         return Proof2{c[0], c[1]};
     }
 
-    // prove3 (lib.rs:2272-2354)
+    // prove3 (lib.rs:2272-2354): V(chi, zeta), R(chi, zeta), R(chi / w_x, zeta), R(chi / w_x, zeta / w_y) with V = v + rV_X t_n + rV_Y t_smax
+    // and R = r + rR_X t_mI + rR_Y t_smax.  The reference forms V, R, R(w_x^-1 X, Y) and R(w_x^-1 X, w_y^-1 Y) as coefficient matrices
+    // (2 m_I x 2 s_max each) and evaluates those; a coefficient scaling followed by an evaluation is the evaluation at the scaled point, and
+    // the blinding terms are two-coefficient polynomials — so four evaluations of the m_I x s_max matrices v and r plus closed forms give
+    // the same four field elements.
     Proof3 prove3(const ScalarField &chi, const ScalarField &zeta) const {
-        ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(sp.s_max));
+        const ScalarField one = fr_one();
+        const ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(sp.s_max));
+        const ScalarField chi_w = fr_mul(chi, w_inv_x), zeta_w = fr_mul(zeta, w_inv_y);
+        auto vanish = [&](const ScalarField &at, size_t size) { return fr_sub(fr_pow(at, size), one); };
+        auto R_at = [&](const ScalarField &x, const ScalarField &y) {
+            return fr_add(rXY.eval(x, y), fr_add(fr_mul(mixer.rR_X, vanish(x, m_i)), fr_mul(mixer.rR_Y, vanish(y, sp.s_max))));
+        };
         Proof3 out;
-        out.V_eval = blinded_V().eval(chi, zeta);
-        Poly RXY = blinded_R();
-        out.R_eval = RXY.eval(chi, zeta);
-        Poly R_omegaX = RXY.scale_coeffs(&w_inv_x, nullptr);
-        out.R_omegaX_eval = R_omegaX.eval(chi, zeta);
-        out.R_omegaX_omegaY_eval = R_omegaX.scale_coeffs(nullptr, &w_inv_y).eval(chi, zeta);
+        out.V_eval = fr_add(vXY.eval(chi, zeta), fr_add(fr_mul(mixer.rV_X, vanish(chi, sp.n)), fr_mul(mixer.rV_Y, vanish(zeta, sp.s_max))));
+        out.R_eval = R_at(chi, zeta);
+        out.R_omegaX_eval = R_at(chi_w, zeta);
+        out.R_omegaX_omegaY_eval = R_at(chi_w, zeta_w);
         return out;
     }
 
@@ -661,74 +711,79 @@ class Prover {
         // M, N: openings of R at (chi / w_x, zeta) and (chi / w_x, zeta / w_y) (lib.rs:2534-2701).  First in this round (the reference has
         // them after Pi_A; they depend on R and the round-3 openings only): their commitments can then run under everything that follows.
         ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(s_max));
-        Poly RXY = blinded_R();
-        auto M = sub_const(RXY, proof3.R_omegaX_eval).div_by_ruffini(fr_mul(w_inv_x, chi), zeta);
-        auto N = sub_const(RXY, proof3.R_omegaX_omegaY_eval).div_by_ruffini(fr_mul(w_inv_x, chi), fr_mul(w_inv_y, zeta));
+        const ScalarField chi_w = fr_mul(w_inv_x, chi), zeta_w = fr_mul(w_inv_y, zeta);
+        // R = r + rR_X t_mI + rR_Y t_smax and V = v + rV_X t_n + rV_Y t_smax enter this round only inside sums: they stay symbolic (Lin) and
+        // are never stored as the 2 m_I x 2 s_max matrices their blinding terms would make of them
+        Lin R_lin, V_lin;
+        R_lin.add(one, rXY).add(mx.rR_X, t_mi).add(mx.rR_Y, t_smax);
+        V_lin.add(one, vXY).add(mx.rV_X, t_n).add(mx.rV_Y, t_smax);
+        auto minus_constant = [&](const Lin &p, const Poly &minus_c) {   // p - c as one pass (minus_c: the 1 x 1 polynomial -c)
+            Lin d = p;
+            return d.add(one, minus_c).materialize();
+        };
+        const Poly m_R_wx = constant_poly(fr_neg(proof3.R_omegaX_eval)), m_R_wxy = constant_poly(fr_neg(proof3.R_omegaX_omegaY_eval));
+        const Poly m_R = constant_poly(fr_neg(proof3.R_eval)), m_V = constant_poly(fr_neg(proof3.V_eval));
+        auto M = minus_constant(R_lin, m_R_wx).div_by_ruffini(chi_w, zeta);
+        auto N = minus_constant(R_lin, m_R_wxy).div_by_ruffini(chi_w, zeta_w);
         std::future<std::vector<G1Affine>> early;   // declared after M and N: it ends (and is waited for) before the polynomials its jobs read
         if (!test_parts && can_commit_early())
             early = commit_early({sigma->sigma1.job(std::get<0>(M), "M_X"), sigma->sigma1.job(std::get<1>(M), "M_Y"), sigma->sigma1.job(std::get<1>(N), "N_Y")});
 
-        // Pi_A: arithmetic constraints + the opening of V (lib.rs:2383-2532)
-        ScalarField t_n_eval = t_n.eval(chi, one), t_smax_eval = t_smax.eval(one, zeta), small_v_eval = ev(vXY);
+        // Pi_A: arithmetic constraints + the opening of V (lib.rs:2383-2532); t_n(chi) = chi^n - 1, t_smax(zeta) = zeta^s_max - 1
+        const ScalarField t_n_eval = fr_sub(fr_pow(chi, n), one), t_smax_eval = fr_sub(fr_pow(zeta, s_max), one), small_v_eval = ev(vXY);
         Poly rW_X = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_X.begin(), mx.rW_X.end()), 4, 1);
         Poly rW_Y = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_Y.begin(), mx.rW_Y.end()), 1, 4);
-        if (!w_zk) w_zk.reset(new Poly(low_degree_times_vanishing(mx.rW_X, n, true) + low_degree_times_vanishing(mx.rW_Y, s_max, false)));
-        Poly V_minus = blinded_V();
-        add_const_in_place(V_minus, fr_neg(proof3.V_eval));
-        Poly pA_XY = poly_comb({{kappa1, &V_minus},
-                                {small_v_eval, &uXY},
-                                {minus_one, &wXY},
-                                {fr_neg(t_n_eval), &q0XY},
-                                {fr_neg(t_smax_eval), &q1XY},
-                                {fr_mul(small_v_eval, mx.rU_X), &t_n},
-                                {fr_mul(small_v_eval, mx.rU_Y), &t_smax},
-                                {fr_neg(fr_add(fr_mul(mx.rU_X, t_n_eval), fr_mul(mx.rU_Y, t_smax_eval))), &vXY},
-                                {t_n_eval, &rW_X},
-                                {t_smax_eval, &rW_Y},
-                                {minus_one, w_zk.get()}});
-        auto piA = pA_XY.div_by_ruffini(chi, zeta);
+        if (!w_zk_x) {
+            w_zk_x.reset(new Poly(low_degree_times_vanishing(mx.rW_X, n, true)));
+            w_zk_y.reset(new Poly(low_degree_times_vanishing(mx.rW_Y, s_max, false)));
+        }
+        Lin pA;   // lib.rs:2440-2500, one pass over u, v, w, q0, q1 and a handful of rows and columns
+        pA.add(kappa1, V_lin).add(kappa1, m_V)
+            .add(small_v_eval, uXY).add(minus_one, wXY).add(fr_neg(t_n_eval), q0XY).add(fr_neg(t_smax_eval), q1XY)
+            .add(fr_mul(small_v_eval, mx.rU_X), t_n).add(fr_mul(small_v_eval, mx.rU_Y), t_smax)
+            .add(fr_neg(fr_add(fr_mul(mx.rU_X, t_n_eval), fr_mul(mx.rU_Y, t_smax_eval))), vXY)
+            .add(t_n_eval, rW_X).add(t_smax_eval, rW_Y).add(minus_one, *w_zk_x).add(minus_one, *w_zk_y);
+        auto piA = pA.materialize().div_by_ruffini(chi, zeta);
 
-        // Pi_C: copy constraints (lib.rs:2703-3130)
+        // Pi_C: copy constraints (lib.rs:2703-3130).  The reference builds pC, term5, term6, term10, the two mul_by_term9 products, LHS_zk1,
+        // LHS_zk2, R - R(chi, zeta) and their weighted sum as ten matrices; only K0 * (...) needs its operand as a matrix (a product with a
+        // polynomial, not a shift), everything else is one combination of g, f, q2, q3, KL, r_D1, r and a few rows and columns.
         Poly r_omegaX = rXY.scale_coeffs(&w_inv_x, nullptr);
         Poly r_omegaX_omegaY = r_omegaX.scale_coeffs(nullptr, &w_inv_y);
         auto f_g = fg(thetas);
         const Poly &fXY = f_g.first, &gXY = f_g.second;
-        ScalarField t_mi_eval = fr_sub(fr_pow(chi, m_i), one), t_s_max_eval = fr_sub(fr_pow(zeta, s_max), one);
+        ScalarField t_mi_eval = fr_sub(fr_pow(chi, m_i), one), t_s_max_eval = t_smax_eval;
         const LagrangePolys &lg = lagrange_polys();
         const Poly &K0 = lg.K0;
-        ScalarField K0_eval = ev(K0), small_r = ev(rXY), small_r_wx = ev(r_omegaX), small_r_wxy = ev(r_omegaX_omegaY);
-        Poly term5 = poly_comb({{small_r, &gXY}, {fr_neg(small_r_wx), &fXY}});
-        Poly term6 = poly_comb({{small_r, &gXY}, {fr_neg(small_r_wxy), &fXY}});
-        ScalarField chi_m1 = fr_sub(chi, one), kappa0_sq = fr_mul(kappa0, kappa0);
-        Poly pC_XY = poly_comb({{fr_sub(small_r, one), &lg.KL},
-                                {fr_mul(kappa0, chi_m1), &term5},
-                                {fr_mul(kappa0_sq, K0_eval), &term6},
-                                {fr_neg(t_mi_eval), &q2XY},
-                                {fr_neg(t_s_max_eval), &q3XY}});
+        // r(w_x^-1 X, Y) at (chi, zeta) is r at (chi / w_x, zeta): the evaluations need no scaled copy
+        const ScalarField K0_eval = ev(K0), small_r = ev(rXY), small_r_wx = rXY.eval(chi_w, zeta), small_r_wxy = rXY.eval(chi_w, zeta_w);
+        const ScalarField chi_m1 = fr_sub(chi, one), kappa0_sq = fr_mul(kappa0, kappa0);
+        // r_D1 = r - r(w_x^-1 X, Y), r_D2 = r - r(w_x^-1 X, w_y^-1 Y) stay matrices (m_I x s_max): each is read under three shifts, and a
+        // Y shift of a matrix is one ring exchange of it in the sharded prover — of one operand rather than of two
         Poly r_D1 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX}}), r_D2 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX_omegaY}});
-        ScalarField r_D1_eval = ev(r_D1), r_D2_eval = ev(r_D2);
-        if (!term_b_zk) term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
-        // term10 = (rR_X t_mi(chi) + rR_Y t_smax(zeta)) * (g - f)
-        ScalarField c10 = fr_add(fr_mul(mx.rR_X, t_mi_eval), fr_mul(mx.rR_Y, t_s_max_eval));
-        Poly term10 = poly_comb({{c10, &gXY}, {fr_neg(c10), &fXY}});
-        auto with_term10 = [&](const Poly &r_D) {   // mul_by_term9(r_D) + term10 (lib.rs:96-124), one pass
-            std::vector<Term> t = term9(r_D, mx.rB_X, mx.rB_Y, t_mi_eval, t_s_max_eval);
-            t.emplace_back(one, &term10);
-            return Poly::lincomb(t);
-        };
-        Poly r_d1_t = with_term10(r_D1);
-        // (1 - X) * r_d1_t enters LHS_zk1 as two shifted terms
-        Poly LHS_zk1 = Poly::lincomb({Term(fr_mul(chi_m1, r_D1_eval), term_b_zk.get()), Term(one, &r_d1_t), Term(minus_one, &r_d1_t, 1, 0), Term(chi_m1, &term10)});
-        Poly r_d2_t = with_term10(r_D2);
+        const ScalarField r_D1_eval = fr_sub(small_r, small_r_wx), r_D2_eval = fr_sub(small_r, small_r_wxy);   // evaluation is linear
+        if (!b_zk_x) {
+            b_zk_x.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true)));
+            b_zk_y.reset(new Poly(low_degree_times_vanishing(mx.rB_Y, s_max, false)));
+        }
+        const ScalarField c10 = fr_add(fr_mul(mx.rR_X, t_mi_eval), fr_mul(mx.rR_Y, t_s_max_eval));
+        Lin term5, term6, term10, b_zk, pC, r_d1_t, r_d2_lin, LHS_zk1, LHS_zk2, LHS_for_copy;
+        term5.add(small_r, gXY).add(fr_neg(small_r_wx), fXY);
+        term6.add(small_r, gXY).add(fr_neg(small_r_wxy), fXY);
+        term10.add(c10, gXY).add(fr_neg(c10), fXY);   // (rR_X t_mI(chi) + rR_Y t_smax(zeta)) * (g - f)
+        b_zk.add(one, *b_zk_x).add(one, *b_zk_y);
+        pC.add(fr_sub(small_r, one), lg.KL).add(fr_mul(kappa0, chi_m1), term5).add(fr_mul(kappa0_sq, K0_eval), term6)
+            .add(fr_neg(t_mi_eval), q2XY).add(fr_neg(t_s_max_eval), q3XY);
+        r_d1_t.add(term9(r_D1, mx.rB_X, mx.rB_Y, t_mi_eval, t_s_max_eval)).add(one, term10);   // mul_by_term9(r_D1) + term10 (lib.rs:96-124)
+        LHS_zk1.add(fr_mul(chi_m1, r_D1_eval), b_zk).add(one, r_d1_t).add(minus_one, r_d1_t, 1, 0).add(chi_m1, term10);   // (1 - X) r_d1_t: two shifts
+        r_d2_lin.add(term9(r_D2, mx.rB_X, mx.rB_Y, t_mi_eval, t_s_max_eval)).add(one, term10);
+        Poly r_d2_t = r_d2_lin.materialize();
         Poly k0_r_d2_t = r_d2_t.mul_ones_x(m_i, fr_inv(fr_from_u32((uint32_t)m_i)));   // K0 * r_d2_t
-        Poly LHS_zk2 = poly_comb({{fr_mul(K0_eval, r_D2_eval), term_b_zk.get()}, {K0_eval, &term10}, {minus_one, &k0_r_d2_t}});
-        Poly R_minus_eval = sub_const(RXY, proof3.R_eval);
-        ScalarField k1_2 = fr_mul(kappa1, kappa1);
-        Poly LHS_for_copy = poly_comb({{k1_2, &pC_XY},
-                                       {fr_mul(k1_2, kappa0), &LHS_zk1},
-                                       {fr_mul(fr_mul(k1_2, kappa0), kappa0), &LHS_zk2},
-                                       {fr_mul(k1_2, kappa1), &R_minus_eval}});
-        auto piC = LHS_for_copy.div_by_ruffini(chi, zeta);
+        LHS_zk2.add(fr_mul(K0_eval, r_D2_eval), b_zk).add(K0_eval, term10).add(minus_one, k0_r_d2_t);
+        const ScalarField k1_2 = fr_mul(kappa1, kappa1);
+        LHS_for_copy.add(k1_2, pC).add(fr_mul(k1_2, kappa0), LHS_zk1).add(fr_mul(fr_mul(k1_2, kappa0), kappa0), LHS_zk2)
+            .add(fr_mul(k1_2, kappa1), R_lin).add(fr_mul(k1_2, kappa1), m_R);
+        auto piC = LHS_for_copy.materialize().div_by_ruffini(chi, zeta);
 
         // Pi_B: opening of a_free (lib.rs:3137-3181)
         ScalarField A_eval = ev(a_free_X);
