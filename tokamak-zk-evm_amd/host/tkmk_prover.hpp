@@ -437,6 +437,32 @@ class Prover {
         add_const_in_place(g, th[2]);
         return {std::move(f), std::move(g)};
     }
+    // what prove2 and prove4 both need of r, f and g (lib.rs:1975-1990 and 2703-2725 recompute them): f, g, r(w_x^-1 X, Y),
+    // r(w_x^-1 X, w_y^-1 Y) and the two differences r_D1, r_D2 — six m_I x s_max matrices, built once per (r, thetas)
+    struct CopyOperands {
+        std::vector<ScalarField> thetas;
+        const void *r_data = nullptr;
+        Poly f, g, r_omegaX, r_omegaX_omegaY, r_D1, r_D2;
+    };
+    std::unique_ptr<CopyOperands> copy_operands_;
+    const CopyOperands &copy_operands(const std::vector<ScalarField> &thetas) {
+        using namespace prover_detail;
+        if (copy_operands_ && copy_operands_->r_data == (const void *)rXY.poly.ptr() && copy_operands_->thetas.size() == thetas.size() &&
+            std::memcmp(copy_operands_->thetas.data(), thetas.data(), thetas.size() * sizeof(ScalarField)) == 0)
+            return *copy_operands_;
+        std::unique_ptr<CopyOperands> c(new CopyOperands());
+        c->thetas = thetas, c->r_data = (const void *)rXY.poly.ptr();
+        const ScalarField one = fr_one(), minus_one = fr_neg(one);
+        const ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(sp.s_max));
+        auto f_g = fg(thetas);
+        c->f = std::move(f_g.first), c->g = std::move(f_g.second);
+        c->r_omegaX = rXY.scale_coeffs(&w_inv_x, nullptr);
+        c->r_omegaX_omegaY = c->r_omegaX.scale_coeffs(nullptr, &w_inv_y);
+        c->r_D1 = poly_comb({{one, &rXY}, {minus_one, &c->r_omegaX}});
+        c->r_D2 = poly_comb({{one, &rXY}, {minus_one, &c->r_omegaX_omegaY}});
+        copy_operands_ = std::move(c);
+        return *copy_operands_;
+    }
     Poly blinded_R() const {
         using namespace prover_detail;
         return poly_comb({{fr_one(), &rXY}, {mixer.rR_X, &t_mi}, {mixer.rR_Y, &t_smax}});
@@ -626,11 +652,8 @@ class Prover {
         const Mixer &mx = mixer;
         size_t s_max = sp.s_max;
         ScalarField kappa0_sq = fr_mul(kappa0, kappa0), one = fr_one(), inv_m_i = fr_inv(fr_from_u32((uint32_t)m_i));
-        ScalarField w_inv_x = fr_inv(root_of_unity(m_i)), w_inv_y = fr_inv(root_of_unity(s_max));
-        Poly r_omegaX = rXY.scale_coeffs(&w_inv_x, nullptr);
-        Poly r_omegaX_omegaY = r_omegaX.scale_coeffs(nullptr, &w_inv_y);
-        auto f_g = fg(thetas);
-        const Poly &fXY = f_g.first, &gXY = f_g.second;
+        const CopyOperands &co = copy_operands(thetas);   // kept for prove4
+        const Poly &fXY = co.f, &gXY = co.g;
         const LagrangePolys &lg = lagrange_polys();
         const Poly &K_last = lg.K_last, &L_last = lg.L_last, &KL = lg.KL, &K0 = lg.K0;
 
@@ -657,7 +680,7 @@ class Prover {
         auto q23 = p_comb.div_by_vanishing_opt((int64_t)m_i, (int64_t)s_max);
         q2XY = std::move(q23.first), q3XY = std::move(q23.second);
         ScalarField minus_one = fr_neg(one);
-        Poly r_D1 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX}}), r_D2 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX_omegaY}});
+        const Poly &r_D1 = co.r_D1, &r_D2 = co.r_D2;
         Poly g_D = poly_comb({{one, &gXY}, {minus_one, &fXY}});
 
         auto q_c = [&](const Poly &quot, const std::array<ScalarField, 2> &rB, const ScalarField &rR, bool x_axis) {
@@ -748,10 +771,8 @@ class Prover {
         // Pi_C: copy constraints (lib.rs:2703-3130).  The reference builds pC, term5, term6, term10, the two mul_by_term9 products, LHS_zk1,
         // LHS_zk2, R - R(chi, zeta) and their weighted sum as ten matrices; only K0 * (...) needs its operand as a matrix (a product with a
         // polynomial, not a shift), everything else is one combination of g, f, q2, q3, KL, r_D1, r and a few rows and columns.
-        Poly r_omegaX = rXY.scale_coeffs(&w_inv_x, nullptr);
-        Poly r_omegaX_omegaY = r_omegaX.scale_coeffs(nullptr, &w_inv_y);
-        auto f_g = fg(thetas);
-        const Poly &fXY = f_g.first, &gXY = f_g.second;
+        const CopyOperands &co = copy_operands(thetas);   // prove2 left them
+        const Poly &fXY = co.f, &gXY = co.g;
         ScalarField t_mi_eval = fr_sub(fr_pow(chi, m_i), one), t_s_max_eval = t_smax_eval;
         const LagrangePolys &lg = lagrange_polys();
         const Poly &K0 = lg.K0;
@@ -760,7 +781,7 @@ class Prover {
         const ScalarField chi_m1 = fr_sub(chi, one), kappa0_sq = fr_mul(kappa0, kappa0);
         // r_D1 = r - r(w_x^-1 X, Y), r_D2 = r - r(w_x^-1 X, w_y^-1 Y) stay matrices (m_I x s_max): each is read under three shifts, and a
         // Y shift of a matrix is one ring exchange of it in the sharded prover — of one operand rather than of two
-        Poly r_D1 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX}}), r_D2 = poly_comb({{one, &rXY}, {minus_one, &r_omegaX_omegaY}});
+        const Poly &r_D1 = co.r_D1, &r_D2 = co.r_D2;
         const ScalarField r_D1_eval = fr_sub(small_r, small_r_wx), r_D2_eval = fr_sub(small_r, small_r_wxy);   // evaluation is linear
         if (!b_zk_x) {
             b_zk_x.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true)));
