@@ -339,6 +339,10 @@ tkmk_error tkmk_g1_ntt(const tkmk_g1_affine *in_dev, int bases_form, uint32_t in
 #define TKMK_G1_NTT_AXIS_Y 2
 tkmk_error tkmk_g1_ntt_axes(const tkmk_g1_affine *in_dev, int bases_form, uint32_t in_stride, uint32_t x_size, uint32_t y_size, tkmk_ntt_dir dir,
                             int axes, tkmk_g1_affine *out_dev, tkmk_stream stream);
+/* out[i] = [scalar] in[i]: n plain affine records on the device (out_dev may be in_dev), one host scalar (plain integer below r).  No
+ * reference counterpart (the reference multiplies single points on the host: G1serde `*`, libs/src/group_structures/mod.rs:916-931); here it
+ * folds the 1 / N of an inverse transform into a resident Lagrange-basis table once per circuit. */
+tkmk_error tkmk_g1_scale(const tkmk_g1_affine *in_dev, uint64_t n, const tkmk_fr *scalar, tkmk_g1_affine *out_dev, tkmk_stream stream);
 /* Prefix sums of points: out[j] = sum_{j' <= j} in[idx(j')], idx(j) = j, or (j % rows) * cols + j / rows with `transposed` (the rows x cols
  * row-major table walked column by column).  With the Lagrange-basis points in the order of prove1's running product (lib.rs:1858-1866) this
  * is the table over which a PIECEWISE-CONSTANT evaluation vector commits as an MSM of its few jumps: sum_j r_j L_j = sum_j (r_j - r_{j+1}) S_j,

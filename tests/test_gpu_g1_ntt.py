@@ -139,3 +139,23 @@ def test_g1_ntt_one_axis_at_a_time(gpu, oracle, xs, ys):
     assert (np.asarray(gpu.g1_ntt(x_only, xs, ys, inverse=True, axes=gpu.G1_NTT_AXIS_Y).to_host()) == both).all()
     with pytest.raises(gpu.TkmkError):
         gpu.g1_ntt(pts, xs, ys, axes=4)
+
+
+def test_g1_scale_every_point_by_one_scalar(gpu, oracle):
+    """tkmk_g1_scale: out[i] = [s] in[i] against the oracle's scalar multiplication — a full-size scalar, 1, 0, the 1 / N a Lagrange table
+    is scaled by, a point at infinity in the input, and in place"""
+    n, R = 67, oracle.R_MOD
+    h, pts = _points(gpu, oracle, 91, n)
+    P = np.asarray(pts.to_host()).copy().reshape(n, 96)
+    P[5] = 0                                               # (0, 0) = infinity stays infinity
+    src = gpu.DeviceBuffer.from_host(P.reshape(-1))
+    for s in (0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % R, 1, 0, pow(4096 * 1024, -1, R), R - 1):
+        sb = oracle.to_bytes([s], 32)
+        got = np.asarray(gpu.g1_scale(src, n, sb).to_host()).reshape(n, 96)
+        for i in range(n):
+            want = np.zeros(96, np.uint8) if (i == 5 or s == 0) else np.asarray(oracle.g1_scalar_mul(sb, P[i]))
+            assert (got[i] == want).all(), (hex(s), i)
+    sb = oracle.to_bytes([7], 32)
+    inplace = gpu.DeviceBuffer.from_host(P.reshape(-1))
+    gpu.g1_scale(inplace, n, sb, out=inplace)
+    assert (np.asarray(inplace.to_host()).reshape(n, 96)[9] == np.asarray(oracle.g1_scalar_mul(sb, P[9]))).all()

@@ -79,6 +79,28 @@ __global__ __launch_bounds__(128) void k_g1ntt_store(const g1_xyzz_t *__restrict
     tk_store(out + e, a);
 }
 
+// out[i] = [w] in[i]: plain affine records in and out, one scalar for every point (the wave runs the same double-and-add)
+__global__ __launch_bounds__(128) void k_g1_scale(const g1_affine_t *__restrict__ in, uint64_t n, fr_t w, int top, g1_affine_t *__restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    g1_affine_t p = tk_load(in + e);
+    g1_affine_t a;
+    a.x = Fq::zero(), a.y = Fq::zero();
+    if (!G1::is_inf(p) && top >= 0) {
+        p.x = Fq::to_mont(Fq::canon(p.x)), p.y = Fq::to_mont(Fq::canon(p.y));
+        g1_xyzz_t acc = G1::from_affine(p);
+        for (int bit = top - 1; bit >= 0; bit--) {
+            acc = G1::dbl(acc);
+            if ((w.l[bit >> 5] >> (bit & 31)) & 1u) acc = G1::add_mixed(acc, p);
+        }
+        if (!G1::is_inf(acc)) {
+            a = G1::to_affine(acc);
+            a.x = Fq::from_mont(a.x), a.y = Fq::from_mont(a.y);
+        }
+    }
+    tk_store(out + e, a);
+}
+
 // ---- prefix sums of points: out[j] = sum_{j' <= j} in[idx(j')] ---------------------------------------------------------------
 // three phases: runs of PS_RUN elements per lane, a one-workgroup scan of the run totals, the runs again with their offsets
 #define PS_RUN 64
@@ -212,6 +234,24 @@ TK_API tkmk_error tkmk_g1_ntt_axes(const tkmk_g1_affine *in_dev, int bases_form,
     hipLaunchKernelGGL(k_g1ntt_store, tk_div_up(n, 128), 128, 0, s, (const g1_xyzz_t *)cur, n, (g1_affine_t *)out_dev);
     TK_HIP(hipGetLastError());
     TK_HIP(hipStreamSynchronize(s));   // the host twiddle vectors and the frame's scratch end with this call
+    return TKMK_SUCCESS;
+}
+
+// out[i] = [scalar] in[i] for n plain affine records on the device (in place allowed); scalar: host, plain integer below r.
+// The prover's Lagrange-basis tables are the UNSCALED inverse transform of the monomial grid, N [L_i L_j] G; scaled once by 1 / N here, a
+// commitment from evaluations is the MSM itself and no per-proof scalar multiplication by 1 / N remains (tkmk_service.hpp).
+TK_API tkmk_error tkmk_g1_scale(const tkmk_g1_affine *in_dev, uint64_t n, const tkmk_fr *scalar, tkmk_g1_affine *out_dev, tkmk_stream stream) {
+    if (!in_dev || !out_dev || !scalar) return TKMK_ERR_INVALID_POINTER;
+    if (!n) return TKMK_ERR_INVALID_ARGUMENT;
+    TK_TRY(tk_require_device());
+    fr_t w;
+    for (int i = 0; i < 8; i++) w.l[i] = scalar->limbs[i];
+    w = Fr::canon(w);
+    int top = 254;
+    while (top >= 0 && !((w.l[top >> 5] >> (top & 31)) & 1u)) top--;   // -1: the zero scalar (every point becomes infinity)
+    hipStream_t s = tk_stream(stream);
+    hipLaunchKernelGGL(k_g1_scale, tk_div_up(n, 128), 128, 0, s, (const g1_affine_t *)in_dev, n, w, top, (g1_affine_t *)out_dev);
+    TK_HIP(hipGetLastError());
     return TKMK_SUCCESS;
 }
 

@@ -1155,14 +1155,18 @@ class Sigma1 {
         if (table_c_ && (uint64_t)rs_x_ * rs_y_ * table_factor_ >= (1ull << 20)) j.table_c = table_c_, j.table_factor = table_factor_;
         return j;
     }
-    // The Lagrange-basis twin of the grid [0, xs) x [0, ys) of this table: N [L_i(tau_x) L_j(tau_y)] G = the inverse NTT over G1 points of
-    // the monomial sub-grid (tkmk_g1_ntt, unscaled), with the same commit table treatment.  commit(P) = (1/N) MSM(evaluations of P, this).
+    // The Lagrange-basis twin of the grid [0, xs) x [0, ys) of this table: [L_i(tau_x) L_j(tau_y)] G = (1 / N) x the inverse NTT over G1
+    // points of the monomial sub-grid (tkmk_g1_ntt is unscaled; tkmk_g1_scale folds the 1 / N in, once per circuit), with the same commit
+    // table treatment.  commit(P) = MSM(evaluations of P, this).
+    static ScalarField inverse_of_grid_size(size_t xs, size_t ys) { return fr_inv(fr_mul(fr_from_u32((uint32_t)xs), fr_from_u32((uint32_t)ys))); }
     DeviceVec<G1Affine> lagrange_points(size_t xs, size_t ys) const {   // plain affine records, row-major xs x ys
         if (shard_.world != 1) throw Error("Lagrange table: needs the whole grid (build it before the rows are sharded)");
         if (xs > rs_x_ || ys > rs_y_ || !is_pow2(xs) || !is_pow2(ys)) throw Error("Lagrange table: the grid must be a power-of-two corner of xy_powers");
         DeviceVec<G1Affine> lam(xs * ys);
         host_trace("lagrange_points %zu x %zu", xs, ys);
         check(tkmk_g1_ntt(xy_powers_.ptr(), TKMK_BASES_CONVERTED, (uint32_t)rs_y_, (uint32_t)xs, (uint32_t)ys, TKMK_NTT_INVERSE, lam.ptr(), nullptr), "tkmk_g1_ntt");
+        const ScalarField inv_n = inverse_of_grid_size(xs, ys);
+        check(tkmk_g1_scale(lam.ptr(), xs * ys, &inv_n, lam.ptr(), nullptr), "tkmk_g1_scale");
         return lam;
     }
     Sigma1 lagrange_of(size_t xs, size_t ys) const { return Sigma1(lagrange_points(xs, ys), xs, ys, table_c_); }

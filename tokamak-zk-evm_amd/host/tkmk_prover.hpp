@@ -16,6 +16,7 @@
 
 #include <cerrno>
 
+#include "tkmk_fq_host.hpp"
 #include "tkmk_fr.hpp"
 #include "tkmk_json.hpp"
 #include "tkmk_protocol.hpp"
@@ -284,7 +285,7 @@ inline std::vector<Term> term9(const Poly &p, const std::array<ScalarField, 2> &
     return {Term(constant, &p), Term(fr_mul(t_mi_eval, rB_X[1]), &p, 1, 0), Term(fr_mul(t_smax_eval, rB_Y[1]), &p, 0, 1)};
 }
 // several equally long linear combinations of G1 points in one batched MSM call (G1serde `+`, `-`, `* scalar`)
-inline std::vector<G1Affine> g1_lincombs(const std::vector<std::vector<std::pair<ScalarField, G1Affine>>> &rows) {
+inline std::vector<G1Affine> g1_lincombs(const std::vector<std::vector<std::pair<ScalarField, G1Affine>>> &rows, tkmk_stream stream = nullptr) {
     size_t k = rows.at(0).size();
     std::vector<ScalarField> sc;
     std::vector<G1Affine> pts;
@@ -295,6 +296,7 @@ inline std::vector<G1Affine> g1_lincombs(const std::vector<std::vector<std::pair
     tkmk_msm_config cfg = tkmk_msm_default_config();
     cfg.batch_size = (int)rows.size();
     cfg.are_points_shared_in_batch = false;
+    cfg.stream_handle = stream;   // a helper thread names its own stream (include/tkmk.h: one host thread per stream)
     std::vector<tkmk_g1_projective> res(rows.size());
     check(bls12_381_msm(sc.data(), pts.data(), (int)k, &cfg, res.data()), "msm::msm");
     std::vector<G1Affine> out;
@@ -327,7 +329,7 @@ class Prover {
     std::shared_ptr<const LagrangePolys> lagrange;
     // Evaluation-basis commitments (a resident context with Lagrange-basis tables): u, v, w and b exist as evaluations on the roots of
     // unity before they exist as coefficients (read_R1CS_gen_uvwXY, gen_bXY), and those are mostly zeros and small numbers.  With the
-    // tables set, prove0 commits U, V, W, B as (1/N) MSM(evaluations, Lagrange table) + the blinding terms; the points are the same.
+    // tables set, prove0 commits U, V, W, B as MSM(evaluations, Lagrange table) + the blinding terms; the points are the same.
     DeviceVec<ScalarField> u_ev, v_ev, w_ev, b_ev;
     // the permutation polynomials' evaluations on the m_I x s_max grid and their identity part (w_x^row, w_y^col) — kept by a resident
     // context: prove1's f and g are then formed ON THE GRID (the forward transforms of lib.rs:1813-1830 are linear and exact, so the
@@ -358,9 +360,50 @@ class Prover {
         }();
         return enabled && commit_stream && !dist_ctx().on() && !commit_comm().comm && !commit_box_sink() && tkmk_msm_get_pipeline_streams() > 1;
     }
-    std::future<std::vector<G1Affine>> commit_early(std::vector<tkmk_msm_job_ex> jobs) const {
+    std::future<std::vector<G1Affine>> commit_early(std::vector<tkmk_msm_job_ex> jobs, bool with_blinds = false) const {
         tkmk_stream st = commit_stream;
-        return std::async(std::launch::async, [jobs, st] { return Sigma1::run_jobs(jobs, st); });
+        return std::async(std::launch::async, [jobs, st, with_blinds, this] {
+            std::vector<G1Affine> r = Sigma1::run_jobs(jobs, st);
+            if (with_blinds && !blinds_) blinds_.reset(new Blinds(compute_blinds(st)));   // read after the future is collected
+            return r;
+        });
+    }
+    // The blinding points of the evaluation-basis commitments: commit(p + sum_k c_k T^k (T^e - 1)) = MSM(evaluations of p, Lagrange table)
+    // + sum_k c_k ([tau^(e+k)]G - [tau^k]G), and the second summand depends on the mixer and the CRS only — one small batched MSM per
+    // proof, made beside prove0's work (the reference has no such step: it commits the blinded coefficients, lib.rs:1744-1782, 1940-1956);
+    // U, V, W, B and R are then ONE affine addition each on the host when their MSM returns.
+    struct Blinds {
+        G1Affine U, V, W, B, R;
+    };
+    mutable std::unique_ptr<Blinds> blinds_;
+    Blinds compute_blinds(tkmk_stream st) const {
+        using namespace prover_detail;
+        const Mixer &mx = mixer;
+        const size_t n = sp.n, s_max = sp.s_max;
+        using Row = std::vector<std::pair<ScalarField, G1Affine>>;
+        auto vanishing_terms = [&](Row &row, const ScalarField *coef, size_t k_count, size_t exponent, bool x_axis) {
+            for (size_t k = 0; k < k_count; k++) {
+                row.push_back({coef[k], x_axis ? sigma->xy_at(exponent + k, 0) : sigma->xy_at(0, exponent + k)});
+                row.push_back({fr_neg(coef[k]), x_axis ? sigma->xy_at(k, 0) : sigma->xy_at(0, k)});
+            }
+        };
+        Row ru, rv, rw, rb, rr;
+        vanishing_terms(ru, &mx.rU_X, 1, n, true), vanishing_terms(ru, &mx.rU_Y, 1, s_max, false);
+        vanishing_terms(rv, &mx.rV_X, 1, n, true), vanishing_terms(rv, &mx.rV_Y, 1, s_max, false);
+        vanishing_terms(rw, mx.rW_X.data(), mx.rW_X.size(), n, true), vanishing_terms(rw, mx.rW_Y.data(), mx.rW_Y.size(), s_max, false);
+        vanishing_terms(rb, mx.rB_X.data(), mx.rB_X.size(), m_i, true), vanishing_terms(rb, mx.rB_Y.data(), mx.rB_Y.size(), s_max, false);
+        vanishing_terms(rr, &mx.rR_X, 1, m_i, true), vanishing_terms(rr, &mx.rR_Y, 1, s_max, false);
+        size_t width = 0;
+        for (Row *r : {&ru, &rv, &rw, &rb, &rr}) width = std::max(width, r->size());
+        ScalarField zero{};
+        for (Row *r : {&ru, &rv, &rw, &rb, &rr})
+            while (r->size() < width) r->push_back({zero, r->front().second});
+        auto b = g1_lincombs({ru, rv, rw, rb, rr}, st);
+        return Blinds{b[0], b[1], b[2], b[3], b[4]};
+    }
+    const Blinds &blinds() const {
+        if (!blinds_) blinds_.reset(new Blinds(compute_blinds(nullptr)));
+        return *blinds_;
     }
 
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -482,20 +525,21 @@ class Prover {
         std::future<std::vector<G1Affine>> early;
         if (from_evaluations && can_commit_early())
             early = commit_early({lagrange_n->job_evals(u_ev, "U", n, s_max), lagrange_n->job_evals(v_ev, "V", n, s_max), lagrange_n->job_evals(w_ev, "W", n, s_max),
-                                  lagrange_mi->job_evals(b_ev, "B", m_i, s_max)});
+                                  lagrange_mi->job_evals(b_ev, "B", m_i, s_max)}, true);
         Poly p0XY = uXY * vXY - wXY;
         auto q01 = p0XY.div_by_vanishing_opt((int64_t)n, (int64_t)s_max);
         q0XY = std::move(q01.first), q1XY = std::move(q01.second);
         Poly rW_X = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_X.begin(), mx.rW_X.end()), 4, 1);
         Poly rW_Y = Poly::from_coeffs(std::vector<ScalarField>(mx.rW_Y.begin(), mx.rW_Y.end()), 1, 4);
         ScalarField one = fr_one(), minus_one = fr_neg(one);
-        w_zk.reset(new Poly(low_degree_times_vanishing(mx.rW_X, n, true) + low_degree_times_vanishing(mx.rW_Y, s_max, false)));
         Poly Q_AX_XY = poly_comb({{one, &q0XY}, {mx.rU_X, &vXY}, {mx.rV_X, &uXY}, {minus_one, &rW_X}, {fr_mul(mx.rU_X, mx.rV_X), &t_n},
                                   {fr_mul(mx.rU_Y, mx.rV_X), &t_smax}});
         Poly Q_AY_XY = poly_comb({{one, &q1XY}, {mx.rU_Y, &vXY}, {mx.rV_Y, &uXY}, {minus_one, &rW_Y}, {fr_mul(mx.rU_X, mx.rV_Y), &t_n},
                                   {fr_mul(mx.rU_Y, mx.rV_Y), &t_smax}});
-        term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
         if (from_evaluations) return prove0_from_evaluations(Q_AX_XY, Q_AY_XY, early);
+        // the coefficient route commits the blinded polynomials themselves: (sum c_k X^k)(X^n - 1) + (sum c_k Y^k)(Y^s_max - 1) as matrices
+        w_zk.reset(new Poly(low_degree_times_vanishing(mx.rW_X, n, true) + low_degree_times_vanishing(mx.rW_Y, s_max, false)));
+        term_b_zk.reset(new Poly(low_degree_times_vanishing(mx.rB_X, m_i, true) + low_degree_times_vanishing(mx.rB_Y, s_max, false)));
         Poly UXY = poly_comb({{one, &uXY}, {mx.rU_X, &t_n}, {mx.rU_Y, &t_smax}});
         Poly VXY = blinded_V();
         Poly WXY = poly_comb({{one, &wXY}, {one, w_zk.get()}});
@@ -504,11 +548,10 @@ class Prover {
         return Proof0{c[0], c[1], c[2], c[3], c[4], c[5]};
     }
     // U, V, W, B from the evaluations (same points as the coefficient route above):
-    //   commit(p + sum_k c_k T^k (T^e - 1)) = (1/N) MSM(evaluations of p, Lagrange table) + sum_k c_k ([tau^(e+k)]G - [tau^k]G)
+    //   commit(p + sum_k c_k T^k (T^e - 1)) = MSM(evaluations of p, Lagrange table) + sum_k c_k ([tau^(e+k)]G - [tau^k]G)
     // early (valid): the four evaluation commits were issued before the round's polynomial work and are collected here
     Proof0 prove0_from_evaluations(Poly &Q_AX_XY, Poly &Q_AY_XY, std::future<std::vector<G1Affine>> &early) {
         using namespace prover_detail;
-        const Mixer &mx = mixer;
         const size_t n = sp.n, s_max = sp.s_max;
         std::vector<G1Affine> c(6);
         if (early.valid()) {
@@ -519,26 +562,9 @@ class Prover {
             c = Sigma1::run_jobs({lagrange_n->job_evals(u_ev, "U", n, s_max), lagrange_n->job_evals(v_ev, "V", n, s_max), lagrange_n->job_evals(w_ev, "W", n, s_max),
                                   sigma->sigma1.job(Q_AX_XY, "Q_AX"), sigma->sigma1.job(Q_AY_XY, "Q_AY"), lagrange_mi->job_evals(b_ev, "B", m_i, s_max)});
         }
-        const ScalarField inv_n = fr_inv(fr_mul(fr_from_u32((uint32_t)n), fr_from_u32((uint32_t)s_max)));
-        const ScalarField inv_mi = fr_inv(fr_mul(fr_from_u32((uint32_t)m_i), fr_from_u32((uint32_t)s_max)));
-        using Row = std::vector<std::pair<ScalarField, G1Affine>>;
-        auto vanishing_terms = [&](Row &row, const ScalarField *coef, size_t k_count, size_t exponent, bool x_axis) {
-            for (size_t k = 0; k < k_count; k++) {
-                row.push_back({coef[k], x_axis ? sigma->xy_at(exponent + k, 0) : sigma->xy_at(0, exponent + k)});
-                row.push_back({fr_neg(coef[k]), x_axis ? sigma->xy_at(k, 0) : sigma->xy_at(0, k)});
-            }
-        };
-        Row ru{{inv_n, c[0]}}, rv{{inv_n, c[1]}}, rw{{inv_n, c[2]}}, rb{{inv_mi, c[5]}};
-        vanishing_terms(ru, &mx.rU_X, 1, n, true), vanishing_terms(ru, &mx.rU_Y, 1, s_max, false);
-        vanishing_terms(rv, &mx.rV_X, 1, n, true), vanishing_terms(rv, &mx.rV_Y, 1, s_max, false);
-        vanishing_terms(rw, mx.rW_X.data(), mx.rW_X.size(), n, true), vanishing_terms(rw, mx.rW_Y.data(), mx.rW_Y.size(), s_max, false);
-        vanishing_terms(rb, mx.rB_X.data(), mx.rB_X.size(), m_i, true), vanishing_terms(rb, mx.rB_Y.data(), mx.rB_Y.size(), s_max, false);
-        size_t width = std::max(std::max(ru.size(), rv.size()), std::max(rw.size(), rb.size()));
-        ScalarField zero{};
-        for (Row *r : {&ru, &rv, &rw, &rb})
-            while (r->size() < width) r->push_back({zero, r->front().second});
-        auto uvwb = g1_lincombs({ru, rv, rw, rb});
-        return Proof0{uvwb[0], uvwb[1], uvwb[2], c[3], c[4], uvwb[3]};
+        // the Lagrange tables carry the transform's 1 / N (tkmk_g1_scale at open): the MSM is the commitment of the unblinded polynomial
+        const Blinds &bl = blinds();
+        return Proof0{fqh::g1_affine_add(c[0], bl.U), fqh::g1_affine_add(c[1], bl.V), fqh::g1_affine_add(c[2], bl.W), c[3], c[4], fqh::g1_affine_add(c[5], bl.B)};
     }
 
     // prove1 (lib.rs:1784-1956)
@@ -635,12 +661,7 @@ class Prover {
                 check(tkmk_memcpy_2d_d2d(d.ptr() + (m_i - 1), m_i * sizeof(ScalarField), compact.ptr(), sizeof(ScalarField), sizeof(ScalarField), lc), "scatter column ends");
             }
             G1Affine core = Sigma1::run_jobs({lagrange_mi_prefix->job_evals(d, "R", m_i * s_max, 1)})[0];
-            const ScalarField inv_cells = fr_inv(fr_mul(fr_from_u32((uint32_t)m_i), fr_from_u32((uint32_t)s_max)));
-            const Mixer &mx = mixer;
-            std::vector<std::pair<ScalarField, G1Affine>> row = {{inv_cells, core},
-                                                                 {mx.rR_X, sigma->xy_at(m_i, 0)}, {fr_neg(mx.rR_X), sigma->xy_at(0, 0)},
-                                                                 {mx.rR_Y, sigma->xy_at(0, s_max)}, {fr_neg(mx.rR_Y), sigma->xy_at(0, 0)}};
-            return Proof1{prover_detail::g1_lincombs({row})[0]};
+            return Proof1{fqh::g1_affine_add(core, blinds().R)};
         }
         Poly RXY = blinded_R();
         return Proof1{sigma->sigma1.encode_poly(RXY, "R")};

@@ -311,6 +311,8 @@ class ProverContext {
                         check(tkmk_g1_ntt_axes(rows.ptr(), TKMK_BASES_PLAIN, (uint32_t)ys, (uint32_t)h, (uint32_t)ys, TKMK_NTT_INVERSE, TKMK_G1_NTT_AXIS_Y, b.ptr(), nullptr),
                               "tkmk_g1_ntt_axes");
                         check(lk.relayout_rows_to_cols(lk.comm, b.ptr(), xs, ys, sizeof(G1Affine), a.ptr()), "tkmk_dist_relayout_rows_to_cols");
+                        const ScalarField inv_n = Sigma1::inverse_of_grid_size(xs, ys);   // the transform's 1 / N, on this rank's columns
+                        check(tkmk_g1_scale(a.ptr(), xs * lcs, &inv_n, a.ptr(), nullptr), "tkmk_g1_scale");
                         return a;
                     };
                     DeviceVec<G1Affine> lam_mi = lagrange_cols(m_i, s_max);

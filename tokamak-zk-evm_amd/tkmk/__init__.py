@@ -82,7 +82,7 @@ SYMBOLS = [
     "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
     "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
     "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
-    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_keccak256", "tkmk_r1cs_index", "tkmk_msm_default_config", "bls12_381_msm", "bls12_381_g2_msm", "tkmk_g1_ntt", "tkmk_g1_ntt_axes", "tkmk_g1_prefix_sums", "bls12_381_msm_precompute_bases", "bn254_msm_precompute_bases", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "bn254_get_root_of_unity", "bn254_ntt_init_domain", "bn254_ntt_release_domain",
+    "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_keccak256", "tkmk_r1cs_index", "tkmk_msm_default_config", "bls12_381_msm", "bls12_381_g2_msm", "tkmk_g1_ntt", "tkmk_g1_ntt_axes", "tkmk_g1_prefix_sums", "tkmk_g1_scale", "bls12_381_msm_precompute_bases", "bn254_msm_precompute_bases", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "bn254_get_root_of_unity", "bn254_ntt_init_domain", "bn254_ntt_release_domain",
     "bn254_ntt", "tkmk_bn254_bintt", "tkmk_bn254_fr_random_device",
     "tkmk_bn254_g1_batch_scalar_mul_device",
     "tkmk_ntt_default_config", "bls12_381_get_root_of_unity", "bls12_381_ntt_init_domain", "bls12_381_ntt_release_domain",
@@ -453,6 +453,14 @@ def g1_prefix_sums(points, rows, cols, transposed=False, bases_form=0, out=None)
     out = DeviceBuffer(96 * rows * cols) if out is None else out
     _check(lib().tkmk_g1_prefix_sums(_p(points), int(bases_form), ctypes.c_uint32(rows), ctypes.c_uint32(cols), int(bool(transposed)), _p(out), None),
            "tkmk_g1_prefix_sums")
+    return out
+
+
+def g1_scale(points, n, scalar, out=None):
+    """out[i] = [scalar] points[i] (tkmk_g1_scale): plain affine device records, one 32-byte little-endian scalar"""
+    out = DeviceBuffer(96 * n) if out is None else out
+    sc = np.ascontiguousarray(np.frombuffer(bytes(scalar), np.uint8))
+    _check(lib().tkmk_g1_scale(_p(points), ctypes.c_uint64(n), _p(sc), _p(out), None), "tkmk_g1_scale")
     return out
 
 
