@@ -6,6 +6,7 @@ import json
 import os
 import random
 
+import numpy as np
 import pytest
 
 PINS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pins.json")))
@@ -81,3 +82,21 @@ def test_cpp_g2_equals_python(g2):
     # a point that is not on the twist is reported as such
     r = subprocess.run([driver, PINS["fixed_tau_g2_y"], PINS["fixed_tau_g2_x"]], input="oncurve 0x0\n", capture_output=True, text=True, timeout=60)
     assert r.stdout.split() == ["0"]
+
+
+def test_cpp_g1_affine_add_equals_oracle(oracle):
+    """fqh::g1_affine_add (host/tkmk_fq_host.hpp: a commitment plus its precomputed blinding point, G1serde `+` of
+    libs/src/group_structures/mod.rs:895-903) against the oracle's addition: generic pairs, p + p, p + (-p), either operand at infinity"""
+    import subprocess
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_cpp", "g2_driver")
+    assert os.path.exists(driver), "tests/host_cpp/g2_driver is not built (run __graft_entry__.build())"
+    pts = np.asarray(oracle.g1_random_bases(77, 8)).reshape(8, 96)
+    inf = np.zeros(96, np.uint8)
+    pairs = [(pts[i], pts[i + 1]) for i in range(7)] + [(pts[0], pts[0]), (pts[1], np.asarray(oracle.g1_neg(np.ascontiguousarray(pts[1])))), (inf, pts[2]), (pts[3], inf), (inf, inf)]
+    lines = ["g1add %s %s" % (bytes(p).hex(), bytes(q).hex()) for p, q in pairs]
+    r = subprocess.run([driver, PINS["fixed_tau_g2_x"], PINS["fixed_tau_g2_y"]], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.split()
+    assert len(out) == len(pairs)
+    for got, (p, q) in zip(out, pairs):
+        assert bytes.fromhex(got) == bytes(np.asarray(oracle.g1_add(np.ascontiguousarray(p), np.ascontiguousarray(q)))), (bytes(p).hex()[:16], bytes(q).hex()[:16])
