@@ -19,6 +19,30 @@ def build():
     subprocess.run(["make", "-s", "-C", _HERE, "libtk_oracle.so"], check=True)
 
 
+def usable_cpus(limit=None):
+    """CPUs this process may really use: the affinity mask and the cgroup CPU quota, whichever is smaller (at most `limit`)"""
+    n = limit if limit else (os.cpu_count() or 1)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+    try:       # cgroup v1
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0 and period > 0:
+            n = min(n, max(1, quota // period))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -35,6 +59,12 @@ def lib():
         for f in ("tko_bn254_ntt", "tko_bn254_bintt", "tko_bn254_dft_naive", "tko_bn254_get_root_of_unity"):
             getattr(_LIB, f).restype = ctypes.c_int
         _LIB.tko_num_threads.restype = ctypes.c_int
+        _LIB.tko_set_num_threads.restype = ctypes.c_int
+        if "OMP_NUM_THREADS" not in os.environ:
+            # OpenMP's default is every hardware thread of the host (256 on a GPU box); a process that only has a share of them — an
+            # affinity mask or a cgroup CPU quota, 16 for one GPU — is throttled for a scheduler period every time 256 threads wake up:
+            # measured 0.1-0.2 s per oracle call, whatever its size (tools/scratch: a 2-point NTT took as long as a 2^12-point one)
+            _LIB.tko_set_num_threads(usable_cpus(_LIB.tko_num_threads()))
         _LIB.tko_poly_mul_monomial.restype = ctypes.c_int
         _LIB.tko_poly_div_by_vanishing_opt.restype = ctypes.c_int
     return _LIB

@@ -250,6 +250,17 @@ int tko_num_threads(void) {
     return 1;
 #endif
 }
+/* the parallel regions of the calling thread use at most n threads from here on (OpenMP's default counts every hardware thread of the
+ * host; a process held to a CPU quota is throttled for a scheduler period each time that many threads wake up: oracle/__init__.py) */
+int tko_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------
  * Element-wise Fr / Fq (ICICLE VecOps as used by libs/src/vector_operations/mod.rs:34-139)

@@ -28,7 +28,7 @@ def test_msm_randomized(gpu, oracle, curve):
     rnd = random.Random(20260101 if curve == "bls12_381" else 20260202)
     pool_n = 6000
     pool = o.g1_random_bases(900, pool_n)
-    for it in range(15):
+    for it in range(18):
         n = rnd.choice((2, 3, 5, 31, 64, 65, 200, 777, 1500, 4096, 6000))
         c = rnd.choice((0, 0, 2, 4, 7, 9, 12, 13, 14, 16, 17))
         pattern = rnd.choice(("uniform", "uniform", "small", "edges", "same"))
@@ -71,8 +71,8 @@ def test_ntt_randomized(gpu, oracle, curve):
         logn = rnd.randrange(0, 15)
         n = 1 << logn
         batch = rnd.choice((1, 1, 2, 3, 5, 8, 17, 64))
-        if n * batch > (1 << 16):
-            batch = max(1, (1 << 16) // n)
+        if n * batch > (1 << 17):
+            batch = max(1, (1 << 17) // n)
         columns = rnd.random() < 0.5
         inverse = rnd.random() < 0.5
         coset = o.fr_random(1000 + it, 1) if rnd.random() < 0.5 else None

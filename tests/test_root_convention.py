@@ -76,11 +76,10 @@ def test_gpu_parity_tiers_under_the_alternative_generator():
     default tier runs them with the declared g)"""
     env = dict(os.environ, TKMK_FR_ROOT_GENERATOR="7")
     # the tests of the three tiers whose result depends on the root: the transforms against the oracle (bivariate = both 1-D passes, cosets,
-    # in place), products, the fused evaluator and its leaf views, and the prover end to end (the native C++ prover runs under g = 7 in
-    # test_native_pipeline_verifies_under_either_generator_but_not_across below).  Left to the default tier alone: the 1-D
+    # in place), products, the fused evaluator and its leaf views, and the prover end to end.  Left to the default tier alone: the 1-D
     # shape sweeps, the large padded-transform shapes and the root-free polynomial bookkeeping (find_degree, resize, lincomb).
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_ntt.py", "tests/test_gpu_poly.py",
-                        "tests/test_gpu_prove.py::test_prove_equals_reference_restatement_and_verifies",
+                        "tests/test_gpu_prove.py::test_prove_equals_reference_restatement_and_verifies", "tests/test_gpu_service.py::test_service_equals_python_prover_and_restatement",
                         "-k", "bintt_vs_oracle or row_then_column or coset or mul_vs_oracle or polyexpr_fused or restatement",
                         "-p", "no:cacheprovider", "-o", "addopts="], capture_output=True, text=True, timeout=3000, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
