@@ -28,7 +28,7 @@ def test_msm_randomized(gpu, oracle, curve):
     rnd = random.Random(20260101 if curve == "bls12_381" else 20260202)
     pool_n = 6000
     pool = o.g1_random_bases(900, pool_n)
-    for it in range(18):
+    for it in range(36):
         n = rnd.choice((2, 3, 5, 31, 64, 65, 200, 777, 1500, 4096, 6000))
         c = rnd.choice((0, 0, 2, 4, 7, 9, 12, 13, 14, 16, 17))
         pattern = rnd.choice(("uniform", "uniform", "small", "edges", "same"))
@@ -67,7 +67,7 @@ def test_ntt_randomized(gpu, oracle, curve):
     o = oracle if curve == "bls12_381" else oracle.bn254
     gpu.init_ntt_domain_for_size(1 << 20, curve=curve)
     rnd = random.Random(77 if curve == "bls12_381" else 78)
-    for it in range(16):
+    for it in range(40):
         logn = rnd.randrange(0, 15)
         n = 1 << logn
         batch = rnd.choice((1, 1, 2, 3, 5, 8, 17, 64))
@@ -87,7 +87,7 @@ def test_ntt_randomized(gpu, oracle, curve):
                           out=d if mode == "inplace" else None)
             got = out.to_host()
         assert (got == want).all(), (curve, it, logn, batch, columns, inverse, coset is not None, mode)
-    for it in range(5):                                   # bivariate shapes incl. degenerate axes
+    for it in range(12):                                  # bivariate shapes incl. degenerate axes
         xs, ys = 1 << rnd.randrange(0, 9), 1 << rnd.randrange(0, 9)
         m = o.fr_random(3000 + it, xs * ys)
         cx = o.fr_random(3100 + it, 1) if rnd.random() < 0.5 else None

@@ -14,11 +14,13 @@ Unmeasured on multi-GPU hardware (no SCALE run so far); `bench.py --gpus N --one
 import json
 import os
 import random
+import sys
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SHAPES = [(61, dict(s_max=8, n_gate_kinds=2)),
           (62, dict(s_max=16, n_gate_kinds=3, n_out=2, n_in=3, n_prv=9, used_placements=11, k_out=0, k_pub=3, bit_fraction=0.5))]
@@ -250,3 +252,15 @@ def test_the_ranks_divide_the_polynomial_work(gpu, oracle, tmp_path, monkeypatch
             p.close()
         for c in comms:
             c.close()
+
+
+def test_fuzz_shapes_native_and_sharded_against_the_restatement():
+    """tools/prove_fuzz.py over 16 seeded random circuit shapes (s_max 8 / 16, 0-2 output and 1-3 public buffers, 2-6 gate kinds, m_I 16-64):
+    the Python prover and the native binary against the big-int restatement (every point, evaluation and challenge; the verifier equation on
+    the discrete logarithms), and the same files through tkmk_prover_open_sharded with 2, 4 or 8 virtual ranks, with and without the commit /
+    Lagrange tables — every rank's proof.json the binary's byte for byte.  (The tool's longer runs are recorded under profiles/.)"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_fuzz.py"), "16", "8100", "sharded"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.strip().splitlines()[-1] == "all 16 cases equal the restatement and verify", r.stdout[-1500:]
+    assert r.stdout.count(" ok ") == 16
