@@ -172,6 +172,43 @@ def test_production_shape_sharded_over_two_virtual_ranks(gpu):
         gpu.release_scratch()
 
 
+def test_configs3_sharded_over_four_and_eight_virtual_ranks(gpu):
+    """BASELINE.json configs[3] (n = 4096, m_I = 4096, s_max = 1024, 1024 placements: the bench's workload) through the sharded prover with G = 4
+    (20-bit table windows) and G = 8 (16-bit windows): every rank's proof equals the single-GPU context's byte for byte
+    for the same blinding scalars — at the size the headline is measured on, not only at the small shapes above"""
+    import shutil
+    import prove_bench
+    from tkmk import dist, service
+    from tkmk.prove import random_mixer
+    files = prove_bench.stage_files(s_max=1024)
+    try:
+        mixer = random_mixer(random.Random(2028))
+        hx = lambda v: [hx(e) for e in v] if isinstance(v, list) else "0x%x" % v          # noqa: E731
+        mixer_path = os.path.join(files["tmp"], "mixer.json")
+        json.dump({k: hx(v) for k, v in mixer.items()}, open(mixer_path, "w"))
+        with service.Prover(files["qap"], files["crs"], testing=True) as single:
+            want, _, boxes = single.prove(files["synth"], None, testing_mixer_json=mixer_path, want_boxes=True)
+        gpu.release_scratch()
+        for world in (4, 8):
+            comms = dist.loopback_comms(world)
+            provers = _open_ranks(dist, service, comms, files["qap"], files["crs"])
+            by_rank = {p.comm.rank: p for p in provers}
+            try:
+                res = dist.run_ranks(comms, lambda c: by_rank[c.rank].prove(files["synth"], None, testing_mixer_json=mixer_path, want_boxes=True))
+                for r in range(world):
+                    assert res[r][0] == want, (world, r)
+                    assert res[r][2] == boxes, (world, r)
+            finally:
+                for p in provers:
+                    p.close()
+                for c in comms:
+                    c.close()
+                gpu.release_scratch()
+    finally:
+        shutil.rmtree(files["tmp"], ignore_errors=True)
+        gpu.release_scratch()
+
+
 def test_an_input_error_only_one_rank_can_see_is_every_ranks_error(gpu, oracle, tmp_path, monkeypatch):
     """a rank converts only its own placements' values, so a bad hex digit inside placement 1 is seen by rank 1 alone — the ranks agree on
     the outcome of the input phase before any of them goes on: EVERY rank reports the error (none proves on with a peer missing), the
