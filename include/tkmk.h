@@ -22,10 +22,12 @@
  *   - one host thread at a time PER STREAM: every entry keeps its scratch in a grow-only arena that belongs to the stream it is
  *     given (stream_handle / the `stream` argument; NULL = the default stream), so two threads may call concurrently only if they
  *     name DIFFERENT streams (the reference issues all device calls from its main thread: SURVEY.md section 8b);
- *   - one MSM BATCH at a time per process: bls12_381_msm (batch or single), tkmk_msm_multi and tkmk_msm_multi_ex run their
- *     jobs over a process-wide set of pipeline streams and pinned result buffers behind one lock, held from the first job's launch
- *     to the last job's result — a second thread's MSM call waits for the whole batch of the first (results are unaffected; the
- *     resident prover's binding-commitment helper thread relies on exactly this);
+ *   - one MSM BATCH at a time per CALLER STREAM: bls12_381_msm (batch or single), tkmk_msm_multi and tkmk_msm_multi_ex run their
+ *     jobs over a set of pipeline streams and pinned result buffers that belongs to the stream the call names (cfg->stream_handle;
+ *     NULL = the default stream), behind that set's lock, held from the first job's launch to the last job's result — a second
+ *     thread's MSM call on the SAME stream waits for the whole batch of the first; calls that name DIFFERENT streams run
+ *     concurrently and share the device (the resident prover's helper threads commit on their own streams beside the main
+ *     thread's batches: results are unaffected, see tests/test_gpu_service.py);
  *   - process-global state: the NTT domain (like ICICLE's; initialise / grow it from one thread while no transform runs), the
  *     device binding (tkmk_set_device: one device per process), the allocator's cache, the pipeline width
  *     (tkmk_msm_set_pipeline_streams), the profile / stats counters;

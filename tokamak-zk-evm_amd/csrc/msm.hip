@@ -4,6 +4,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 

@@ -507,6 +507,14 @@ TK_API const char *tkmk_error_string(tkmk_error e) {
 }
 TK_API int tkmk_is_hip_build(void) { return 1; }
 
+// HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and streams that share a queue run one
+// after the other.  The resident prover keeps up to three commit batches in flight (the main thread's, the binding helper's and the early
+// commits' — three pipeline streams each, csrc/msm_impl.inc): on 4 queues an early commit was seen waiting 11 ms behind an unrelated
+// binding job that shared its queue (rocprofv3 kernel trace, production shape).  8 queues measured best (production shape 68.6 -> 65.7 ms,
+// configs[3] 203.9 -> 202.2 ms; 16 no better).  Set when this library is loaded, before the HIP runtime reads its environment, and only
+// if the process has not chosen a value itself.
+__attribute__((constructor)) static void tk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 // ---- event profiler ----
 // Sections are bracketed by events recorded on the launch stream; nothing waits for them when they are recorded (a
 // synchronisation inside the pipelined MSM entry would serialise exactly the overlap being measured).  finish() parks the

@@ -360,22 +360,20 @@ class Prover {
         }();
         return enabled && commit_stream && !dist_ctx().on() && !commit_comm().comm && !commit_box_sink() && tkmk_msm_get_pipeline_streams() > 1;
     }
-    std::future<std::vector<G1Affine>> commit_early(std::vector<tkmk_msm_job_ex> jobs, bool with_blinds = false) const {
+    std::future<std::vector<G1Affine>> commit_early(std::vector<tkmk_msm_job_ex> jobs) const {
         tkmk_stream st = commit_stream;
-        return std::async(std::launch::async, [jobs, st, with_blinds, this] {
-            std::vector<G1Affine> r = Sigma1::run_jobs(jobs, st);
-            if (with_blinds && !blinds_) blinds_.reset(new Blinds(compute_blinds(st)));   // read after the future is collected
-            return r;
-        });
+        return std::async(std::launch::async, [jobs, st] { return Sigma1::run_jobs(jobs, st); });
     }
     // The blinding points of the evaluation-basis commitments: commit(p + sum_k c_k T^k (T^e - 1)) = MSM(evaluations of p, Lagrange table)
     // + sum_k c_k ([tau^(e+k)]G - [tau^k]G), and the second summand depends on the mixer and the CRS only — one small batched MSM per
-    // proof, made beside prove0's work (the reference has no such step: it commits the blinded coefficients, lib.rs:1744-1782, 1940-1956);
-    // U, V, W, B and R are then ONE affine addition each on the host when their MSM returns.
+    // proof, made by the helper thread of `init`'s binding commitments before its own batch (tkmk_service.hpp), i.e. under prove0's work (the
+    // reference has no such step: it commits the blinded coefficients, lib.rs:1744-1782, 1940-1956); U, V, W, B and R are then ONE
+    // affine addition each on the host when their MSM returns.  blinds_ready (valid when a helper makes them) is waited for by blinds().
     struct Blinds {
         G1Affine U, V, W, B, R;
     };
     mutable std::unique_ptr<Blinds> blinds_;
+    std::shared_future<void> blinds_ready;
     Blinds compute_blinds(tkmk_stream st) const {
         using namespace prover_detail;
         const Mixer &mx = mixer;
@@ -402,6 +400,7 @@ class Prover {
         return Blinds{b[0], b[1], b[2], b[3], b[4]};
     }
     const Blinds &blinds() const {
+        if (blinds_ready.valid()) blinds_ready.get();   // rethrows what the helper met
         if (!blinds_) blinds_.reset(new Blinds(compute_blinds(nullptr)));
         return *blinds_;
     }
@@ -525,7 +524,7 @@ class Prover {
         std::future<std::vector<G1Affine>> early;
         if (from_evaluations && can_commit_early())
             early = commit_early({lagrange_n->job_evals(u_ev, "U", n, s_max), lagrange_n->job_evals(v_ev, "V", n, s_max), lagrange_n->job_evals(w_ev, "W", n, s_max),
-                                  lagrange_mi->job_evals(b_ev, "B", m_i, s_max)}, true);
+                                  lagrange_mi->job_evals(b_ev, "B", m_i, s_max)});
         Poly p0XY = uXY * vXY - wXY;
         auto q01 = p0XY.div_by_vanishing_opt((int64_t)n, (int64_t)s_max);
         q0XY = std::move(q01.first), q1XY = std::move(q01.second);

@@ -616,7 +616,26 @@ class ProverContext {
             pb.mid_sc = std::move(mid_sc), pb.prv_sc = std::move(prv_sc), pb.pub_sc = std::move(pub_sc);   // the jobs point into these blocks
             pb.mid_ix = std::move(mid_ix), pb.prv_ix = std::move(prv_ix), pb.pub_ix = std::move(pub_ix);
             tkmk_stream bs = binding_stream_;
-            pb.cores = std::async(std::launch::async, [binding_jobs, bs] { return Sigma1::run_jobs(binding_jobs, bs); });
+            // the helper first makes the proof's blinding points (one small MSM + a host Horner, 2 ms: prove0 needs them at its END, the
+            // binding commitments are needed after prove4), then runs the binding batch
+            const bool make_blinds = p->lagrange_n && p->lagrange_mi && p->u_ev.len() && p->v_ev.len() && p->w_ev.len() && p->b_ev.len();
+            std::shared_ptr<std::promise<void>> blinds_done;
+            if (make_blinds) {
+                blinds_done = std::make_shared<std::promise<void>>();
+                p->blinds_ready = blinds_done->get_future().share();
+            }
+            Prover *pp = p.get();   // alive until this future has been collected (ProverContext::prove: `pending` goes before the prover)
+            pb.cores = std::async(std::launch::async, [binding_jobs, bs, pp, blinds_done] {
+                if (blinds_done) {
+                    try {
+                        pp->blinds_.reset(new Prover::Blinds(pp->compute_blinds(bs)));
+                        blinds_done->set_value();
+                    } catch (...) {
+                        blinds_done->set_exception(std::current_exception());
+                    }
+                }
+                return Sigma1::run_jobs(binding_jobs, bs);
+            });
             tm.binding = Prover::now() - t3;
             tm.init = Prover::now() - t0;
             p->timing["init.parse"] = tm.parse, p->timing["init.upload"] = tm.upload, p->timing["init.build"] = tm.build;

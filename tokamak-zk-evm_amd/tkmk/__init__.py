@@ -12,6 +12,10 @@ import os
 
 import numpy as np
 
+# the library's own default (csrc/runtime.hip: streams share 4 hardware queues otherwise), made here too because a Python process may
+# initialise HIP through another module before libtkmk_hip.so is loaded
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("TKMK_HIP_LIBRARY") or os.path.join(_PKG, "libtkmk_hip.so")   # the override is for kernel experiments (tools/)
 _lib = None
