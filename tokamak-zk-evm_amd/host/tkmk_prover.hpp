@@ -371,6 +371,7 @@ class Prover {
     // affine addition each on the host when their MSM returns.  blinds_ready (valid when a helper makes them) is waited for by blinds().
     struct Blinds {
         G1Affine U, V, W, B, R;
+        G1Affine O_mid, O_prv;   // the blinding terms of the two binding commitments (lib.rs:1100-1160), same treatment
     };
     mutable std::unique_ptr<Blinds> blinds_;
     std::shared_future<void> blinds_ready;
@@ -391,13 +392,21 @@ class Prover {
         vanishing_terms(rw, mx.rW_X.data(), mx.rW_X.size(), n, true), vanishing_terms(rw, mx.rW_Y.data(), mx.rW_Y.size(), s_max, false);
         vanishing_terms(rb, mx.rB_X.data(), mx.rB_X.size(), m_i, true), vanishing_terms(rb, mx.rB_Y.data(), mx.rB_Y.size(), s_max, false);
         vanishing_terms(rr, &mx.rR_X, 1, m_i, true), vanishing_terms(rr, &mx.rR_Y, 1, s_max, false);
+        const auto &xh = sigma->delta_inv_alphak_xh_tx, &xj = sigma->delta_inv_alpha4_xj_tx, &yi = sigma->delta_inv_alphak_yi_ty;
+        Row mid = {{mx.rO_mid, sigma->delta}};
+        Row prv = {   // lib.rs:1146-1160 without the core commitment
+            {fr_neg(mx.rO_mid), sigma->eta},
+            {mx.rU_X, xh[0]}, {mx.rV_X, xh[3]}, {mx.rW_X[0], xh[6]}, {mx.rW_X[1], xh[7]}, {mx.rW_X[2], xh[8]},
+            {mx.rB_X[0], xj[0]}, {mx.rB_X[1], xj[1]},
+            {mx.rU_Y, yi[0]}, {mx.rV_Y, yi[3]}, {mx.rW_Y[0], yi[6]}, {mx.rW_Y[1], yi[7]}, {mx.rW_Y[2], yi[8]},
+            {mx.rB_Y[0], yi[9]}, {mx.rB_Y[1], yi[10]}};
         size_t width = 0;
-        for (Row *r : {&ru, &rv, &rw, &rb, &rr}) width = std::max(width, r->size());
+        for (Row *r : {&ru, &rv, &rw, &rb, &rr, &mid, &prv}) width = std::max(width, r->size());
         ScalarField zero{};
-        for (Row *r : {&ru, &rv, &rw, &rb, &rr})
+        for (Row *r : {&ru, &rv, &rw, &rb, &rr, &mid, &prv})
             while (r->size() < width) r->push_back({zero, r->front().second});
-        auto b = g1_lincombs({ru, rv, rw, rb, rr}, st);
-        return Blinds{b[0], b[1], b[2], b[3], b[4]};
+        auto b = g1_lincombs({ru, rv, rw, rb, rr, mid, prv}, st);
+        return Blinds{b[0], b[1], b[2], b[3], b[4], b[5], b[6]};
     }
     const Blinds &blinds() const {
         if (blinds_ready.valid()) blinds_ready.get();   // rethrows what the helper met

@@ -618,12 +618,8 @@ class ProverContext {
             tkmk_stream bs = binding_stream_;
             // the helper first makes the proof's blinding points (one small MSM + a host Horner, 2 ms: prove0 needs them at its END, the
             // binding commitments are needed after prove4), then runs the binding batch
-            const bool make_blinds = p->lagrange_n && p->lagrange_mi && p->u_ev.len() && p->v_ev.len() && p->w_ev.len() && p->b_ev.len();
-            std::shared_ptr<std::promise<void>> blinds_done;
-            if (make_blinds) {
-                blinds_done = std::make_shared<std::promise<void>>();
-                p->blinds_ready = blinds_done->get_future().share();
-            }
+            std::shared_ptr<std::promise<void>> blinds_done = std::make_shared<std::promise<void>>();
+            p->blinds_ready = blinds_done->get_future().share();
             Prover *pp = p.get();   // alive until this future has been collected (ProverContext::prove: `pending` goes before the prover)
             pb.cores = std::async(std::launch::async, [binding_jobs, bs, pp, blinds_done] {
                 if (blinds_done) {
@@ -642,7 +638,7 @@ class ProverContext {
             p->timing["init.binding"] = tm.binding, p->timing["init.total"] = tm.init;
             return {std::move(p), b};
         }
-        b = finish_binding(Sigma1::run_jobs(binding_jobs), mx);
+        b = finish_binding(Sigma1::run_jobs(binding_jobs), p->blinds());
         tm.binding = Prover::now() - t3;
         tm.init = Prover::now() - t0;
         p->timing["init.parse"] = tm.parse, p->timing["init.upload"] = tm.upload, p->timing["init.build"] = tm.build;
@@ -650,24 +646,12 @@ class ProverContext {
         return {std::move(p), b};
     }
 
-    // the blinding terms on top of the four core commitments (lib.rs:1100-1160)
-    Binding finish_binding(const std::vector<G1Affine> &cm, const Mixer &mx) const {
-        using namespace prover_detail;
+    // the blinding terms on top of the four core commitments (lib.rs:1100-1160): O_mid = core + rO_mid delta, O_prv = core - rO_mid eta + the
+    // fourteen mixer-weighted CRS points — both sums come with the proof's other blinding points (Prover::Blinds), one affine addition here
+    Binding finish_binding(const std::vector<G1Affine> &cm, const Prover::Blinds &bl) const {
         Binding b;
         b.A_free = cm[0], b.O_pub_free = cm[1];
-        const G1Affine &O_mid_core = cm[2], &O_prv_core = cm[3];
-        const auto &xh = sigma->delta_inv_alphak_xh_tx, &xj = sigma->delta_inv_alpha4_xj_tx, &yi = sigma->delta_inv_alphak_yi_ty;
-        ScalarField zero{};
-        std::vector<std::pair<ScalarField, G1Affine>> mid = {{fr_one(), O_mid_core}, {mx.rO_mid, sigma->delta}};
-        while (mid.size() < 16) mid.push_back({zero, O_mid_core});
-        std::vector<std::pair<ScalarField, G1Affine>> prv = {   // lib.rs:1146-1160
-            {fr_one(), O_prv_core}, {fr_neg(mx.rO_mid), sigma->eta},
-            {mx.rU_X, xh[0]}, {mx.rV_X, xh[3]}, {mx.rW_X[0], xh[6]}, {mx.rW_X[1], xh[7]}, {mx.rW_X[2], xh[8]},
-            {mx.rB_X[0], xj[0]}, {mx.rB_X[1], xj[1]},
-            {mx.rU_Y, yi[0]}, {mx.rV_Y, yi[3]}, {mx.rW_Y[0], yi[6]}, {mx.rW_Y[1], yi[7]}, {mx.rW_Y[2], yi[8]},
-            {mx.rB_Y[0], yi[9]}, {mx.rB_Y[1], yi[10]}};
-        auto both = g1_lincombs({mid, prv});
-        b.O_mid = both[0], b.O_prv = both[1];
+        b.O_mid = fqh::g1_affine_add(cm[2], bl.O_mid), b.O_prv = fqh::g1_affine_add(cm[3], bl.O_prv);
         return b;
     }
 
@@ -706,7 +690,7 @@ class ProverContext {
         }
         if (pending) {   // collect the binding commitments issued during init
             const double tb = Prover::now();
-            proof.binding = finish_binding(pending->cores.get(), mixer);
+            proof.binding = finish_binding(pending->cores.get(), pb.first->blinds());
             pending.reset();
             tm.binding += Prover::now() - tb;
         }
