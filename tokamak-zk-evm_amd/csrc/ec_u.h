@@ -162,7 +162,7 @@ struct ecu {
         E qq = FU::mul(u1, pp);
         X r;
         r.inf = false;
-        r.x = FU::template sub<4>(FU::sqr(rd), FU::add(ppp, FU::dbl(qq)));
+        r.x = FU::template sub<4>(FU::sqr(rd), FU::add_dbl(ppp, qq));
         r.y = FU::mul_add(rd, FU::template sub<8>(qq, r.x), FU::template sub<2>(FU::zero(), s1), ppp);
         r.zz = FU::mul(FU::mul(p.zz, q.zz), pp);
         r.zzz = FU::mul(FU::mul(p.zzz, q.zzz), ppp);
@@ -201,7 +201,7 @@ struct ecu {
         E qq = FU::mul(p.x, pp);
         X r;
         r.inf = false;
-        E t = FU::add(ppp, FU::dbl(qq));
+        E t = FU::add_dbl(ppp, qq);
         r.x = FU::template sub<4>(FU::sqr(rd), t);
         E d = FU::template sub<8>(qq, r.x);
         r.y = FU::mul_add(rd, d, FU::template sub<2>(FU::zero(), p.y), ppp);  // R (Q - X3) + (2p - Y1) PPP, one reduction

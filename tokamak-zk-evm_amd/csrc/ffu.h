@@ -75,6 +75,14 @@ struct ffu {
         return norm(t);
     }
     static FF_HD E dbl(const E &a) { return add(a, a); }
+    // a + 2 b with ONE carry sweep (limbs below 3 * 2^29 before it): the PPP + 2 Q of the addition formulas
+    static FF_HD E add_dbl(const E &a, const E &b) {
+        FFU_ASSERT(strict(a) && strict(b));
+        E t;
+#pragma unroll
+        for (int i = 0; i < L; i++) t.l[i] = a.l[i] + (b.l[i] << 1);
+        return norm(t);
+    }
     // a - b + K p for K in {2, 4, 8, 16}; b must be strict with value < K p (so that every limb of K p's
     // dominating form covers b's limb); the result is strict with value < a + K p
     template <int K>
