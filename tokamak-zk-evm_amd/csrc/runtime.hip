@@ -462,8 +462,12 @@ TK_API tkmk_error tkmk_stream_synchronize(tkmk_stream s) {
     }
     return TKMK_SUCCESS;
 }
+namespace tk_msm_bls12_381 { void drop_pipe_set(hipStream_t caller); }
+namespace tk_msm_bn254 { void drop_pipe_set(hipStream_t caller); }
 TK_API tkmk_error tkmk_stream_destroy(tkmk_stream s) {
     if (!s) return TKMK_SUCCESS;
+    tk_msm_bls12_381::drop_pipe_set(tk_stream(s));   // the MSM pipeline sets that served batches issued on this stream
+    tk_msm_bn254::drop_pipe_set(tk_stream(s));
     {
         std::lock_guard<std::mutex> lk(g_streams_mu);
         for (size_t i = 0; i < g_user_streams.size(); i++)
