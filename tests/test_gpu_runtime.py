@@ -131,3 +131,51 @@ def test_free_then_reuse_waits_for_work_on_caller_streams(gpu, oracle):
         assert (np.asarray(thief.to_host(1 << 16)) == 0xEE).all()
     finally:
         gpu._check(lib.tkmk_stream_destroy(st), "tkmk_stream_destroy")
+
+
+def test_msm_batches_on_two_streams_from_two_threads(gpu, oracle):
+    """include/tkmk.h THREADING: MSM batches that name different caller streams run concurrently, each over its own pipeline set (streams,
+    events, pinned result buffers); batches on one stream take turns.  Two threads each issue batches of four 2^15-point MSMs on their own
+    stream, several times, while the main thread does the same on the default stream: every result equals the oracle's, and a destroyed
+    stream's set is gone with it (a fresh stream afterwards works)."""
+    import threading
+    lib = gpu.lib()
+    n, batch, rounds = 1 << 15, 4, 3
+    bases = oracle.g1_random_bases(71, n)
+    d_bases = gpu.DeviceBuffer.from_host(bases)
+    scal = {k: oracle.fr_random(900 + k, n * batch) for k in range(3)}
+    want = {k: [np.asarray(oracle.g1_msm(scal[k][32 * n * j:32 * n * (j + 1)].copy(), bases)) for j in range(batch)] for k in range(3)}
+    streams = []
+    for _ in range(2):
+        st = ctypes.c_void_p()
+        gpu._check(lib.tkmk_stream_create(ctypes.byref(st)), "tkmk_stream_create")
+        streams.append(st)
+    errors = []
+
+    def work(k, st):
+        try:
+            d_s = gpu.DeviceBuffer.from_host(scal[k])
+            for _ in range(rounds):
+                res = gpu.projective_to_affine_bytes(gpu.msm(d_s, d_bases, msm_size=n, batch=batch, stream=st))
+                for j in range(batch):
+                    if not (res[96 * j:96 * (j + 1)] == want[k][j]).all():
+                        errors.append((k, j))
+        except Exception as e:          # noqa: BLE001 — reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k, streams[k])) for k in range(2)]
+    for t in threads:
+        t.start()
+    work(2, None)
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for st in streams:
+        gpu._check(lib.tkmk_stream_destroy(st), "tkmk_stream_destroy")
+    st = ctypes.c_void_p()
+    gpu._check(lib.tkmk_stream_create(ctypes.byref(st)), "tkmk_stream_create")
+    try:
+        work(0, st)
+        assert not errors, errors
+    finally:
+        gpu._check(lib.tkmk_stream_destroy(st), "tkmk_stream_destroy")
