@@ -114,6 +114,11 @@ tkmk_error tkmk_memset(void *ptr, int value, size_t bytes);
 tkmk_error tkmk_stream_create(tkmk_stream *s);            /* IcicleStream::create */
 tkmk_error tkmk_stream_synchronize(tkmk_stream s);        /* IcicleStream::synchronize */
 tkmk_error tkmk_stream_destroy(tkmk_stream s);            /* IcicleStream::destroy */
+/* Marks a stream as BACKGROUND (on != 0) or foreground again: the accumulate kernels of MSM batches issued on a background stream hold one
+ * workgroup per CU (half their usual share of a CU's registers), so that kernels issued elsewhere at the same time — the polynomial work
+ * a round IS waiting for — find room on every CU.  For commitments nothing waits for until later.  Results are unaffected.  No ICICLE
+ * counterpart (IcicleStream has no priorities: icicle_runtime::stream). */
+tkmk_error tkmk_stream_set_background(tkmk_stream stream, int on);
 tkmk_error tkmk_device_synchronize(void);
 /* scratch used by MSM / NTT calls lives in per-stream grow-only arenas; this returns all of it to the driver */
 tkmk_error tkmk_release_scratch(void);

@@ -31,6 +31,7 @@ tkmk_error tk_map_hip_error(hipError_t e);
 tkmk_error tk_require_device();
 
 static inline hipStream_t tk_stream(tkmk_stream s) { return (hipStream_t)s; }
+bool tk_stream_is_background(hipStream_t s);   // runtime.hip: tkmk_stream_set_background
 
 // Device scratch comes from a per-stream, grow-only arena of plain hipMalloc memory, bump-allocated inside
 // a tk_frame (one per C-ABI call) and recycled when the frame ends.  Launchers therefore never call

@@ -3,6 +3,7 @@
 // (e.g. packages/backend/libs/src/bivariate_polynomial/mod.rs:446-457, libs/src/utils/mod.rs:78-110).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -462,12 +463,28 @@ TK_API tkmk_error tkmk_stream_synchronize(tkmk_stream s) {
     }
     return TKMK_SUCCESS;
 }
+// ---- background streams: MSM batches issued on them yield registers to everything else (csrc/msm_impl.inc) ----
+static std::mutex g_background_mu;
+static std::vector<hipStream_t> g_background;
+bool tk_stream_is_background(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_background_mu);
+    return std::find(g_background.begin(), g_background.end(), s) != g_background.end();
+}
+TK_API tkmk_error tkmk_stream_set_background(tkmk_stream stream, int on) {
+    if (!stream) return TKMK_ERR_INVALID_ARGUMENT;   // the default stream is the foreground by definition
+    std::lock_guard<std::mutex> lk(g_background_mu);
+    auto it = std::find(g_background.begin(), g_background.end(), tk_stream(stream));
+    if (on && it == g_background.end()) g_background.push_back(tk_stream(stream));
+    if (!on && it != g_background.end()) g_background.erase(it);
+    return TKMK_SUCCESS;
+}
 namespace tk_msm_bls12_381 { void drop_pipe_set(hipStream_t caller); }
 namespace tk_msm_bn254 { void drop_pipe_set(hipStream_t caller); }
 TK_API tkmk_error tkmk_stream_destroy(tkmk_stream s) {
     if (!s) return TKMK_SUCCESS;
     tk_msm_bls12_381::drop_pipe_set(tk_stream(s));   // the MSM pipeline sets that served batches issued on this stream
     tk_msm_bn254::drop_pipe_set(tk_stream(s));
+    (void)tkmk_stream_set_background(s, 0);
     {
         std::lock_guard<std::mutex> lk(g_streams_mu);
         for (size_t i = 0; i < g_user_streams.size(); i++)

@@ -85,7 +85,7 @@ class VecOpsConfig(ctypes.Structure):
 SYMBOLS = [
     "tkmk_device_count", "tkmk_set_device", "tkmk_get_available_memory", "tkmk_malloc", "tkmk_malloc_async", "tkmk_free",
     "tkmk_free_async", "tkmk_memcpy_h2d", "tkmk_memcpy_d2h", "tkmk_memcpy_d2d", "tkmk_memcpy_h2d_async",
-    "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy",
+    "tkmk_memcpy_d2h_async", "tkmk_memcpy_2d_d2d", "tkmk_memset", "tkmk_stream_create", "tkmk_stream_synchronize", "tkmk_stream_destroy", "tkmk_stream_set_background",
     "tkmk_device_synchronize", "tkmk_release_scratch", "tkmk_error_string", "tkmk_is_hip_build", "tkmk_keccak256", "tkmk_r1cs_index", "tkmk_msm_default_config", "bls12_381_msm", "bls12_381_g2_msm", "tkmk_g1_ntt", "tkmk_g1_ntt_axes", "tkmk_g1_prefix_sums", "tkmk_g1_scale", "bls12_381_msm_precompute_bases", "bn254_msm_precompute_bases", "tkmk_msm_multi", "bn254_msm", "tkmk_bn254_msm_multi", "bn254_get_root_of_unity", "bn254_ntt_init_domain", "bn254_ntt_release_domain",
     "bn254_ntt", "tkmk_bn254_bintt", "tkmk_bn254_fr_random_device",
     "tkmk_bn254_g1_batch_scalar_mul_device",
