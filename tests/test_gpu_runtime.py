@@ -136,8 +136,8 @@ def test_free_then_reuse_waits_for_work_on_caller_streams(gpu, oracle):
 def test_msm_batches_on_two_streams_from_two_threads(gpu, oracle):
     """include/tkmk.h THREADING: MSM batches that name different caller streams run concurrently, each over its own pipeline set (streams,
     events, pinned result buffers); batches on one stream take turns.  Two threads each issue batches of four 2^15-point MSMs on their own
-    stream, several times, while the main thread does the same on the default stream: every result equals the oracle's, and a destroyed
-    stream's set is gone with it (a fresh stream afterwards works)."""
+    stream (one of them marked background: tkmk_stream_set_background), several times, while the main thread does the same on the default
+    stream: every result equals the oracle's, and a destroyed stream's set is gone with it (a fresh stream afterwards works)."""
     import threading
     lib = gpu.lib()
     n, batch, rounds = 1 << 15, 4, 3
@@ -150,6 +150,9 @@ def test_msm_batches_on_two_streams_from_two_threads(gpu, oracle):
         st = ctypes.c_void_p()
         gpu._check(lib.tkmk_stream_create(ctypes.byref(st)), "tkmk_stream_create")
         streams.append(st)
+    # one of the two is a BACKGROUND stream (its batches' accumulate kernels take one workgroup per CU): same results
+    gpu._check(lib.tkmk_stream_set_background(streams[1], 1), "tkmk_stream_set_background")
+    assert lib.tkmk_stream_set_background(None, 1) != 0        # the default stream is the foreground by definition
     errors = []
 
     def work(k, st):
