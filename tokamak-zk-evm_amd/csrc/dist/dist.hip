@@ -30,8 +30,8 @@ struct loop_group {
     uint64_t generation = 0;
     std::vector<const void *> send;
     std::vector<void *> recv;
-    // libtkmk_hip.so is called from one thread at a time (the reference issues all device calls from its main thread):
-    // the virtual ranks — one host thread each — take turns on the device and give the turn up while they wait in a collective
+    // libtkmk_hip.so takes one host thread at a time PER STREAM (include/tkmk.h, THREADING) and the virtual ranks — one host thread each —
+    // all issue on the default stream: they take turns on the device and give the turn up while they wait in a collective
     std::mutex device_turn;
     explicit loop_group(int w) : world(w), send(w, nullptr), recv(w, nullptr) {}
     bool broken = false;   // a rendezvous timed out: every later one fails at once instead of waiting again
